@@ -1,0 +1,161 @@
+/* tmdiff_hip.h -- C ABI of libtmdiff_hip.so: the MI355X (gfx950) kernels of the TMDiff
+ * denoising hot path.
+ *
+ * The reference (codgodtao/TMDiff) has no FFI of its own: its hot path runs through
+ * PyTorch ATen.  Each entry point below therefore replaces the ATen call sequence of one
+ * reference site (file:line given per function).  Conventions:
+ *   - plain pointers + sizes + a hipStream_t passed as void*; no torch types;
+ *   - every function returns int: 0 = TMDIFF_OK, negative = TMDIFF_E_*; nothing throws
+ *     across the boundary; tmdiff_last_error_string() describes the last failure of the
+ *     calling thread;
+ *   - the library never allocates or frees device memory and never synchronises: the
+ *     caller owns inputs, outputs and workspaces (so calls are HIP-graph capturable);
+ *   - all tensors are dense fp32, 5-D activations are [B, C, N, H, W] (N = spectral
+ *     bands = the conv "depth" axis), row-major, 16-byte aligned base pointers.
+ */
+#ifndef TMDIFF_HIP_H
+#define TMDIFF_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define TMDIFF_ABI_VERSION 1
+
+#define TMDIFF_OK 0
+#define TMDIFF_E_INVALID (-1)     /* bad argument / shape */
+#define TMDIFF_E_UNSUPPORTED (-2) /* valid but not implemented configuration */
+#define TMDIFF_E_LAUNCH (-3)      /* HIP reported an error at launch */
+
+typedef void* tmdiff_stream_t; /* hipStream_t */
+
+int tmdiff_version(void);
+const char* tmdiff_last_error_string(void);
+
+/* ------------------------------------------------------------------------------------
+ * conv3d, kernel 3x3x3 (pad 1) or 1x1x1 (pad 0), stride 1, groups 1 or 3.
+ * Replaces nn.Conv3d / F.conv3d and modulated_conv3d
+ * (GeneralModel/Hyper_unet_general.py:51-77, :161-164, :224-231, :260, :344-361) together
+ * with the elementwise ops the reference runs around them:
+ *   prologue  x' = act(x + in_shift[b,c]) * in_scale[b,c] * in_mask[b,c,n,h,w]
+ *             (temb shift :239, :401; Swish :242, :245, :371, :402; modulation :69 folded
+ *             from the weights onto the input channels; Dropout mask :243, :246, :403)
+ *   epilogue  y = (conv(x') + bias_scale*bias[co] + residual) * out_scale
+ *             (bias; skip additions :249, :408; the 2x of convH_0 :381 via bias_scale)
+ * The input may be given as up to three channel segments that the reference would
+ * torch.cat first (Hyper_unet_general.py:631-634); for groups == 3 segment g is group g's
+ * input (the cat of the three wavelet high bands at :381).
+ * ------------------------------------------------------------------------------------ */
+typedef struct tmdiff_conv3d_desc {
+  int32_t B, N, H, W;
+  int32_t Cin, Cout;   /* totals over all groups */
+  int32_t groups;      /* 1 or 3 */
+  int32_t ksize;       /* 1 or 3 */
+  int32_t nseg;        /* 1..3 input segments */
+  int32_t seg_c[3];    /* channels per segment, sum == Cin (groups==3: each Cin/3) */
+  const float* seg_x[3];
+  const float* w_packed; /* from tmdiff_conv3d_pack_weights */
+  const float* bias;     /* [Cout] or NULL */
+  float bias_scale;
+  const float* in_shift; /* [B, Cin] (row stride in_shift_stride floats) or NULL */
+  const float* in_scale; /* [B, Cin] (row stride in_scale_stride floats) or NULL */
+  int32_t in_shift_stride; /* 0 = dense rows (Cin); > 0 = row stride in floats (a layer's slice of a bank of */
+  int32_t in_scale_stride; /* projections); -1 = one row broadcast over the batch (one prompt for all samples) */
+  const float* in_mask;  /* [B, Cin, N, H, W] multiplicative mask (dropout) or NULL */
+  int32_t in_act;        /* 0 = identity, 1 = SiLU */
+  const float* residual; /* [B, Cout, N, H, W] or NULL */
+  float out_scale;
+  float* y;              /* [B, Cout, N, H, W] */
+} tmdiff_conv3d_desc;
+
+/* w [Cout, Cin/groups, k, k, k] (PyTorch layout) -> packed [g][ci][tap][co] used by the
+ * kernels.  mode 0: forward weights.  mode 1: weights of the data-gradient convolution
+ * (taps flipped, ci/co swapped): conv3d_fwd(dy, packed_mode1) == dL/dx'.
+ * packed must hold Cout*Cin/groups*k^3 floats. */
+int tmdiff_conv3d_pack_weights(const float* w, float* packed, int32_t Cout, int32_t Cin, int32_t ksize,
+                               int32_t groups, int32_t mode, tmdiff_stream_t stream);
+int tmdiff_conv3d_fwd(const tmdiff_conv3d_desc* d, tmdiff_stream_t stream);
+
+/* ------------------------------------------------------------------------------------
+ * Stem / head pointwise convolutions (bandwidth kernels):
+ *  stem: y[b,co,p] = SiLU(w[co]*x[b,p] + bias[co])            AdaptionModulateBEST.conv20 + act (:169-170)
+ *        x is given as pan[b,1,H,W] broadcast over N minus ms[b,N,H,W] when `ms` != NULL
+ *        (WavBEST.forward :605-608), else x = xin[b,N,H,W] (to3D(x_t) :609).
+ *  head: y[b,p] = sum_c w[c]*scale[b,c]*SiLU(x[b,c,p])         FinalBlock act + modulated conv24 (:270-272)
+ * ------------------------------------------------------------------------------------ */
+int tmdiff_stem_fwd(const float* xin, const float* pan, const float* ms, const float* w, const float* bias, float* y,
+                    int32_t B, int32_t Cout, int32_t N, int32_t H, int32_t W, int32_t apply_silu,
+                    tmdiff_stream_t stream);
+int tmdiff_head_fwd(const float* x, const float* w, const float* scale, int32_t scale_stride, float* y, int32_t B,
+                    int32_t C, int64_t P, tmdiff_stream_t stream); /* scale_stride as in_scale_stride above */
+
+/* ------------------------------------------------------------------------------------
+ * 2-D Haar DWT / IDWT on the (H, W) axes of [B*C*N, H, W] planes.
+ * Replaces DWT_2D / IDWT_2D (DWT_IDWT/DWT_IDWT_layer.py:256-334, :337-430) and
+ * DWTFunction_2D / IDWTFunction_2D (DWT_IDWT/DWT_IDWT_Functions.py:47-69, :89-112).
+ *  dwt:  ll = ll_scale * LL(x); lh/hl/hh = hi_scale * {LH,HL,HH}(x) (NULL = band not needed)
+ *        (the /2 of WaveletUPorDown :396 is ll_scale = 0.5).
+ *  idwt: out_k = IDWT(in_scale * ll_k, lh, hl, hh) for k < n_ll low bands sharing the same
+ *        high bands (the two iwt calls with 2*h and 2*x at :383-386 are one launch).  The high
+ *        bands may be channel slices of one [B, 3C, N, h, w] tensor (the convH_0 output, :381-384):
+ *        hi_planes_per_batch = C*N planes per sample, hi_batch_stride = floats between samples
+ *        (0 = dense [planes, h, w] bands).
+ * The adjoint of dwt is idwt and vice versa (orthonormal transform), which is how the
+ * backward passes are served.
+ * ------------------------------------------------------------------------------------ */
+int tmdiff_haar_dwt2d(const float* x, float* ll, float* lh, float* hl, float* hh, int64_t planes, int32_t H,
+                      int32_t W, float ll_scale, float hi_scale, tmdiff_stream_t stream);
+int tmdiff_haar_idwt2d(const float* const ll[2], int32_t n_ll, const float* lh, const float* hl, const float* hh,
+                       int64_t hi_planes_per_batch, int64_t hi_batch_stride, float* const out[2], int64_t planes,
+                       int32_t h, int32_t w, float in_scale, tmdiff_stream_t stream);
+
+/* ------------------------------------------------------------------------------------
+ * Small dense layers: y[b,o] = act(sum_i x[b,i]*w[o,i] + bias[o]); nn.Linear (+Swish) of the
+ * embedding MLPs and every Dense() modulation projection (Hyper_unet_general.py:100-108,
+ * :529-532).  One launch serves a whole bank of projections: w is [O_total, I].
+ * gamma_embedding (:80-97): emb[b, :half] = cos(t*f), emb[b, half:2*half] = sin(t*f), zero pad if dim is
+ * odd; freqs[half] is the host-computed fp32 table exp(-ln(1e4)*k/half) (a 1-ulp difference in f
+ * would be amplified by t ~ 1000, so the table is not recomputed on the device).
+ * ------------------------------------------------------------------------------------ */
+int tmdiff_linear_fwd(const float* x, const float* w, const float* bias, float* y, int32_t B, int32_t I, int32_t O,
+                      int32_t act, tmdiff_stream_t stream);
+int tmdiff_gamma_embedding(const float* t, const float* freqs, float* emb, int32_t B, int32_t dim,
+                           tmdiff_stream_t stream);
+
+/* ------------------------------------------------------------------------------------
+ * Sampler elementwise updates.
+ *  ddpm_step: one reverse step of GeneralDiffusion.p_sample (diffusion_general.py:203-208 with
+ *    :376-378, :192-194, :134-138):  x0 = clamp(c_recip*x - c_recipm1*eps, -1, 1);
+ *    out = coef1*x0 + coef2*x + sigma*noise   (noise may be NULL when sigma == 0)
+ *    and optionally img_out = out + ms (res2img, utils/util.py:135-137).
+ *  axpby: out = sum_{k<n} coef[k] * in[k], n <= 4: every DPM-Solver update
+ *    (core/dpm_solver_pytorch.py:563-927).
+ *  x0_from_model: DPM-Solver++ data prediction for an x_start-parameterised network
+ *    (dpm_solver_pytorch.py:302-306 then :447-456): eps = (x - alpha*out)/sigma;
+ *    x0 = (x - sigma*eps)/alpha.
+ *  abs_quantile_clamp: dynamic thresholding (:430-439): per sample s = max(quantile(|x0|, q), max_val)
+ *    (linear interpolation between order statistics, as torch.quantile), x0 = clamp(x0,-s,s)/s.
+ *    workspace: tmdiff_abs_quantile_workspace_bytes(B, n) bytes.
+ * ------------------------------------------------------------------------------------ */
+int tmdiff_ddpm_step(const float* x, const float* eps, const float* noise, const float* ms, float* out,
+                     float* img_out, int64_t n, float c_recip, float c_recipm1, float coef1, float coef2,
+                     float sigma, int32_t clip, tmdiff_stream_t stream);
+int tmdiff_axpby(const float* const in[4], const float coef[4], int32_t n_in, float* out, int64_t n,
+                 tmdiff_stream_t stream);
+int tmdiff_x0_from_model(const float* x, const float* model_out, float* x0, int64_t n, float alpha, float sigma,
+                         int32_t model_is_x_start, tmdiff_stream_t stream);
+size_t tmdiff_abs_quantile_workspace_bytes(int32_t B, int64_t n_per_sample);
+int tmdiff_abs_quantile_clamp(float* x0, int32_t B, int64_t n_per_sample, float q, float max_val, void* workspace,
+                              tmdiff_stream_t stream);
+/* out = a + b (res2img / img2res with sign), q_sample: out = a[b]*x0 + sqrt(1-a[b]^2)*noise. */
+int tmdiff_add(const float* a, const float* b, float* out, int64_t n, float sign_b, tmdiff_stream_t stream);
+int tmdiff_q_sample(const float* x0, const float* noise, const float* a, float* out, int32_t B, int64_t n_per_sample,
+                    tmdiff_stream_t stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* TMDIFF_HIP_H */

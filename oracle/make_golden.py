@@ -252,7 +252,7 @@ def main():
     arrs["thresh_in_seed"] = np.asarray(151)
     arrs["thresh_out"] = solver.dynamic_thresholding_fn(x0, None)
     # other solver families on a closed-form "model" (cheap, exercises every update rule)
-    toy = lambda x, t: 0.3 * x + 0.1 * torch.sin(3.0 * x) * t.view(-1, 1, 1, 1)
+    toy = lambda x, t: 0.3 * x + 0.1 * torch.tanh(x) * t.view(-1, 1, 1, 1)   # Lipschitz: no chaotic error growth
     xT = randn(152, 2, 4, 8, 8)
     for algo in ("dpmsolver", "dpmsolver++"):
         for method, order, skip, stype in (("singlestep", 3, "logSNR", "dpmsolver"), ("singlestep", 2, "time_uniform", "taylor"),

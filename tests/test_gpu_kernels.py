@@ -1,0 +1,288 @@
+"""GPU parity tests: every C-ABI kernel against the CPU oracle / plain PyTorch fp32 on the same
+seeded inputs.  Run on the MI355X box with ``pytest -m gpu``."""
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+from conftest import assert_close, rel_err
+from oracle import unet_ref as U
+from oracle.haar_ref import haar_dwt2d, haar_idwt2d
+from oracle.make_golden import TINY, FULL, case_inputs, randn
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def ops():
+    assert torch.cuda.is_available(), "these tests need the MI355X"
+    from tmdiff_amd import ops as _ops
+    return _ops
+
+
+def cu(t):
+    return t.cuda().contiguous()
+
+
+# ---------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("shape", [(2, 6, 8, 8), (1, 16, 16, 12), (3, 5, 64, 64), (2, 3, 6, 10), (1, 1, 2, 2)])
+def test_haar_dwt_idwt(ops, shape, golden):
+    x = randn(11, *shape)
+    want = haar_dwt2d(x)
+    got = ops.haar_dwt2d(cu(x))
+    for w, g in zip(want, got):
+        assert_close(g.cpu(), w, 1e-6, 1e-6, "dwt band")
+    ll_only = ops.haar_dwt2d(cu(x), want_high=False, ll_scale=0.5)
+    assert ll_only[1] is None
+    assert torch.equal(ll_only[0].cpu(), got[0].cpu() * 0.5)          # /2 is exact
+    bands = [randn(20 + i, *want[0].shape) for i in range(4)]
+    y = ops.haar_idwt2d([cu(bands[0])], *[cu(b) for b in bands[1:]])[0]
+    assert_close(y.cpu(), haar_idwt2d(*bands), 1e-6, 1e-6, "idwt")
+    rec = ops.haar_idwt2d([got[0]], got[1], got[2], got[3])[0]
+    assert_close(rec.cpu(), x, 2e-6, 2e-6, "perfect reconstruction")
+    if shape == (2, 6, 8, 8):
+        g = golden("haar")
+        assert_close(got[0].cpu(), g["a_ll"], 1e-6, 1e-6, "dwt vs reference fixture")
+        assert_close(y.cpu(), g["a_idwt"], 1e-6, 1e-6, "idwt vs reference fixture")
+
+
+def test_haar_idwt_two_lowbands_stacked(ops):
+    b, c, n, h, w = 2, 3, 4, 8, 8
+    hb, xb = randn(1, b, c, n, h, w), randn(2, b, c, n, h, w)
+    bands = randn(3, b, 3 * c, n, h, w)
+    outs = ops.haar_idwt2d([cu(hb), cu(xb)], None, None, None, in_scale=2.0, stacked_bands=cu(bands))
+    fold = lambda v: v.reshape(b, -1, h, w)
+    lh, hl, hh = fold(bands[:, :c]), fold(bands[:, c:2 * c]), fold(bands[:, 2 * c:])
+    for got, low in zip(outs, (hb, xb)):
+        want = haar_idwt2d(2.0 * fold(low), lh, hl, hh).reshape(b, c, n, 2 * h, 2 * w)
+        assert_close(got.cpu(), want, 1e-6, 1e-6, "stacked idwt")
+
+
+def test_haar_rejects_odd_sizes(ops):
+    from tmdiff_amd._lib import TmdiffError
+    with pytest.raises(TmdiffError):
+        ops.haar_dwt2d(torch.zeros(1, 1, 3, 4, device="cuda"))
+
+
+# ---------------------------------------------------------------------------------------------
+CONV_CASES = [
+    # B, Cin, Cout, N, H, W, k, groups
+    (2, 8, 8, 4, 8, 8, 3, 1),
+    (1, 5, 7, 4, 6, 6, 3, 1),       # odd channels, partial tile
+    (2, 32, 64, 8, 16, 16, 3, 1),
+    (1, 64, 64, 8, 16, 16, 3, 1),
+    (3, 4, 12, 8, 2, 2, 3, 1),      # tiny spatial
+    (2, 12, 8, 3, 10, 12, 3, 1),    # N=3, ragged
+    (2, 16, 32, 8, 16, 16, 1, 1),
+    (1, 5, 3, 4, 6, 6, 1, 1),
+    (2, 24, 12, 8, 8, 8, 3, 3),     # grouped
+    (1, 96, 32, 8, 8, 8, 3, 1),
+    (1, 40, 96, 4, 8, 8, 3, 1),     # cout 96: one full + one partial 64-tile
+]
+
+
+@pytest.mark.parametrize("case", CONV_CASES)
+def test_conv3d_plain(ops, case):
+    b, ci, co, n, h, w, k, g = case
+    x = randn(1, b, ci, n, h, w)
+    wt = randn(2, co, ci // g, k, k, k) / (ci // g * k ** 3) ** 0.5
+    bias = randn(3, co)
+    want = F.conv3d(x, wt, bias, 1, k // 2, 1, g)
+    wp = ops.pack_conv_weight(cu(wt), groups=g)
+    got = ops.conv3d([cu(x)], wp, co, k, groups=g, bias=cu(bias))
+    assert_close(got.cpu(), want, 1e-5, 1e-5, f"conv3d {case}")
+
+
+def test_conv3d_fused_prologue_epilogue_segments(ops):
+    b, n, h, w = 3, 8, 16, 16
+    segs = [randn(10 + i, b, c, n, h, w) for i, c in enumerate((8, 16, 8))]
+    ci, co = 32, 24
+    wt = randn(2, co, ci, 3, 3, 3) / (ci * 27) ** 0.5
+    bias, shift, scale = randn(3, co), randn(4, b, ci), 1 + 0.3 * randn(5, b, ci)
+    res = randn(6, b, co, n, h, w)
+    mask = (torch.rand(b, ci, n, h, w, generator=torch.Generator().manual_seed(7)) > 0.2).float() / 0.8
+    xin = torch.cat(segs, 1)
+    xp = U.silu(xin + shift[:, :, None, None, None]) * scale[:, :, None, None, None] * mask
+    want = (F.conv3d(xp, wt, None, 1, 1) + 2.0 * bias[None, :, None, None, None] + res) * 0.5
+    wp = ops.pack_conv_weight(cu(wt))
+    got = ops.conv3d([cu(s) for s in segs], wp, co, 3, bias=cu(bias), bias_scale=2.0, in_shift=cu(shift),
+                     in_scale=cu(scale), in_act=True, in_mask=cu(mask), residual=cu(res), out_scale=0.5)
+    assert_close(got.cpu(), want, 1e-5, 1e-5, "fused conv")
+    # padding must stay exactly zero under the prologue: an all-zero input with a shift still sees zero halo
+    z = torch.zeros(1, 4, 4, 8, 8)
+    sh = torch.full((1, 4), 0.7)
+    w2 = randn(8, 4, 4, 3, 3, 3)
+    want = F.conv3d(U.silu(z + 0.7), w2, None, 1, 1)
+    got = ops.conv3d([cu(z)], ops.pack_conv_weight(cu(w2)), 4, 3, in_shift=cu(sh), in_act=True)
+    assert_close(got.cpu(), want, 1e-5, 1e-5, "zero padding after the prologue")
+    # bank-style strided / broadcast modulation rows
+    bank = randn(9, b, 100)
+    got = ops.conv3d([cu(xin)], wp, co, 3, in_scale=cu(bank).data_ptr() + 4 * 10, scale_stride=100)
+    want = F.conv3d(xin * bank[:, 10:42, None, None, None], wt, None, 1, 1)
+    assert_close(got.cpu(), want, 1e-5, 1e-5, "strided scale rows")
+    got = ops.conv3d([cu(xin)], wp, co, 3, in_scale=cu(bank[:1, 10:42]), scale_stride=-1)
+    want = F.conv3d(xin * bank[:1, 10:42, None, None, None], wt, None, 1, 1)
+    assert_close(got.cpu(), want, 1e-5, 1e-5, "broadcast scale row")
+
+
+def test_conv3d_modulated_matches_reference_fixture(ops, golden):
+    g = golden("modconv")
+    for b in (1, 3):
+        for k in (1, 3):
+            x = randn(40, b, 5, 4, 6, 6)
+            w = randn(41, 7, 5, k, k, k) / (5 * k ** 3) ** 0.5
+            s = (1 + 0.3 * randn(42, b, 5, 1, 1))
+            got = ops.conv3d([cu(x)], ops.pack_conv_weight(cu(w)), 7, k, in_scale=cu(s.reshape(b, 5)))
+            assert_close(got.cpu(), g[f"b{b}k{k}_y"], 1e-5, 1e-5, "modulated conv vs reference")
+
+
+def test_conv3d_rejects_bad_args(ops):
+    from tmdiff_amd._lib import TmdiffError
+    x = torch.zeros(1, 4, 4, 8, 8, device="cuda")
+    wp = torch.zeros(4 * 4 * 27, device="cuda")
+    with pytest.raises(TmdiffError):
+        ops.conv3d([x], wp, 4, 5)                      # ksize 5
+    with pytest.raises(TmdiffError):
+        ops.conv3d([x], wp, 4, 3, groups=2)
+    with pytest.raises(ValueError):
+        ops.conv3d([x.cpu()], wp, 4, 3)
+    y = ops.conv3d([x[:0]], wp, 4, 3)                  # empty batch is a no-op
+    assert y.shape[0] == 0
+
+
+# ---------------------------------------------------------------------------------------------
+def test_stem_head_linear_gamma(ops, golden):
+    b, n, h, w, c0 = 2, 8, 16, 16, 12
+    d = case_inputs(5, b, n, h, w)
+    wt, bias = randn(1, c0), randn(2, c0)
+    cond = (d["PAN"].repeat(1, n, 1, 1) - d["MS"]).unsqueeze(1)
+    want = U.silu(cond * wt[None, :, None, None, None] + bias[None, :, None, None, None])
+    got = ops.stem(cu(wt), cu(bias), c0, pan=cu(d["PAN"]), ms=cu(d["MS"]))
+    assert_close(got.cpu(), want, 1e-6, 1e-6, "stem(pan-ms)")
+    got = ops.stem(cu(wt), cu(bias), c0, xin=cu(d["x_t"]))
+    want = U.silu(d["x_t"].unsqueeze(1) * wt[None, :, None, None, None] + bias[None, :, None, None, None])
+    assert_close(got.cpu(), want, 1e-6, 1e-6, "stem(x)")
+    x5 = randn(3, b, c0, n, h, w)
+    s = 1 + 0.2 * randn(4, b, c0)
+    want = (U.silu(x5) * (wt[None] * s)[:, :, None, None, None]).sum(1)
+    assert_close(ops.head(cu(x5), cu(wt), cu(s)).cpu(), want, 2e-6, 2e-6, "head")
+    for i, o in ((32, 128), (768, 512), (128, 3000), (100, 7)):
+        x, wl, bl = randn(5, 5, i), randn(6, o, i) / i ** 0.5, randn(7, o)
+        assert_close(ops.linear(cu(x), cu(wl), cu(bl)).cpu(), F.linear(x, wl, bl), 2e-6, 2e-6, "linear")
+        assert_close(ops.linear(cu(x), cu(wl), cu(bl), act=True).cpu(), U.silu(F.linear(x, wl, bl)), 2e-6, 2e-6)
+    g = golden("gamma_embedding")
+    freqs = torch.exp(-np.log(10000) * torch.arange(16, dtype=torch.float32) / 16)
+    for key_t, key_e in (("t_int", "e_int"), ("t_frac", "e_frac")):
+        t = torch.tensor(g[key_t]).float()
+        got = ops.gamma_embedding(cu(t), cu(freqs), 32).cpu()
+        assert np.abs(got.numpy() - g[key_e]).max() <= 1e-6
+
+
+# ---------------------------------------------------------------------------------------------
+def test_sampler_kernels(ops, golden):
+    x, e, nz, ms = (randn(i, 3, 8, 16, 16) for i in range(4))
+    a, bq, c1, c2, sg = 1.25, 0.75, 0.3, 0.69, 0.11
+    x0 = (a * x - bq * e).clamp(-1, 1)
+    want = c1 * x0 + c2 * x + nz * sg
+    img = torch.empty_like(x).cuda()
+    got = ops.ddpm_step(cu(x), cu(e), cu(nz), a, bq, c1, c2, sg, ms=cu(ms), img_out=img)
+    assert_close(got.cpu(), want, 1e-6, 1e-6, "ddpm step")
+    assert_close(img.cpu(), want + ms, 1e-6, 1e-6, "ddpm step image")
+    got = ops.ddpm_step(cu(x), cu(e), None, a, bq, c1, c2, 0.0)
+    assert_close(got.cpu(), c1 * x0 + c2 * x, 1e-6, 1e-6, "ddpm last step")
+    want = 0.5 * x - 1.5 * e + 0.25 * nz
+    assert_close(ops.axpby([cu(x), cu(e), cu(nz)], [0.5, -1.5, 0.25]).cpu(), want, 1e-6, 1e-6, "axpby3")
+    assert_close(ops.axpby([cu(x), cu(e), cu(nz), cu(ms)], [0.5, -1.5, 0.25, 2.0]).cpu(), want + 2 * ms, 1e-6, 1e-6)
+    al, sd = 0.8, 0.6
+    eps = (x - al * e) / sd
+    assert_close(ops.x0_from_model(cu(x), cu(e), al, sd).cpu(), (x - sd * eps) / al, 1e-5, 1e-5, "x0")
+    assert_close(ops.add(cu(x), cu(ms)).cpu(), x + ms, 0, 0, "add")
+    assert_close(ops.add(cu(x), cu(ms), -1.0).cpu(), x - ms, 0, 0, "sub")
+    av = torch.tensor([0.9, 0.5, 0.1])
+    want = av.view(-1, 1, 1, 1) * x + (1 - av.view(-1, 1, 1, 1) ** 2).sqrt() * e
+    assert_close(ops.q_sample(cu(x), cu(e), cu(av)).cpu(), want, 1e-6, 1e-6, "q_sample")
+    # dynamic thresholding against torch.quantile and the reference fixture
+    g = golden("dpm_solver")
+    x0 = randn(151, 3, 8, 16, 16)
+    x0[0, 0, 0, :5] = torch.tensor([9.0, -7.0, 5.0, 30.0, -2.5])
+    x0[1] *= 0.2
+    t = cu(x0.clone())
+    s = ops.abs_quantile_clamp_(t, 0.995, 1.0)
+    want_s = torch.maximum(torch.quantile(x0.abs().reshape(3, -1), 0.995, dim=1), torch.ones(3))
+    assert_close(s.cpu(), want_s, 1e-7, 1e-7, "quantile threshold")
+    assert_close(t.cpu(), g["thresh_out"], 1e-6, 1e-6, "dynamic thresholding vs reference")
+    for n, q in ((1000, 0.5), (4097, 0.995), (37, 1.0), (64, 0.0)):
+        v = randn(n, 2, n)
+        t = cu(v.clone())
+        s = ops.abs_quantile_clamp_(t, q, 0.0)
+        assert_close(s.cpu(), torch.quantile(v.abs(), q, dim=1), 1e-6, 1e-6, f"quantile n={n} q={q}")
+
+
+# ---------------------------------------------------------------------------------------------
+@pytest.fixture(scope="module")
+def nets():
+    from tmdiff_amd.Hyper_unet_general import WavBEST
+    ref = U.fill_weights_(U.WavBESTRef(channels=TINY)).eval()
+    hip = WavBEST(channels=TINY)
+    hip.load_state_dict(ref.state_dict())
+    return ref, hip.cuda().eval()
+
+
+def test_unet_tiny_vs_oracle_and_fixture(nets, golden):
+    ref, hip = nets
+    g = golden("unet_tiny")
+    for c in (4, 8):
+        d = case_inputs(100 + c, 2, c, 16)
+        for prompt in ("QB", "WV3", "GF2", "WV2", "WV4"):
+            t = torch.tensor([[3], [977]])
+            y = hip(cu(d["x_t"]), t.cuda(), cu(d["PAN"]), cu(d["MS"]), prompt).cpu()
+            assert_close(y, g[f"c{c}_{prompt}_int"], 1e-4, 1e-5, f"unet vs reference c{c} {prompt}")
+            with torch.no_grad():
+                assert_close(y, ref(d["x_t"], t, d["PAN"], d["MS"], prompt), 1e-4, 1e-5, "unet vs oracle")
+        y = hip(cu(d["x_t"]), torch.tensor([0.25, 731.4]).cuda(), cu(d["PAN"]), cu(d["MS"]), "WV3").cpu()
+        assert_close(y, g[f"c{c}_WV3_frac"], 1e-4, 1e-5, "fractional t")
+    d = case_inputs(120, 1, 8, 32, 16)
+    y = hip(cu(d["x_t"]), torch.tensor([[500]]).cuda(), cu(d["PAN"]), cu(d["MS"]), "WV3").cpu()
+    assert_close(y, g["nonsquare"], 1e-4, 1e-5, "non-square tile")
+    with pytest.raises(AttributeError):
+        hip(cu(d["x_t"]), torch.tensor([[500]]).cuda(), cu(d["PAN"]), cu(d["MS"]), "LANDSAT")
+
+
+def test_unet_condition_cache_and_per_sample_prompts(nets):
+    ref, hip = nets
+    d = case_inputs(7, 2, 8, 16)
+    pan, ms = cu(d["PAN"]), cu(d["MS"])
+    t = torch.tensor([[10], [400]]).cuda()
+    base = hip(cu(d["x_t"]), t, pan, ms, "GF2")
+    hip.begin_condition_cache(pan, ms, "GF2")
+    try:
+        again = hip(cu(d["x_t"]), t, pan, ms, "GF2")
+        other = hip(cu(d["x_t"]) * 0.5, t, pan, ms, "GF2")
+    finally:
+        hip.end_condition_cache()
+    assert torch.equal(base, again)
+    assert not torch.equal(base, other)
+    mixed = hip(cu(d["x_t"]), t, pan, ms, ["GF2", "WV3"]).cpu()
+    with torch.no_grad():
+        w0 = ref(d["x_t"][:1], t[:1].cpu(), d["PAN"][:1], d["MS"][:1], "GF2")
+        w1 = ref(d["x_t"][1:], t[1:].cpu(), d["PAN"][1:], d["MS"][1:], "WV3")
+    assert_close(mixed, torch.cat([w0, w1]), 1e-4, 1e-5, "per-sample prompts")
+
+
+def test_unet_full_width_vs_reference_fixture(golden):
+    from tmdiff_amd.Hyper_unet_general import WavBEST
+    ref = U.fill_weights_(U.WavBESTRef(channels=FULL))
+    hip = WavBEST(channels=FULL)
+    hip.load_state_dict(ref.state_dict())
+    hip = hip.cuda().eval()
+    d = case_inputs(3407, 1, 8, 64)
+    y = hip(cu(d["x_t"]), torch.tensor([[250]]).cuda(), cu(d["PAN"]), cu(d["MS"]), "WV3").cpu()
+    m, l2 = rel_err(y, golden("unet_full")["y"])
+    print(f"full-width forward vs reference: max-rel {m:.3e} rel-L2 {l2:.3e}")
+    assert m <= 1e-4 and l2 <= 1e-5     # SURVEY 8(d) single-forward tolerance
+    # batch consistency at the benchmark batch size: 4 copies of the tile give 4 identical outputs
+    x4 = [cu(d[k].repeat(4, 1, 1, 1)) for k in ("x_t", "PAN", "MS")]
+    y4 = hip(x4[0], torch.full((4, 1), 250).cuda(), x4[1], x4[2], "WV3").cpu()
+    for i in range(4):
+        assert torch.equal(y4[i], y4[0])
+    assert_close(y4[:1], y, 1e-6, 1e-6, "batch-4 vs batch-1")

@@ -1,0 +1,80 @@
+"""ctypes binding of libtmdiff_hip.so (include/tmdiff_hip.h).
+
+The library is the product: if it is missing or fails to load, importing this module
+raises -- there is no CPU or PyTorch fallback behind it.
+"""
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libtmdiff_hip.so")
+
+c_float_p = C.POINTER(C.c_float)
+vp = C.c_void_p
+
+
+class Conv3dDesc(C.Structure):
+    """struct tmdiff_conv3d_desc"""
+    _fields_ = [
+        ("B", C.c_int32), ("N", C.c_int32), ("H", C.c_int32), ("W", C.c_int32),
+        ("Cin", C.c_int32), ("Cout", C.c_int32),
+        ("groups", C.c_int32), ("ksize", C.c_int32), ("nseg", C.c_int32),
+        ("seg_c", C.c_int32 * 3),
+        ("seg_x", vp * 3),
+        ("w_packed", vp), ("bias", vp), ("bias_scale", C.c_float),
+        ("in_shift", vp), ("in_scale", vp), ("in_shift_stride", C.c_int32), ("in_scale_stride", C.c_int32),
+        ("in_mask", vp), ("in_act", C.c_int32),
+        ("residual", vp), ("out_scale", C.c_float),
+        ("y", vp),
+    ]
+
+
+# name -> (restype, argtypes); mirrors include/tmdiff_hip.h one to one
+SIGNATURES = {
+    "tmdiff_version": (C.c_int, []),
+    "tmdiff_last_error_string": (C.c_char_p, []),
+    "tmdiff_conv3d_pack_weights": (C.c_int, [vp, vp, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32, vp]),
+    "tmdiff_conv3d_fwd": (C.c_int, [C.POINTER(Conv3dDesc), vp]),
+    "tmdiff_stem_fwd": (C.c_int, [vp, vp, vp, vp, vp, vp, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32,
+                                  C.c_int32, vp]),
+    "tmdiff_head_fwd": (C.c_int, [vp, vp, vp, C.c_int32, vp, C.c_int32, C.c_int32, C.c_int64, vp]),
+    "tmdiff_haar_dwt2d": (C.c_int, [vp, vp, vp, vp, vp, C.c_int64, C.c_int32, C.c_int32, C.c_float, C.c_float, vp]),
+    "tmdiff_haar_idwt2d": (C.c_int, [vp * 2, C.c_int32, vp, vp, vp, C.c_int64, C.c_int64, vp * 2, C.c_int64,
+                                     C.c_int32, C.c_int32, C.c_float, vp]),
+    "tmdiff_linear_fwd": (C.c_int, [vp, vp, vp, vp, C.c_int32, C.c_int32, C.c_int32, C.c_int32, vp]),
+    "tmdiff_gamma_embedding": (C.c_int, [vp, vp, vp, C.c_int32, C.c_int32, vp]),
+    "tmdiff_ddpm_step": (C.c_int, [vp, vp, vp, vp, vp, vp, C.c_int64, C.c_float, C.c_float, C.c_float, C.c_float,
+                                   C.c_float, C.c_int32, vp]),
+    "tmdiff_axpby": (C.c_int, [vp * 4, C.c_float * 4, C.c_int32, vp, C.c_int64, vp]),
+    "tmdiff_x0_from_model": (C.c_int, [vp, vp, vp, C.c_int64, C.c_float, C.c_float, C.c_int32, vp]),
+    "tmdiff_abs_quantile_workspace_bytes": (C.c_size_t, [C.c_int32, C.c_int64]),
+    "tmdiff_abs_quantile_clamp": (C.c_int, [vp, C.c_int32, C.c_int64, C.c_float, C.c_float, vp, vp]),
+    "tmdiff_add": (C.c_int, [vp, vp, vp, C.c_int64, C.c_float, vp]),
+    "tmdiff_q_sample": (C.c_int, [vp, vp, vp, vp, C.c_int32, C.c_int64, vp]),
+}
+
+
+class TmdiffError(RuntimeError):
+    """Non-zero status from the C ABI (the reference surfaces errors as ordinary exceptions)."""
+
+
+def _load():
+    if not os.path.exists(LIB_PATH):
+        raise ImportError(
+            f"{LIB_PATH} is missing: build it with `make` (or `python -c 'import __graft_entry__ as g; g.build()'`). "
+            "tmdiff_amd has no CPU fallback.")
+    lib = C.CDLL(LIB_PATH)
+    for name, (res, args) in SIGNATURES.items():
+        fn = getattr(lib, name)          # AttributeError here == header/library mismatch
+        fn.restype, fn.argtypes = res, args
+    return lib
+
+
+lib = _load()
+ABI_VERSION = lib.tmdiff_version()
+
+
+def check(status, what=""):
+    if status != 0:
+        msg = lib.tmdiff_last_error_string().decode("utf-8", "replace")
+        raise TmdiffError(f"{what or 'tmdiff'} failed with status {status}: {msg}")

@@ -1,0 +1,196 @@
+// 2-D Haar DWT / IDWT butterflies for gfx950.  HBM-bound: every element is read once and
+// written once, 16 bytes per lane when the row length allows it.
+//
+// Reference: DWT_IDWT/DWT_IDWT_layer.py:256-334, :337-430 and DWT_IDWT_Functions.py:47-69,
+// :89-112, which build dense [H/2,H] / [W,W/2] filter matrices on every call and run six
+// batched GEMMs.  The only non-zero taps are +-s, s = fp32(1/sqrt(2)); the two-stage
+// evaluation below (rows, then columns, one multiply by s per stage) keeps the reference's
+// rounding order:  L = s*top + s*bot,  LL = s*L[even] + s*L[odd], ...
+#include "common.h"
+
+namespace {
+
+constexpr float kS = 0.70710678118654752440f;  // fp32(1/sqrt(2)) == 0x3F3504F3
+
+template <int V>
+struct Vec;
+template <>
+struct Vec<1> {
+  using in_t = float2;
+  using out_t = float;
+};
+template <>
+struct Vec<4> {
+  using in_t = float4;  // two of them per row
+  using out_t = float4;
+};
+
+__device__ __forceinline__ void butterfly(float a, float b, float c, float d, float& ll, float& lh, float& hl,
+                                          float& hh) {
+  // a=x[2i,2j] b=x[2i,2j+1] c=x[2i+1,2j] d=x[2i+1,2j+1]
+  const float lo0 = kS * a + kS * c, lo1 = kS * b + kS * d;  // L  = L0 @ X   (low rows)
+  const float hi0 = kS * a - kS * c, hi1 = kS * b - kS * d;  // Hh = H0 @ X   (high rows)
+  ll = kS * lo0 + kS * lo1;
+  lh = kS * lo0 - kS * lo1;
+  hl = kS * hi0 + kS * hi1;
+  hh = kS * hi0 - kS * hi1;
+}
+
+__device__ __forceinline__ void inv_butterfly(float ll, float lh, float hl, float hh, float& a, float& b, float& c,
+                                              float& d) {
+  const float lo0 = kS * ll + kS * lh, lo1 = kS * ll - kS * lh;  // L  = LL @ L1^T + LH @ H1^T
+  const float hi0 = kS * hl + kS * hh, hi1 = kS * hl - kS * hh;  // Hh = HL @ L1^T + HH @ H1^T
+  a = kS * lo0 + kS * hi0;
+  b = kS * lo1 + kS * hi1;
+  c = kS * lo0 - kS * hi0;
+  d = kS * lo1 - kS * hi1;
+}
+
+// One thread -> V adjacent output columns of one output row.  grid-stride over all outputs.
+template <int V>
+__global__ void __launch_bounds__(256) dwt2d_kernel(const float* __restrict__ x, float* __restrict__ ll,
+                                                    float* __restrict__ lh, float* __restrict__ hl,
+                                                    float* __restrict__ hh, long total, int h, int w, float ll_scale,
+                                                    float hi_scale) {
+  const int wv = w / V;  // vector columns per output row
+  const int W = 2 * w;
+  for (long i = blockIdx.x * 256L + threadIdx.x; i < total; i += 256L * gridDim.x) {
+    const int j = (int)(i % wv);
+    const long rp = i / wv;  // plane * h + row
+    const long plane = rp / h;
+    const int r = (int)(rp - plane * h);
+    const float* top = x + (plane * 2 * h + 2 * r) * W + 2 * V * j;
+    const float* bot = top + W;
+    float t[2 * V], b[2 * V], o[4][V];
+    if constexpr (V == 4) {
+      *reinterpret_cast<float4*>(t) = *reinterpret_cast<const float4*>(top);
+      *reinterpret_cast<float4*>(t + 4) = *reinterpret_cast<const float4*>(top + 4);
+      *reinterpret_cast<float4*>(b) = *reinterpret_cast<const float4*>(bot);
+      *reinterpret_cast<float4*>(b + 4) = *reinterpret_cast<const float4*>(bot + 4);
+    } else {
+      t[0] = top[0], t[1] = top[1], b[0] = bot[0], b[1] = bot[1];
+    }
+#pragma unroll
+    for (int k = 0; k < V; ++k) butterfly(t[2 * k], t[2 * k + 1], b[2 * k], b[2 * k + 1], o[0][k], o[1][k], o[2][k], o[3][k]);
+    const long off = rp * w + V * j;
+    float* outs[4] = {ll, lh, hl, hh};
+#pragma unroll
+    for (int band = 0; band < 4; ++band) {
+      if (outs[band] == nullptr) continue;
+      const float sc = band == 0 ? ll_scale : hi_scale;
+      if constexpr (V == 4) {
+        *reinterpret_cast<float4*>(outs[band] + off) =
+            make_float4(sc * o[band][0], sc * o[band][1], sc * o[band][2], sc * o[band][3]);
+      } else {
+        outs[band][off] = sc * o[band][0];
+      }
+    }
+  }
+}
+
+template <int V>
+__global__ void __launch_bounds__(256) idwt2d_kernel(const float* __restrict__ ll0, const float* __restrict__ ll1,
+                                                     const float* __restrict__ lh, const float* __restrict__ hl,
+                                                     const float* __restrict__ hh, float* __restrict__ out0,
+                                                     float* __restrict__ out1, long total, int h, int w,
+                                                     float in_scale, long hi_ppb, long hi_bstride) {
+  const int wv = w / V;
+  const int W = 2 * w;
+  for (long i = blockIdx.x * 256L + threadIdx.x; i < total; i += 256L * gridDim.x) {
+    const int j = (int)(i % wv);
+    const long rp = i / wv;
+    const long plane = rp / h;
+    const int r = (int)(rp - plane * h);
+    const long off = rp * w + V * j;
+    // high bands may be channel slices of a [B, 3C, N, h, w] tensor: sample stride != planes*h*w
+    const long hoff = hi_bstride ? (plane / hi_ppb) * hi_bstride + ((plane % hi_ppb) * h + r) * (long)w + V * j : off;
+    float b1[V], b2[V], b3[V];
+    if constexpr (V == 4) {
+      *reinterpret_cast<float4*>(b1) = *reinterpret_cast<const float4*>(lh + hoff);
+      *reinterpret_cast<float4*>(b2) = *reinterpret_cast<const float4*>(hl + hoff);
+      *reinterpret_cast<float4*>(b3) = *reinterpret_cast<const float4*>(hh + hoff);
+    } else {
+      b1[0] = lh[hoff], b2[0] = hl[hoff], b3[0] = hh[hoff];
+    }
+    const float* lls[2] = {ll0, ll1};
+    float* outs[2] = {out0, out1};
+#pragma unroll
+    for (int k = 0; k < 2; ++k) {
+      if (lls[k] == nullptr) continue;
+      float b0[V], t[2 * V], bt[2 * V];
+      if constexpr (V == 4) {
+        *reinterpret_cast<float4*>(b0) = *reinterpret_cast<const float4*>(lls[k] + off);
+      } else {
+        b0[0] = lls[k][off];
+      }
+#pragma unroll
+      for (int c = 0; c < V; ++c) inv_butterfly(in_scale * b0[c], b1[c], b2[c], b3[c], t[2 * c], t[2 * c + 1], bt[2 * c], bt[2 * c + 1]);
+      float* top = outs[k] + (plane * 2 * h + 2 * r) * W + 2 * V * j;
+      float* bot = top + W;
+      if constexpr (V == 4) {
+        *reinterpret_cast<float4*>(top) = *reinterpret_cast<float4*>(t);
+        *reinterpret_cast<float4*>(top + 4) = *reinterpret_cast<float4*>(t + 4);
+        *reinterpret_cast<float4*>(bot) = *reinterpret_cast<float4*>(bt);
+        *reinterpret_cast<float4*>(bot + 4) = *reinterpret_cast<float4*>(bt + 4);
+      } else {
+        top[0] = t[0], top[1] = t[1], bot[0] = bt[0], bot[1] = bt[1];
+      }
+    }
+  }
+}
+
+inline int grid_for(long total) {
+  long blocks = (total + 255) / 256;
+  return (int)(blocks < 1 ? 1 : (blocks > 256 * 8 ? 256 * 8 : blocks));  // <= 8 blocks per CU, grid-stride beyond
+}
+
+}  // namespace
+
+extern "C" int tmdiff_haar_dwt2d(const float* x, float* ll, float* lh, float* hl, float* hh, int64_t planes, int32_t H,
+                                 int32_t W, float ll_scale, float hi_scale, tmdiff_stream_t stream) {
+  using namespace tmdiff;
+  TMDIFF_REQUIRE(x && ll, "haar_dwt2d: x and ll must not be NULL");
+  TMDIFF_REQUIRE(planes >= 0 && H > 0 && W > 0 && H % 2 == 0 && W % 2 == 0, "haar_dwt2d: H=%d W=%d must be positive and even",
+                 H, W);
+  if (planes == 0) return TMDIFF_OK;
+  const int h = H / 2, w = W / 2;
+  const bool vec = (w % 4 == 0) && aligned16(x) && aligned16(ll) && aligned16(lh) && aligned16(hl) && aligned16(hh);
+  if (vec) {
+    const long total = planes * h * (w / 4);
+    dwt2d_kernel<4><<<grid_for(total), 256, 0, as_stream(stream)>>>(x, ll, lh, hl, hh, total, h, w, ll_scale, hi_scale);
+  } else {
+    const long total = planes * h * w;
+    dwt2d_kernel<1><<<grid_for(total), 256, 0, as_stream(stream)>>>(x, ll, lh, hl, hh, total, h, w, ll_scale, hi_scale);
+  }
+  return check_launch("haar_dwt2d");
+}
+
+extern "C" int tmdiff_haar_idwt2d(const float* const ll[2], int32_t n_ll, const float* lh, const float* hl,
+                                  const float* hh, int64_t hi_planes_per_batch, int64_t hi_batch_stride,
+                                  float* const out[2], int64_t planes, int32_t h, int32_t w, float in_scale,
+                                  tmdiff_stream_t stream) {
+  using namespace tmdiff;
+  TMDIFF_REQUIRE(n_ll == 1 || n_ll == 2, "haar_idwt2d: n_ll=%d must be 1 or 2", n_ll);
+  TMDIFF_REQUIRE(ll && out && ll[0] && out[0] && lh && hl && hh, "haar_idwt2d: NULL band/output");
+  TMDIFF_REQUIRE(n_ll == 1 || (ll[1] && out[1]), "haar_idwt2d: second low band / output is NULL");
+  TMDIFF_REQUIRE(planes >= 0 && h > 0 && w > 0, "haar_idwt2d: bad sizes");
+  TMDIFF_REQUIRE(hi_batch_stride == 0 || (hi_planes_per_batch > 0 && planes % hi_planes_per_batch == 0 &&
+                                          hi_batch_stride >= hi_planes_per_batch * h * w && hi_batch_stride % 4 == 0),
+                 "haar_idwt2d: bad high-band slicing (planes_per_batch=%ld stride=%ld)", (long)hi_planes_per_batch,
+                 (long)hi_batch_stride);
+  if (planes == 0) return TMDIFF_OK;
+  const float* ll1 = n_ll == 2 ? ll[1] : nullptr;
+  float* out1 = n_ll == 2 ? out[1] : nullptr;
+  const bool vec = (w % 4 == 0) && aligned16(ll[0]) && aligned16(ll1) && aligned16(lh) && aligned16(hl) &&
+                   aligned16(hh) && aligned16(out[0]) && aligned16(out1);
+  if (vec) {
+    const long total = planes * h * (w / 4);
+    idwt2d_kernel<4><<<grid_for(total), 256, 0, as_stream(stream)>>>(ll[0], ll1, lh, hl, hh, out[0], out1, total, h, w, in_scale,
+                                                                     hi_planes_per_batch, hi_batch_stride);
+  } else {
+    const long total = planes * h * w;
+    idwt2d_kernel<1><<<grid_for(total), 256, 0, as_stream(stream)>>>(ll[0], ll1, lh, hl, hh, out[0], out1, total, h, w, in_scale,
+                                                                     hi_planes_per_batch, hi_batch_stride);
+  }
+  return check_launch("haar_idwt2d");
+}

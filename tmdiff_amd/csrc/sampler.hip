@@ -1,0 +1,304 @@
+// Sampler-side elementwise kernels for gfx950 (all HBM-bound, 16 B per lane):
+//   DDPM reverse step, DPM-Solver linear combinations, x0 prediction, dynamic thresholding
+//   (per-sample |x| quantile by radix select), q_sample, add.
+// Reference: GeneralModel/diffusion_general.py:134-138, :192-208, :341-347, :376-378;
+//            core/dpm_solver_pytorch.py:302-306, :430-456, :563-927; utils/util.py:135-142.
+// Arithmetic uses explicit round-to-nearest mul/add (no FMA contraction) in the reference's
+// evaluation order, so a step differs from the PyTorch CPU path only through eps itself.
+#include <initializer_list>
+
+#include "common.h"
+
+namespace {
+
+inline int grid_for(long nvec) {
+  long blocks = (nvec + 255) / 256;
+  return (int)(blocks < 1 ? 1 : (blocks > 2048 ? 2048 : blocks));
+}
+
+struct DdpmCoef {
+  float c_recip, c_recipm1, coef1, coef2, sigma;
+  int clip;
+};
+
+__device__ __forceinline__ float ddpm_one(float x, float e, float nz, const DdpmCoef& k) {
+  float x0 = __fsub_rn(__fmul_rn(k.c_recip, x), __fmul_rn(k.c_recipm1, e));  // predict_start_from_noise
+  if (k.clip) x0 = fminf(fmaxf(x0, -1.f), 1.f);                              // clamp_(-1, 1)
+  const float mean = __fadd_rn(__fmul_rn(k.coef1, x0), __fmul_rn(k.coef2, x));  // q_posterior
+  return __fadd_rn(mean, __fmul_rn(nz, k.sigma));                            // + noise * exp(0.5 logvar)
+}
+
+template <int V>
+__global__ void __launch_bounds__(256) ddpm_step_kernel(const float* __restrict__ x, const float* __restrict__ eps,
+                                                        const float* __restrict__ noise, const float* __restrict__ ms,
+                                                        float* __restrict__ out, float* __restrict__ img, long nvec,
+                                                        DdpmCoef k) {
+  for (long i = blockIdx.x * 256L + threadIdx.x; i < nvec; i += 256L * gridDim.x) {
+    float xv[V], ev[V], nv[V], mv[V], ov[V];
+    if constexpr (V == 4) {
+      *reinterpret_cast<float4*>(xv) = reinterpret_cast<const float4*>(x)[i];
+      *reinterpret_cast<float4*>(ev) = reinterpret_cast<const float4*>(eps)[i];
+      if (noise) *reinterpret_cast<float4*>(nv) = reinterpret_cast<const float4*>(noise)[i];
+      if (img) *reinterpret_cast<float4*>(mv) = reinterpret_cast<const float4*>(ms)[i];
+    } else {
+      xv[0] = x[i], ev[0] = eps[i];
+      if (noise) nv[0] = noise[i];
+      if (img) mv[0] = ms[i];
+    }
+#pragma unroll
+    for (int j = 0; j < V; ++j) ov[j] = ddpm_one(xv[j], ev[j], noise ? nv[j] : 0.f, k);
+    if constexpr (V == 4) {
+      reinterpret_cast<float4*>(out)[i] = *reinterpret_cast<float4*>(ov);
+      if (img) reinterpret_cast<float4*>(img)[i] = make_float4(ov[0] + mv[0], ov[1] + mv[1], ov[2] + mv[2], ov[3] + mv[3]);
+    } else {
+      out[i] = ov[0];
+      if (img) img[i] = ov[0] + mv[0];
+    }
+  }
+}
+
+struct AxpbyArgs {
+  const float* in[4];
+  float coef[4];
+  int n_in;
+};
+
+template <int V>
+__global__ void __launch_bounds__(256) axpby_kernel(AxpbyArgs a, float* __restrict__ out, long nvec) {
+  for (long i = blockIdx.x * 256L + threadIdx.x; i < nvec; i += 256L * gridDim.x) {
+    float acc[V];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      if (k >= a.n_in) break;
+      float v[V];
+      if constexpr (V == 4)
+        *reinterpret_cast<float4*>(v) = reinterpret_cast<const float4*>(a.in[k])[i];
+      else
+        v[0] = a.in[k][i];
+#pragma unroll
+      for (int j = 0; j < V; ++j) acc[j] = k == 0 ? __fmul_rn(a.coef[0], v[j]) : __fadd_rn(acc[j], __fmul_rn(a.coef[k], v[j]));
+    }
+    if constexpr (V == 4)
+      reinterpret_cast<float4*>(out)[i] = *reinterpret_cast<float4*>(acc);
+    else
+      out[i] = acc[0];
+  }
+}
+
+template <int V>
+__global__ void __launch_bounds__(256) x0_kernel(const float* __restrict__ x, const float* __restrict__ m,
+                                                 float* __restrict__ x0, long nvec, float alpha, float sigma,
+                                                 int is_x_start) {
+  for (long i = blockIdx.x * 256L + threadIdx.x; i < nvec; i += 256L * gridDim.x) {
+    float xv[V], mv[V], ov[V];
+    if constexpr (V == 4) {
+      *reinterpret_cast<float4*>(xv) = reinterpret_cast<const float4*>(x)[i];
+      *reinterpret_cast<float4*>(mv) = reinterpret_cast<const float4*>(m)[i];
+    } else {
+      xv[0] = x[i], mv[0] = m[i];
+    }
+#pragma unroll
+    for (int j = 0; j < V; ++j) {
+      // model_wrapper: x_start output -> noise  (dpm_solver_pytorch.py:304-306)
+      const float eps = is_x_start ? __fdiv_rn(__fsub_rn(xv[j], __fmul_rn(alpha, mv[j])), sigma) : mv[j];
+      // data_prediction_fn: noise -> x0          (:451-453)
+      ov[j] = __fdiv_rn(__fsub_rn(xv[j], __fmul_rn(sigma, eps)), alpha);
+    }
+    if constexpr (V == 4)
+      reinterpret_cast<float4*>(x0)[i] = *reinterpret_cast<float4*>(ov);
+    else
+      x0[i] = ov[0];
+  }
+}
+
+template <int V>
+__global__ void __launch_bounds__(256) add_kernel(const float* __restrict__ a, const float* __restrict__ b,
+                                                  float* __restrict__ out, long nvec, float sign_b) {
+  for (long i = blockIdx.x * 256L + threadIdx.x; i < nvec; i += 256L * gridDim.x) {
+    if constexpr (V == 4) {
+      const float4 u = reinterpret_cast<const float4*>(a)[i], v = reinterpret_cast<const float4*>(b)[i];
+      reinterpret_cast<float4*>(out)[i] = make_float4(u.x + sign_b * v.x, u.y + sign_b * v.y, u.z + sign_b * v.z, u.w + sign_b * v.w);
+    } else {
+      out[i] = a[i] + sign_b * b[i];
+    }
+  }
+}
+
+__global__ void __launch_bounds__(256) q_sample_kernel(const float* __restrict__ x0, const float* __restrict__ noise,
+                                                       const float* __restrict__ a, float* __restrict__ out,
+                                                       long n_per) {
+  const int b = blockIdx.y;
+  const float ab = a[b];
+  const float sb = sqrtf(__fsub_rn(1.f, __fmul_rn(ab, ab)));  // (1 - a**2).sqrt()
+  for (long i = blockIdx.x * 256L + threadIdx.x; i < n_per; i += 256L * gridDim.x) {
+    const long o = (long)b * n_per + i;
+    out[o] = __fadd_rn(__fmul_rn(ab, x0[o]), __fmul_rn(sb, noise[o]));
+  }
+}
+
+// ---- dynamic thresholding: per-sample k-th order statistic of |x| by 4 x 8-bit radix select ------
+// One 1024-thread workgroup per sample; |x| >= 0 so the fp32 bit pattern orders like the value.
+// Result: s = max(lerp(v[k], v[k+1], frac), max_val) as torch.quantile(..., interpolation='linear'),
+// then x = clamp(x, -s, s) / s in place.
+__global__ void __launch_bounds__(1024) quantile_clamp_kernel(float* __restrict__ x, long n, long k, float frac,
+                                                              float max_val, float* __restrict__ s_out) {
+  __shared__ unsigned hist[256];
+  __shared__ unsigned sh_prefix, sh_rank, sh_min;
+  __shared__ unsigned long long sh_cnt_le;
+  float* xs = x + (long)blockIdx.x * n;
+  const int tid = threadIdx.x;
+  unsigned prefix = 0;          // high bits decided so far
+  unsigned long long rank = k;  // rank of the target inside the current bucket
+  for (int pass = 0; pass < 4; ++pass) {
+    const int shift = 24 - 8 * pass;
+    if (tid < 256) hist[tid] = 0;
+    __syncthreads();
+    const unsigned mask_hi = pass == 0 ? 0u : (0xFFFFFFFFu << (shift + 8));
+    for (long i = tid; i < n; i += 1024) {
+      const unsigned u = __float_as_uint(fabsf(xs[i]));
+      if ((u & mask_hi) == prefix) atomicAdd(&hist[(u >> shift) & 255u], 1u);
+    }
+    __syncthreads();
+    if (tid == 0) {
+      unsigned long long acc = 0;
+      unsigned d = 0;
+      for (; d < 256; ++d) {
+        if (acc + hist[d] > rank) break;
+        acc += hist[d];
+      }
+      sh_prefix = prefix | (d << shift);
+      sh_rank = (unsigned)(rank - acc);
+    }
+    __syncthreads();
+    prefix = sh_prefix;
+    rank = sh_rank;
+    __syncthreads();
+  }
+  const unsigned vlo_bits = prefix;  // exact bit pattern of the k-th smallest |x|
+  // v[k+1]: equals v[k] if more than (rank-in-bucket + 1) copies exist, else the smallest value above it.
+  if (tid == 0) { sh_cnt_le = 0; sh_min = 0x7F800000u; }
+  __syncthreads();
+  unsigned long long cnt_le = 0;
+  unsigned vmin = 0x7F800000u;
+  for (long i = tid; i < n; i += 1024) {
+    const unsigned u = __float_as_uint(fabsf(xs[i]));
+    if (u <= vlo_bits) ++cnt_le; else vmin = u < vmin ? u : vmin;
+  }
+  atomicAdd(&sh_cnt_le, cnt_le);
+  atomicMin(&sh_min, vmin);
+  __syncthreads();
+  const float vlo = __uint_as_float(vlo_bits);
+  float vhi = vlo;
+  if (frac > 0.f && sh_cnt_le < (unsigned long long)k + 2) vhi = __uint_as_float(sh_min);
+  // at::lerp: w < 0.5 ? a + w*(b-a) : b - (b-a)*(1-w)
+  const float diff = __fsub_rn(vhi, vlo);
+  const float qv = frac < 0.5f ? __fadd_rn(vlo, __fmul_rn(frac, diff)) : __fsub_rn(vhi, __fmul_rn(diff, __fsub_rn(1.f, frac)));
+  const float s = fmaxf(qv, max_val);
+  if (tid == 0 && s_out) s_out[blockIdx.x] = s;
+  for (long i = tid; i < n; i += 1024) xs[i] = __fdiv_rn(fminf(fmaxf(xs[i], -s), s), s);
+}
+
+inline bool all_aligned(std::initializer_list<const void*> ps, long n, int) {
+  if (n % 4) return false;
+  for (const void* p : ps)
+    if (p && !tmdiff::aligned16(p)) return false;
+  return true;
+}
+
+}  // namespace
+
+extern "C" int tmdiff_ddpm_step(const float* x, const float* eps, const float* noise, const float* ms, float* out,
+                                float* img_out, int64_t n, float c_recip, float c_recipm1, float coef1, float coef2,
+                                float sigma, int32_t clip, tmdiff_stream_t stream) {
+  using namespace tmdiff;
+  TMDIFF_REQUIRE(x && eps && out, "ddpm_step: NULL pointer");
+  TMDIFF_REQUIRE(n >= 0, "ddpm_step: n=%ld", (long)n);
+  TMDIFF_REQUIRE(noise || sigma == 0.f, "ddpm_step: noise is NULL but sigma != 0");
+  TMDIFF_REQUIRE(!img_out || ms, "ddpm_step: img_out needs ms");
+  if (n == 0) return TMDIFF_OK;
+  DdpmCoef k{c_recip, c_recipm1, coef1, coef2, sigma, clip};
+  if (all_aligned({x, eps, noise, ms, out, img_out}, n, 0)) {
+    ddpm_step_kernel<4><<<grid_for(n / 4), 256, 0, as_stream(stream)>>>(x, eps, noise, ms, out, img_out, n / 4, k);
+  } else {
+    ddpm_step_kernel<1><<<grid_for(n), 256, 0, as_stream(stream)>>>(x, eps, noise, ms, out, img_out, n, k);
+  }
+  return check_launch("ddpm_step");
+}
+
+extern "C" int tmdiff_axpby(const float* const in[4], const float coef[4], int32_t n_in, float* out, int64_t n,
+                            tmdiff_stream_t stream) {
+  using namespace tmdiff;
+  TMDIFF_REQUIRE(in && coef && out, "axpby: NULL pointer");
+  TMDIFF_REQUIRE(n_in >= 1 && n_in <= 4 && n >= 0, "axpby: n_in=%d n=%ld", n_in, (long)n);
+  AxpbyArgs a;
+  bool al = n % 4 == 0 && aligned16(out);
+  for (int k = 0; k < 4; ++k) {
+    a.in[k] = k < n_in ? in[k] : nullptr;
+    a.coef[k] = k < n_in ? coef[k] : 0.f;
+    if (k < n_in) {
+      TMDIFF_REQUIRE(in[k] != nullptr, "axpby: input %d is NULL", k);
+      al = al && aligned16(in[k]);
+    }
+  }
+  a.n_in = n_in;
+  if (n == 0) return TMDIFF_OK;
+  if (al)
+    axpby_kernel<4><<<grid_for(n / 4), 256, 0, as_stream(stream)>>>(a, out, n / 4);
+  else
+    axpby_kernel<1><<<grid_for(n), 256, 0, as_stream(stream)>>>(a, out, n);
+  return check_launch("axpby");
+}
+
+extern "C" int tmdiff_x0_from_model(const float* x, const float* model_out, float* x0, int64_t n, float alpha,
+                                    float sigma, int32_t model_is_x_start, tmdiff_stream_t stream) {
+  using namespace tmdiff;
+  TMDIFF_REQUIRE(x && model_out && x0 && n >= 0, "x0_from_model: bad arguments");
+  if (n == 0) return TMDIFF_OK;
+  if (all_aligned({x, model_out, x0}, n, 0))
+    x0_kernel<4><<<grid_for(n / 4), 256, 0, as_stream(stream)>>>(x, model_out, x0, n / 4, alpha, sigma, model_is_x_start);
+  else
+    x0_kernel<1><<<grid_for(n), 256, 0, as_stream(stream)>>>(x, model_out, x0, n, alpha, sigma, model_is_x_start);
+  return check_launch("x0_from_model");
+}
+
+extern "C" size_t tmdiff_abs_quantile_workspace_bytes(int32_t B, int64_t /*n_per_sample*/) {
+  return B > 0 ? (size_t)B * sizeof(float) : 0;  // the per-sample thresholds s[B] (readable by the caller)
+}
+
+extern "C" int tmdiff_abs_quantile_clamp(float* x0, int32_t B, int64_t n_per_sample, float q, float max_val,
+                                         void* workspace, tmdiff_stream_t stream) {
+  using namespace tmdiff;
+  TMDIFF_REQUIRE(x0 && B >= 0 && n_per_sample > 0, "abs_quantile_clamp: bad arguments");
+  TMDIFF_REQUIRE(q >= 0.f && q <= 1.f, "abs_quantile_clamp: q=%f outside [0,1]", q);
+  if (B == 0) return TMDIFF_OK;
+  // torch.quantile: rank = q * (n - 1) evaluated in the input dtype (fp32); lerp weight = rank - floor(rank)
+  const float rank = q * (float)(n_per_sample - 1);
+  long k = (long)floorf(rank);
+  if (k > n_per_sample - 1) k = n_per_sample - 1;
+  const float frac = rank - (float)k;
+  quantile_clamp_kernel<<<B, 1024, 0, as_stream(stream)>>>(x0, n_per_sample, k, frac, max_val,
+                                                           reinterpret_cast<float*>(workspace));
+  return check_launch("abs_quantile_clamp");
+}
+
+extern "C" int tmdiff_add(const float* a, const float* b, float* out, int64_t n, float sign_b, tmdiff_stream_t stream) {
+  using namespace tmdiff;
+  TMDIFF_REQUIRE(a && b && out && n >= 0, "add: bad arguments");
+  if (n == 0) return TMDIFF_OK;
+  if (all_aligned({a, b, out}, n, 0))
+    add_kernel<4><<<grid_for(n / 4), 256, 0, as_stream(stream)>>>(a, b, out, n / 4, sign_b);
+  else
+    add_kernel<1><<<grid_for(n), 256, 0, as_stream(stream)>>>(a, b, out, n, sign_b);
+  return check_launch("add");
+}
+
+extern "C" int tmdiff_q_sample(const float* x0, const float* noise, const float* a, float* out, int32_t B,
+                               int64_t n_per_sample, tmdiff_stream_t stream) {
+  using namespace tmdiff;
+  TMDIFF_REQUIRE(x0 && noise && a && out && B >= 0 && B <= 65535 && n_per_sample >= 0, "q_sample: bad arguments");
+  if (B == 0 || n_per_sample == 0) return TMDIFF_OK;
+  long blocks = (n_per_sample + 255) / 256;
+  if (blocks > 256) blocks = 256;
+  q_sample_kernel<<<dim3((unsigned)blocks, B), 256, 0, as_stream(stream)>>>(x0, noise, a, out, n_per_sample);
+  return check_launch("q_sample");
+}

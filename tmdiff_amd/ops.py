@@ -1,0 +1,219 @@
+"""Thin tensor-level wrappers over the C ABI (include/tmdiff_hip.h).
+
+PyTorch is plumbing here: it owns device memory and the current HIP stream; every FLOP of
+these ops runs in libtmdiff_hip.so.  All wrappers require CUDA(HIP) fp32 contiguous
+tensors and raise otherwise -- there is no eager fallback.
+"""
+import ctypes as C
+
+import torch
+
+from . import _lib
+from ._lib import Conv3dDesc, check, lib
+
+
+def stream_ptr():
+    return torch.cuda.current_stream().cuda_stream
+
+
+def _chk(t, name):
+    if t is None:
+        return None
+    if not (t.is_cuda and t.dtype == torch.float32 and t.is_contiguous()):
+        raise ValueError(f"{name}: need a contiguous float32 tensor on the GPU, got {t.dtype} {t.device} "
+                         f"contiguous={t.is_contiguous()}")
+    return t.data_ptr()
+
+
+def pack_conv_weight(w, groups=1, mode=0):
+    """[Cout, Cin/g, k,k,k] -> packed [g][ci][tap][co] (mode 0) or the data-gradient packing (mode 1)."""
+    cout, cin_g, k = w.shape[0], w.shape[1], w.shape[2]
+    out = torch.empty(w.numel(), device=w.device, dtype=torch.float32)
+    check(lib.tmdiff_conv3d_pack_weights(_chk(w.detach(), "w"), out.data_ptr(), cout, cin_g * groups, k, groups, mode,
+                                         stream_ptr()), "conv3d_pack_weights")
+    return out
+
+
+def make_conv_desc(segs, w_packed, cout, ksize, y, groups=1, bias=None, bias_scale=1.0, in_shift=None, in_scale=None,
+                   shift_stride=0, scale_stride=0, in_act=False, in_mask=None, residual=None, out_scale=1.0):
+    """Fill a tmdiff_conv3d_desc.  `segs` = list of 1..3 tensors [B, c_i, N, H, W] (concat-free input).
+    in_shift / in_scale may be tensors or raw (ptr) ints into a projection bank."""
+    d = Conv3dDesc()
+    b, _, n, h, w = segs[0].shape
+    d.B, d.N, d.H, d.W = b, n, h, w
+    d.Cin = sum(s.shape[1] for s in segs)
+    d.Cout, d.groups, d.ksize, d.nseg = cout, groups, ksize, len(segs)
+    for i, s in enumerate(segs):
+        if tuple(s.shape[2:]) != (n, h, w) or s.shape[0] != b:
+            raise ValueError("conv3d: input segments disagree on [B, N, H, W]")
+        d.seg_c[i] = s.shape[1]
+        d.seg_x[i] = _chk(s, f"segment {i}")
+    d.w_packed = w_packed if isinstance(w_packed, int) else _chk(w_packed, "w_packed")
+    d.bias = _chk(bias, "bias")
+    d.bias_scale = bias_scale
+    d.in_shift = in_shift if isinstance(in_shift, int) else _chk(in_shift, "in_shift")
+    d.in_scale = in_scale if isinstance(in_scale, int) else _chk(in_scale, "in_scale")
+    d.in_shift_stride, d.in_scale_stride = shift_stride, scale_stride
+    d.in_mask = _chk(in_mask, "in_mask")
+    d.in_act = 1 if in_act else 0
+    if residual is not None and tuple(residual.shape) != tuple(y.shape):
+        raise ValueError("conv3d: residual shape != output shape")
+    d.residual = _chk(residual, "residual")
+    d.out_scale = out_scale
+    if tuple(y.shape) != (b, cout, n, h, w):
+        raise ValueError(f"conv3d: output shape {tuple(y.shape)} != {(b, cout, n, h, w)}")
+    d.y = _chk(y, "y")
+    return d
+
+
+class ConvTimer:
+    """Optional per-launch HIP-event timing of tmdiff_conv3d_fwd (used by bench.py for the roofline
+    object).  Events are recorded on the launch stream; ``summary()`` resolves them after a sync."""
+
+    def __init__(self):
+        self.records = []        # (start_event, end_event, flops, ksize)
+
+    def summary(self):
+        torch.cuda.synchronize()
+        out = {}
+        for e0, e1, fl, k in self.records:
+            n, ms, f = out.get(k, (0, 0.0, 0.0))
+            out[k] = (n + 1, ms + e0.elapsed_time(e1), f + fl)
+        return out
+
+
+TIMER = None      # set to a ConvTimer() to time every conv launch
+
+
+def conv3d(segs, w_packed, cout, ksize, out=None, **kw):
+    b, _, n, h, w = segs[0].shape
+    y = out if out is not None else torch.empty(b, cout, n, h, w, device=segs[0].device, dtype=torch.float32)
+    d = make_conv_desc(segs, w_packed, cout, ksize, y, **kw)
+    if TIMER is None:
+        check(lib.tmdiff_conv3d_fwd(C.byref(d), stream_ptr()), "conv3d_fwd")
+        return y
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    check(lib.tmdiff_conv3d_fwd(C.byref(d), stream_ptr()), "conv3d_fwd")
+    e1.record()
+    TIMER.records.append((e0, e1, 2.0 * b * cout * (d.Cin // d.groups) * ksize ** 3 * n * h * w, ksize))
+    return y
+
+
+def stem(w, bias, out_channels, xin=None, pan=None, ms=None, silu=True, out=None):
+    ref = ms if ms is not None else xin
+    b, n, h, wd = ref.shape
+    y = out if out is not None else torch.empty(b, out_channels, n, h, wd, device=ref.device, dtype=torch.float32)
+    check(lib.tmdiff_stem_fwd(_chk(xin, "xin"), _chk(pan, "pan"), _chk(ms, "ms"), _chk(w, "w"), _chk(bias, "bias"),
+                              _chk(y, "y"), b, out_channels, n, h, wd, 1 if silu else 0, stream_ptr()), "stem_fwd")
+    return y
+
+
+def head(x, w, scale, scale_stride=0, out=None):
+    b, c, n, h, wd = x.shape
+    y = out if out is not None else torch.empty(b, n, h, wd, device=x.device, dtype=torch.float32)
+    check(lib.tmdiff_head_fwd(_chk(x, "x"), _chk(w, "w"), scale if isinstance(scale, int) else _chk(scale, "scale"),
+                              scale_stride, _chk(y, "y"), b, c, n * h * wd, stream_ptr()), "head_fwd")
+    return y
+
+
+def haar_dwt2d(x, want_high=True, ll_scale=1.0, hi_scale=1.0, outs=None):
+    """x [..., H, W] -> (ll, lh, hl, hh); the high bands are None when want_high is False."""
+    hh_, ww = x.shape[-2:]
+    planes = x.numel() // (hh_ * ww)
+    shape = (*x.shape[:-2], hh_ // 2, ww // 2)
+    if outs is None:
+        outs = [torch.empty(shape, device=x.device, dtype=torch.float32) for _ in range(4 if want_high else 1)]
+    ptrs = [_chk(o, "band") for o in outs] + [None] * (4 - len(outs))
+    check(lib.tmdiff_haar_dwt2d(_chk(x, "x"), *ptrs, planes, hh_, ww, ll_scale, hi_scale, stream_ptr()), "haar_dwt2d")
+    return tuple(outs) + (None,) * (4 - len(outs))
+
+
+def haar_idwt2d(lls, lh, hl, hh, in_scale=1.0, outs=None, stacked_bands=None):
+    """lls: list of 1 or 2 low bands sharing the high bands; returns a list of reconstructions.
+    ``stacked_bands`` [B, 3C, N, h, w] (the convH_0 output) supplies lh/hl/hh as channel slices
+    without copying them out."""
+    ll0 = lls[0]
+    h, w = ll0.shape[-2:]
+    planes = ll0.numel() // (h * w)
+    if outs is None:
+        outs = [torch.empty((*ll0.shape[:-2], 2 * h, 2 * w), device=ll0.device, dtype=torch.float32) for _ in lls]
+    llp = (C.c_void_p * 2)(*[_chk(t, "ll") for t in lls], *([None] * (2 - len(lls))))
+    outp = (C.c_void_p * 2)(*[_chk(t, "out") for t in outs], *([None] * (2 - len(outs))))
+    if stacked_bands is not None:
+        b = stacked_bands.shape[0]
+        ppb = planes // b
+        if stacked_bands.numel() != 3 * planes * h * w:
+            raise ValueError("haar_idwt2d: stacked bands must be [B, 3C, N, h, w]")
+        base = _chk(stacked_bands, "bands")
+        step = 4 * ppb * h * w
+        hp = (base, base + step, base + 2 * step, ppb, 3 * ppb * h * w)
+    else:
+        hp = (_chk(lh, "lh"), _chk(hl, "hl"), _chk(hh, "hh"), 0, 0)
+    check(lib.tmdiff_haar_idwt2d(llp, len(lls), *hp, outp, planes, h, w, in_scale, stream_ptr()), "haar_idwt2d")
+    return outs
+
+
+def linear(x, w, bias=None, act=False, out=None):
+    b, i = x.shape
+    o = w.shape[0]
+    y = out if out is not None else torch.empty(b, o, device=x.device, dtype=torch.float32)
+    check(lib.tmdiff_linear_fwd(_chk(x, "x"), _chk(w, "w"), _chk(bias, "bias"), _chk(y, "y"), b, i, o,
+                                1 if act else 0, stream_ptr()), "linear_fwd")
+    return y
+
+
+def gamma_embedding(t, freqs, dim, out=None):
+    b = t.shape[0]
+    y = out if out is not None else torch.empty(b, dim, device=t.device, dtype=torch.float32)
+    check(lib.tmdiff_gamma_embedding(_chk(t, "t"), _chk(freqs, "freqs"), _chk(y, "emb"), b, dim, stream_ptr()),
+          "gamma_embedding")
+    return y
+
+
+def ddpm_step(x, eps, noise, c_recip, c_recipm1, coef1, coef2, sigma, clip=True, ms=None, out=None, img_out=None):
+    y = out if out is not None else torch.empty_like(x)
+    check(lib.tmdiff_ddpm_step(_chk(x, "x"), _chk(eps, "eps"), _chk(noise, "noise"), _chk(ms, "ms"), _chk(y, "out"),
+                               _chk(img_out, "img_out"), x.numel(), c_recip, c_recipm1, coef1, coef2, sigma,
+                               1 if clip else 0, stream_ptr()), "ddpm_step")
+    return y
+
+
+def axpby(tensors, coefs, out=None):
+    n_in = len(tensors)
+    y = out if out is not None else torch.empty_like(tensors[0])
+    ptrs = (C.c_void_p * 4)(*[_chk(t, "in") for t in tensors], *([None] * (4 - n_in)))
+    cf = (C.c_float * 4)(*[float(c) for c in coefs], *([0.0] * (4 - n_in)))
+    check(lib.tmdiff_axpby(ptrs, cf, n_in, _chk(y, "out"), y.numel(), stream_ptr()), "axpby")
+    return y
+
+
+def x0_from_model(x, model_out, alpha, sigma, model_is_x_start=True, out=None):
+    y = out if out is not None else torch.empty_like(x)
+    check(lib.tmdiff_x0_from_model(_chk(x, "x"), _chk(model_out, "model_out"), _chk(y, "x0"), x.numel(), alpha, sigma,
+                                   1 if model_is_x_start else 0, stream_ptr()), "x0_from_model")
+    return y
+
+
+def abs_quantile_clamp_(x0, q=0.995, max_val=1.0):
+    """In place: per sample s = max(quantile(|x0|, q), max_val); x0 = clamp(x0, -s, s) / s.  Returns s [B]."""
+    b = x0.shape[0]
+    n = x0.numel() // b
+    ws = torch.empty(max(1, lib.tmdiff_abs_quantile_workspace_bytes(b, n) // 4), device=x0.device, dtype=torch.float32)
+    check(lib.tmdiff_abs_quantile_clamp(_chk(x0, "x0"), b, n, q, max_val, ws.data_ptr(), stream_ptr()),
+          "abs_quantile_clamp")
+    return ws[:b]
+
+
+def add(a, b, sign_b=1.0, out=None):
+    y = out if out is not None else torch.empty_like(a)
+    check(lib.tmdiff_add(_chk(a, "a"), _chk(b, "b"), _chk(y, "out"), a.numel(), sign_b, stream_ptr()), "add")
+    return y
+
+
+def q_sample(x0, noise, a, out=None):
+    b = x0.shape[0]
+    y = out if out is not None else torch.empty_like(x0)
+    check(lib.tmdiff_q_sample(_chk(x0, "x0"), _chk(noise, "noise"), _chk(a, "a"), _chk(y, "out"), b,
+                              x0.numel() // b, stream_ptr()), "q_sample")
+    return y
