@@ -48,19 +48,24 @@ struct ConvArgs {
   unsigned total_blocks;
 };
 
-template <int KS, int CO, int KC, int TN, int TH, int TW>
+// Tile geometry.  A workgroup = 4 waves; wave w owns NS position sub-tiles (32 positions each) x MSUB
+// channel sub-tiles (32 channels each): NS*MSUB fp32 32x32 accumulators (16 AGPRs each).
+template <int KS, int NS, int MSUB, int KC, int TN, int TH, int TW>
 struct Geo {
   static constexpr int TAPS = KS * KS * KS;
   static constexpr int HALO = KS / 2;
+  static constexpr int CO = 32 * MSUB;
   static constexpr int HN = TN + 2 * HALO, HH = TH + 2 * HALO, HW = TW + 2 * HALO;
   static constexpr int TILE_ELEMS = HN * HH * HW;
   static constexpr int POS = TN * TH * TW;
-  static constexpr int EPT = (TILE_ELEMS + 255) / 256;  // staged elements per thread per channel
+  static constexpr int EPT = (TILE_ELEMS + 255) / 256;         // staged input elements per thread per channel
+  static constexpr int W4 = (KC * TAPS * CO / 4 + 255) / 256;  // staged weight float4s per thread per chunk
   static constexpr int LDS_IN = KC * TILE_ELEMS;
   static constexpr int LDS_W = KC * TAPS * CO;
-  static constexpr int MSUB = CO / 32;
-  static_assert(POS == 256, "a workgroup tile is 256 positions (4 waves x 2 sub-tiles x 32)");
-  static_assert(KC % 2 == 0 && CO % 32 == 0, "K step is 2 channels; channel sub-tiles are 32 wide");
+  static constexpr int STAGE = (LDS_IN + LDS_W + 3) / 4 * 4;   // floats per pipeline stage (16-B aligned)
+  static_assert(POS == 4 * NS * 32, "workgroup tile = 4 waves x NS sub-tiles x 32 positions");
+  static_assert(KC % 2 == 0, "K step is 2 channels");
+  static_assert(LDS_IN % 4 == 0, "weight slab must start 16-B aligned");
 };
 
 // XCD-aware block id: blocks b and b+8 share an XCD (round-robin dispatch), so hand each XCD a
@@ -71,12 +76,18 @@ __device__ __forceinline__ unsigned xcd_remap(unsigned bid, unsigned nwg) {
   return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + k;
 }
 
-template <int KS, int CO, int KC, int TN, int TH, int TW>
-__global__ void __launch_bounds__(256) conv3d_mfma_kernel(const ConvArgs a) {
-  using G = Geo<KS, CO, KC, TN, TH, TW>;
-  __shared__ __attribute__((aligned(16))) float lds[G::LDS_IN + G::LDS_W];
-  float* lds_in = lds;
-  float* lds_w = lds + G::LDS_IN;
+// Software pipeline (one barrier per chunk, two LDS stages):
+//   issue global loads of chunk c+1 into registers -> MFMA loop over chunk c (stage c&1) -> apply the
+//   prologue to the prefetched registers and write them to stage (c+1)&1 -> barrier.
+// The loads fly under ~100-200 MFMAs per wave; the only serial part per chunk is the register->LDS
+// hand-off, which the other workgroup on the CU covers.
+// FAST: cin_g % KC == 0, cout_g % CO == 0 and 16-byte-loadable weight rows (every production layer):
+// no per-channel / per-column bounds logic in the loop.
+template <int KS, int NS, int MSUB, int KC, int TN, int TH, int TW, bool FAST>
+__global__ void __launch_bounds__(256, 2) conv3d_mfma_kernel(const ConvArgs a) {
+  using G = Geo<KS, NS, MSUB, KC, TN, TH, TW>;
+  constexpr int CO = G::CO;
+  __shared__ __attribute__((aligned(16))) float lds[2 * G::STAGE];
 
   const int tid = threadIdx.x;
   const int lane = tid & 63, wv = tid >> 6;
@@ -105,139 +116,216 @@ __global__ void __launch_bounds__(256) conv3d_mfma_kernel(const ConvArgs a) {
     gok[i] = (e < G::TILE_ELEMS) && n >= 0 && n < a.N && h >= 0 && h < a.H && w >= 0 && w < a.W;
     goff[i] = gok[i] ? (n * a.H + h) * a.W + w : 0;
   }
+  // weight slab float4 idx = tid + 256*j  ->  row = idx / (CO/4) = wrow0 + j*WSTEP, col = wcol (256 % (CO/4) == 0)
+  constexpr int WSTEP = 256 / (CO / 4);
+  const int wrow0 = tid / (CO / 4), wcol = (tid % (CO / 4)) * 4;
 
   // ---- per-lane operand offsets ---------------------------------------------------------------
-  int boff[2];  // float index of this lane's position inside the haloed box, tap (0,0,0)
+  int boff[NS];  // float index of this lane's position inside the haloed box, tap (0,0,0)
 #pragma unroll
-  for (int s = 0; s < 2; ++s) {
-    const int p = (wv * 2 + s) * 32 + l31;
+  for (int s = 0; s < NS; ++s) {
+    const int p = (wv * NS + s) * 32 + l31;
     const int pw = p % TW, ph = (p / TW) % TH, pn = p / (TW * TH);
     boff[s] = (pn * G::HH + ph) * G::HW + pw + khalf * G::TILE_ELEMS;
   }
-  const int aoff = khalf * G::TAPS * CO + l31;
+  // A operand: the slab row holds the block's CO channels as [l31][m] (see pack_weights), so one
+  // ds_read_b32/b64/b128 fetches this lane's weight for all MSUB channel sub-tiles.
+  const int aoff = G::LDS_IN + khalf * G::TAPS * CO + l31 * MSUB;
 
-  f32x16 acc[2][G::MSUB];
+  f32x16 acc[NS][MSUB];
 #pragma unroll
-  for (int s = 0; s < 2; ++s)
+  for (int s = 0; s < NS; ++s)
 #pragma unroll
-    for (int m = 0; m < G::MSUB; ++m)
+    for (int m = 0; m < MSUB; ++m)
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[s][m][r] = 0.f;
 
   const float* wp_g = a.wp + (long)g * a.cin_g * G::TAPS * a.cout_g;
 
-  for (int c0 = 0; c0 < a.cin_g; c0 += KC) {
-    if (c0) __syncthreads();  // everyone is done reading the previous chunk
-    // ---- stage the haloed input box, prologue applied once per element -------------------------
-#pragma unroll 1
+  // prefetch registers of the chunk in flight
+  float xr[KC][G::EPT];
+  float wr[G::W4][4];  // (scalars, not float4[]: an array of vectors is left in scratch by SROA here)
+  float shr[KC], scr[KC];
+  bool cval[KC];
+
+  // Software pipeline, one barrier per chunk, two LDS stages.  Iteration `it`:
+  //   1. issue the global loads of chunk it+1 (registers xr / wr; they fly under the MFMAs),
+  //   2. run the K-steps of chunk it from stage it&1, fetching the LDS operands one K-step ahead,
+  //   3. hand chunk it+1 to stage (it+1)&1 in NPIECE small pieces (prologue math + ds_write) that are
+  //      slotted between the K-steps of the second half of step 2, i.e. issued in the shadow of MFMAs,
+  //   4. barrier.
+  // All loads are unconditional (out-of-range elements read a clamped, valid address and are zeroed by a
+  // select when staged): a branch around a load would split the MFMA basic block and force vmcnt(0) waits.
+  constexpr int NPIECE = KC * G::EPT + G::W4;
+  constexpr int KSTEPS = (KC / 2) * G::TAPS;
+  constexpr int PIECE0 = KSTEPS > NPIECE ? KSTEPS - NPIECE : 0;  // first K-step that carries a piece
+
+  auto issue_loads = [&](int cn) {
+#pragma unroll
     for (int ci = 0; ci < KC; ++ci) {
-      const int cl = c0 + ci;           // channel within group
-      const bool cvalid = cl < a.cin_g;
-      int cg = g * a.cin_g + cl;        // channel within the concatenated input
-      const float* src = nullptr;
-      const float* msk = nullptr;
-      float sh = 0.f, sc = 1.f;
-      if (cvalid) {
-        if (a.in_shift) sh = a.in_shift[(long)b * a.shift_stride + cg];
-        if (a.in_scale) sc = a.in_scale[(long)b * a.scale_stride + cg];
-        if (a.in_mask) msk = a.in_mask + ((long)b * a.Cin + cg) * plane;
-        int cs = cg, segc = a.seg_c[0];  // which concat segment holds channel cg (no dynamic kernarg indexing)
-        const float* base = a.seg_x[0];
-        if (a.nseg > 1 && cs >= segc) {
-          cs -= segc; base = a.seg_x[1]; segc = a.seg_c[1];
-          if (a.nseg > 2 && cs >= segc) { cs -= segc; base = a.seg_x[2]; segc = a.seg_c[2]; }
-        }
-        src = base + ((long)b * segc + cs) * plane;
+      const int cl = cn + ci;  // channel within group
+      cval[ci] = FAST || cl < a.cin_g;
+      const int cg = g * a.cin_g + (cval[ci] ? cl : 0);  // channel within the concatenated input (clamped)
+      shr[ci] = a.in_shift ? a.in_shift[(long)b * a.shift_stride + cg] : 0.f;
+      scr[ci] = a.in_scale ? a.in_scale[(long)b * a.scale_stride + cg] : 1.f;
+      int cs = cg, segc = a.seg_c[0];  // which concat segment holds channel cg (no dynamic kernarg indexing)
+      const float* base = a.seg_x[0];
+      if (a.nseg > 1 && cs >= segc) {
+        cs -= segc; base = a.seg_x[1]; segc = a.seg_c[1];
+        if (a.nseg > 2 && cs >= segc) { cs -= segc; base = a.seg_x[2]; segc = a.seg_c[2]; }
       }
-      float v[G::EPT];
+      const float* src = base + ((long)b * segc + cs) * plane;
 #pragma unroll
-      for (int i = 0; i < G::EPT; ++i) v[i] = (cvalid && gok[i]) ? src[goff[i]] : 0.f;
-#pragma unroll
-      for (int i = 0; i < G::EPT; ++i) {
-        const int e = tid + 256 * i;
-        if (e < G::TILE_ELEMS) {
-          float t = 0.f;
-          if (cvalid && gok[i]) {
-            t = v[i] + sh;
-            if (a.in_act) t = tmdiff::silu_f(t);
-            t *= sc;
-            if (msk) t *= msk[goff[i]];
-          }
-          lds_in[ci * G::TILE_ELEMS + e] = t;
-        }
-      }
+      for (int i = 0; i < G::EPT; ++i) xr[ci][i] = src[goff[i]];
     }
-    // ---- stage the weight slab: rows [c0*TAPS, (c0+KC)*TAPS) x columns [co0, co0+CO) -------------
-    {
-      constexpr int ROWS = KC * G::TAPS;
-      constexpr int V4 = CO / 4;
-      for (int idx = tid; idx < ROWS * V4; idx += 256) {
-        const int row = idx / V4, c4 = (idx % V4) * 4;
-        const int cl = c0 + row / G::TAPS;
-        const long grow = (long)c0 * G::TAPS + row;
-        float4 wv4 = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+    for (int j = 0; j < G::W4; ++j) {
+      const int row = min(wrow0 + j * WSTEP, KC * G::TAPS - 1);
+      if constexpr (FAST) {
+        const float4 v = *reinterpret_cast<const float4*>(wp_g + ((long)cn * G::TAPS + row) * a.cout_g + co0 + wcol);
+        wr[j][0] = v.x, wr[j][1] = v.y, wr[j][2] = v.z, wr[j][3] = v.w;
+      } else {
+        const int cl = cn + row / G::TAPS;
+        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
         if (cl < a.cin_g) {
-          const float* p = wp_g + grow * a.cout_g + co0 + c4;
-          if (a.w_vec4 && co0 + c4 + 3 < a.cout_g) {
-            wv4 = *reinterpret_cast<const float4*>(p);
+          const float* p = wp_g + ((long)cn * G::TAPS + row) * a.cout_g + co0 + wcol;
+          if (a.w_vec4 && co0 + wcol + 3 < a.cout_g) {
+            v = *reinterpret_cast<const float4*>(p);
           } else {
-            if (co0 + c4 + 0 < a.cout_g) wv4.x = p[0];
-            if (co0 + c4 + 1 < a.cout_g) wv4.y = p[1];
-            if (co0 + c4 + 2 < a.cout_g) wv4.z = p[2];
-            if (co0 + c4 + 3 < a.cout_g) wv4.w = p[3];
+            if (co0 + wcol + 0 < a.cout_g) v.x = p[0];
+            if (co0 + wcol + 1 < a.cout_g) v.y = p[1];
+            if (co0 + wcol + 2 < a.cout_g) v.z = p[2];
+            if (co0 + wcol + 3 < a.cout_g) v.w = p[3];
           }
         }
-        *reinterpret_cast<float4*>(lds_w + row * CO + c4) = wv4;
+        wr[j][0] = v.x, wr[j][1] = v.y, wr[j][2] = v.z, wr[j][3] = v.w;
       }
     }
+  };
+
+  // piece `pc` of the register -> LDS hand-off of the chunk starting at channel cn
+  auto stage_piece = [&](int pc, float* st, int cn) {
+    if (pc < KC * G::EPT) {
+      const int ci = pc / G::EPT, i = pc % G::EPT;
+      const int e = tid + 256 * i;
+      if (e < G::TILE_ELEMS) {
+        float t = xr[ci][i] + shr[ci];
+        if (a.in_act) t = tmdiff::silu_f(t);
+        t *= scr[ci];
+        if (a.in_mask && cval[ci])  // dropout mask (training only): read here, not prefetched
+          t *= a.in_mask[((long)b * a.Cin + g * a.cin_g + cn + ci) * plane + goff[i]];
+        // halo / out-of-range elements are exactly zero: the conv pads the ACTIVATED tensor
+        st[ci * G::TILE_ELEMS + e] = (gok[i] && cval[ci]) ? t : 0.f;
+      }
+    } else {
+      const int j = pc - KC * G::EPT;
+      const int row = wrow0 + j * WSTEP;
+      if (row < KC * G::TAPS)
+        *reinterpret_cast<float4*>(st + G::LDS_IN + row * CO + wcol) = make_float4(wr[j][0], wr[j][1], wr[j][2], wr[j][3]);
+    }
+  };
+
+  // prologue: chunk 0 -> stage 0
+  issue_loads(0);
+#pragma unroll
+  for (int pc = 0; pc < NPIECE; ++pc) stage_piece(pc, lds, 0);
+  __syncthreads();
+
+  for (int it = 0;; ++it) {
+    const int cn = (it + 1) * KC;  // first channel of the chunk to prefetch
+    const bool more = cn < a.cin_g;
+    if (more) issue_loads(cn);
+    const float* st = lds + (it & 1) * G::STAGE;
+    float* st_next = lds + ((it + 1) & 1) * G::STAGE;
+
+    auto fetch = [&](int ks, float (&av)[MSUB], float (&bv)[NS]) {
+      const int kp = ks / G::TAPS, tap = ks % G::TAPS;
+      const int dn = tap / (KS * KS), dh = (tap / KS) % KS, dw = tap % KS;
+      const int toff = (dn * G::HH + dh) * G::HW + dw;
+      const float* ap = st + aoff + (kp * 2 * G::TAPS + tap) * CO;
+      if constexpr (MSUB == 1) {
+        av[0] = ap[0];
+      } else if constexpr (MSUB == 2) {
+        const float2 t2 = *reinterpret_cast<const float2*>(ap);
+        av[0] = t2.x, av[1] = t2.y;
+      } else {
+        const float4 t4 = *reinterpret_cast<const float4*>(ap);
+        av[0] = t4.x, av[1] = t4.y, av[2] = t4.z, av[3] = t4.w;
+      }
+#pragma unroll
+      for (int s = 0; s < NS; ++s) bv[s] = st[boff[s] + kp * 2 * G::TILE_ELEMS + toff];
+    };
+    float av[2][MSUB], bv[2][NS];
+    fetch(0, av[0], bv[0]);
+#pragma unroll
+    for (int ks = 0; ks < KSTEPS; ++ks) {
+      if (ks + 1 < KSTEPS) fetch(ks + 1, av[(ks + 1) & 1], bv[(ks + 1) & 1]);
+      __builtin_amdgcn_sched_barrier(0);  // keep the prefetch ahead of this step's MFMAs (hipcc sinks it otherwise)
+#pragma unroll
+      for (int s = 0; s < NS; ++s)
+#pragma unroll
+        for (int m = 0; m < MSUB; ++m)
+          acc[s][m] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[ks & 1][m], bv[ks & 1][s], acc[s][m], 0, 0, 0);
+      __builtin_amdgcn_sched_barrier(0);
+      // hand-off pieces ride behind the MFMAs just issued (on the last chunk they stage stale registers into the
+      // unused stage: harmless, and it keeps this block free of branches)
+      if (ks >= PIECE0) {
+#pragma unroll
+        for (int pc = (ks - PIECE0) * NPIECE / (KSTEPS - PIECE0); pc < (ks + 1 - PIECE0) * NPIECE / (KSTEPS - PIECE0); ++pc)
+          stage_piece(pc, st_next, cn);
+        __builtin_amdgcn_sched_barrier(0);
+      }
+    }
+    if (!more) break;
     __syncthreads();
-    // ---- K loop over the chunk: KC/2 channel pairs x taps --------------------------------------
-#pragma unroll
-    for (int kp = 0; kp < KC / 2; ++kp) {
-#pragma unroll
-      for (int tap = 0; tap < G::TAPS; ++tap) {
-        const int dn = tap / (KS * KS), dh = (tap / KS) % KS, dw = tap % KS;
-        const int toff = (dn * G::HH + dh) * G::HW + dw;
-        float av[G::MSUB], bv[2];
-#pragma unroll
-        for (int m = 0; m < G::MSUB; ++m) av[m] = lds_w[aoff + (kp * 2 * G::TAPS + tap) * CO + m * 32];
-#pragma unroll
-        for (int s = 0; s < 2; ++s) bv[s] = lds_in[boff[s] + kp * 2 * G::TILE_ELEMS + toff];
-#pragma unroll
-        for (int s = 0; s < 2; ++s)
-#pragma unroll
-          for (int m = 0; m < G::MSUB; ++m)
-            acc[s][m] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[m], bv[s], acc[s][m], 0, 0, 0);
-      }
-    }
   }
 
   // ---- epilogue: bias, residual, scale; D layout: col = lane&31 (position), row = channel --------
+  // Loads first (bias rows, then all residual elements of a sub-tile), then the stores: no load->store chains.
 #pragma unroll
-  for (int s = 0; s < 2; ++s) {
-    const int p = (wv * 2 + s) * 32 + l31;
-    const int n = n0 + p / (TW * TH), h = h0 + (p / TW) % TH, w = w0 + p % TW;
-    if (n >= a.N || h >= a.H || w >= a.W) continue;
-    const long sp = ((long)n * a.H + h) * a.W + w;
+  for (int m = 0; m < MSUB; ++m) {
+    float bias_r[16];
 #pragma unroll
-    for (int m = 0; m < G::MSUB; ++m) {
+    for (int r = 0; r < 16; ++r) {
+      const int col = co0 + m * 32 + (r & 3) + 8 * (r >> 2) + 4 * khalf;  // channel within group
+      const int cglob = g * a.cout_g + min(col, a.cout_g - 1);
+      bias_r[r] = a.bias ? a.bias_scale * a.bias[cglob] : 0.f;
+    }
+#pragma unroll
+    for (int s = 0; s < NS; ++s) {
+      const int p = (wv * NS + s) * 32 + l31;
+      const int n = n0 + p / (TW * TH), h = h0 + (p / TW) % TH, w = w0 + p % TW;
+      const bool pok = n < a.N && h < a.H && w < a.W;
+      const long sp = pok ? ((long)n * a.H + h) * a.W + w : 0;
+      const long obase = ((long)b * a.Cout + g * a.cout_g + co0 + m * 32 + 4 * khalf) * plane + sp;
+      float res[16];
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
-        const int col = co0 + m * 32 + (r & 3) + 8 * (r >> 2) + 4 * khalf;  // channel within group
-        if (col >= a.cout_g) continue;
-        const int cglob = g * a.cout_g + col;
-        const long o = ((long)b * a.Cout + cglob) * plane + sp;
-        float t = acc[s][m][r];
-        if (a.bias) t += a.bias_scale * a.bias[cglob];
-        if (a.residual) t += a.residual[o];
-        a.y[o] = t * a.out_scale;
+        const int row = (r & 3) + 8 * (r >> 2);
+        const bool ok = pok && (FAST || co0 + m * 32 + 4 * khalf + row < a.cout_g);
+        res[r] = (a.residual && ok) ? a.residual[obase + row * plane] : 0.f;
+      }
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int row = (r & 3) + 8 * (r >> 2);
+        const bool ok = pok && (FAST || co0 + m * 32 + 4 * khalf + row < a.cout_g);
+        if (ok) a.y[obase + row * plane] = (acc[s][m][r] + bias_r[r] + res[r]) * a.out_scale;
       }
     }
   }
 }
 
-// packed[g][ci][tap][co] <- w[g*cout_g + co][ci][tap]              (mode 0, forward)
-// packed[g][co][taps-1-tap][ci] <- w[g*cout_g + co][ci][tap]       (mode 1, data gradient: roles swapped)
+// Column order inside a packed row.  When the (output) channel count is a multiple of 64 the forward kernel
+// runs 64-channel tiles with two 32-channel MFMA sub-tiles per wave; channel c of a tile is then stored at
+// (c % 32) * 2 + c / 32 so that one 8-byte LDS read returns a lane's weight for both sub-tiles.
+__host__ __device__ inline int packed_col(int c, int n_out) {
+  if (n_out % 64) return c;
+  const int t = c / 64, r = c % 64;
+  return t * 64 + (r % 32) * 2 + r / 32;
+}
+
+// packed[g][ci][tap][col(co)] <- w[g*cout_g + co][ci][tap]               (mode 0, forward)
+// packed[g][co][taps-1-tap][col(ci)] <- w[g*cout_g + co][ci][tap]        (mode 1, data gradient: roles swapped)
 __global__ void __launch_bounds__(256) pack_weights_kernel(const float* __restrict__ w, float* __restrict__ packed,
                                                            int cout_g, int cin_g, int taps, int groups, int mode,
                                                            long total) {
@@ -250,15 +338,16 @@ __global__ void __launch_bounds__(256) pack_weights_kernel(const float* __restri
     const int g = (int)(r / cout_g);
     long dst;
     if (mode == 0)
-      dst = (((long)g * cin_g + ci) * taps + tap) * cout_g + co;
+      dst = (((long)g * cin_g + ci) * taps + tap) * cout_g + packed_col(co, cout_g);
     else
-      dst = (((long)g * cout_g + co) * taps + (taps - 1 - tap)) * cin_g + ci;
+      dst = (((long)g * cout_g + co) * taps + (taps - 1 - tap)) * cin_g + packed_col(ci, cin_g);
     packed[dst] = w[i];
   }
 }
 
-template <int KS, int CO, int KC, int TN, int TH, int TW>
+template <int KS, int NS, int MSUB, int KC, int TN, int TH, int TW>
 int launch(ConvArgs& a, hipStream_t st) {
+  constexpr int CO = 32 * MSUB;
   a.tiles_n = (a.N + TN - 1) / TN;
   a.tiles_h = (a.H + TH - 1) / TH;
   a.tiles_w = (a.W + TW - 1) / TW;
@@ -266,7 +355,11 @@ int launch(ConvArgs& a, hipStream_t st) {
   const long blocks = (long)a.B * a.groups * a.tiles_n * a.tiles_h * a.tiles_w * a.tiles_co;
   if (blocks <= 0 || blocks > 0x7fffffffL) return tmdiff::fail(TMDIFF_E_INVALID, "conv3d: grid of %ld blocks", blocks);
   a.total_blocks = (unsigned)blocks;
-  conv3d_mfma_kernel<KS, CO, KC, TN, TH, TW><<<(unsigned)blocks, 256, 0, st>>>(a);
+  const bool fast = a.cin_g % KC == 0 && a.cout_g % CO == 0 && a.w_vec4;
+  if (fast)
+    conv3d_mfma_kernel<KS, NS, MSUB, KC, TN, TH, TW, true><<<(unsigned)blocks, 256, 0, st>>>(a);
+  else
+    conv3d_mfma_kernel<KS, NS, MSUB, KC, TN, TH, TW, false><<<(unsigned)blocks, 256, 0, st>>>(a);
   return tmdiff::check_launch("conv3d_fwd");
 }
 
@@ -326,12 +419,14 @@ extern "C" int tmdiff_conv3d_fwd(const tmdiff_conv3d_desc* d, tmdiff_stream_t st
   a.w_vec4 = (a.cout_g % 4 == 0) && aligned16(d->w_packed);
   hipStream_t st = as_stream(stream);
 
-  // Channel-tile choice: 64-wide tiles halve the staging per MFMA; fall back to 32 when the
-  // layer has few channels or too few tiles to fill 256 CUs several times over.
-  const long sp_tiles = (long)d->B * d->groups * ((d->N + 3) / 4) * ((d->H + 7) / 8) * ((d->W + 7) / 8);
-  const bool wide = a.cout_g > 32 && sp_tiles * ((a.cout_g + 63) / 64) >= 2048;
+  // Tile choice.  <NS, MSUB>: 2x2 = 256 positions x 64 channels when the channel count is a multiple of 64
+  // (the packed rows are then sub-tile interleaved, see packed_col); otherwise 32-channel tiles, 512 positions
+  // (4x1) on planes at least 16 wide, else 256 positions (2x1).
+  const bool c64 = a.cout_g % 64 == 0;
   if (d->ksize == 3) {
-    return wide ? launch<3, 64, 4, 4, 8, 8>(a, st) : launch<3, 32, 4, 4, 8, 8>(a, st);
+    if (c64) return launch<3, 2, 2, 4, 4, 8, 8>(a, st);
+    return d->W >= 16 ? launch<3, 4, 1, 4, 4, 8, 16>(a, st) : launch<3, 2, 1, 4, 4, 8, 8>(a, st);
   }
-  return wide ? launch<1, 64, 32, 4, 8, 8>(a, st) : launch<1, 32, 32, 4, 8, 8>(a, st);
+  if (c64) return launch<1, 2, 2, 8, 4, 8, 8>(a, st);
+  return d->W >= 16 ? launch<1, 4, 1, 8, 4, 8, 16>(a, st) : launch<1, 2, 1, 8, 4, 8, 8>(a, st);
 }
