@@ -18,11 +18,28 @@
 // sub-tiles.  All LDS operand reads are ds_read_b32 with compile-time offsets; the fp32 MFMA
 // needs only two operand dwords per 64 cycles, so LDS bandwidth is not the limiter -- the
 // MFMA pipe is, and several workgroups per CU overlap one's staging with another's MFMAs.
+#include <cstdlib>
+#include <type_traits>
+
 #include "common.h"
+
+#ifndef TMDIFF_CONV_DEBUG
+#define TMDIFF_CONV_DEBUG 0  // experiment switches: 1 = no in-loop global loads, 2 = no hand-off items (results wrong)
+#endif
 
 namespace {
 
 using f32x16 = __attribute__((ext_vector_type(16))) float;
+
+// compile-time loop: f(std::integral_constant<int, I>) for I in [B, E) -- indices must be constants so that
+// the register arrays below are addressed statically (a runtime index would send them to scratch).
+template <int B, int E, class F>
+__device__ __forceinline__ void static_for(F&& f) {
+  if constexpr (B < E) {
+    f(std::integral_constant<int, B>{});
+    static_for<B + 1, E>(f);
+  }
+}
 
 struct ConvArgs {
   int B, N, H, W;
@@ -46,6 +63,7 @@ struct ConvArgs {
   int tiles_n, tiles_h, tiles_w, tiles_co;  // tiles_co per group
   int w_vec4;                               // cout_g % 4 == 0 -> 16-byte weight loads
   unsigned total_blocks;
+  int dbg;  // experiment switches (TMDIFF_CONV_DEBUG): 1 = no in-loop global loads, 2 = no hand-off pieces, 4 = no barrier
 };
 
 // Tile geometry.  A workgroup = 4 waves; wave w owns NS position sub-tiles (32 positions each) x MSUB
@@ -62,7 +80,8 @@ struct Geo {
   static constexpr int W4 = (KC * TAPS * CO / 4 + 255) / 256;  // staged weight float4s per thread per chunk
   static constexpr int LDS_IN = KC * TILE_ELEMS;
   static constexpr int LDS_W = KC * TAPS * CO;
-  static constexpr int STAGE = (LDS_IN + LDS_W + 3) / 4 * 4;   // floats per pipeline stage (16-B aligned)
+  static constexpr int DUMMY = (LDS_IN + LDS_W + 3) / 4 * 4;   // 16-B sink for lanes that have nothing to stage
+  static constexpr int STAGE = DUMMY + 4;                      // floats per pipeline stage (16-B aligned)
   static_assert(POS == 4 * NS * 32, "workgroup tile = 4 waves x NS sub-tiles x 32 positions");
   static_assert(KC % 2 == 0, "K step is 2 channels");
   static_assert(LDS_IN % 4 == 0, "weight slab must start 16-B aligned");
@@ -83,7 +102,7 @@ __device__ __forceinline__ unsigned xcd_remap(unsigned bid, unsigned nwg) {
 // hand-off, which the other workgroup on the CU covers.
 // FAST: cin_g % KC == 0, cout_g % CO == 0 and 16-byte-loadable weight rows (every production layer):
 // no per-channel / per-column bounds logic in the loop.
-template <int KS, int NS, int MSUB, int KC, int TN, int TH, int TW, bool FAST>
+template <int KS, int NS, int MSUB, int KC, int TN, int TH, int TW, bool FAST, bool MASK>
 __global__ void __launch_bounds__(256, 2) conv3d_mfma_kernel(const ConvArgs a) {
   using G = Geo<KS, NS, MSUB, KC, TN, TH, TW>;
   constexpr int CO = G::CO;
@@ -94,13 +113,14 @@ __global__ void __launch_bounds__(256, 2) conv3d_mfma_kernel(const ConvArgs a) {
   const int l31 = lane & 31, khalf = lane >> 5;
 
   // ---- which tile -------------------------------------------------------------------------
+  // (integer division runs on the VALU; readfirstlane moves the wave-uniform results back to SGPRs)
   unsigned id = xcd_remap(blockIdx.x, a.total_blocks);
-  const int co_tile = id % a.tiles_co; id /= a.tiles_co;
-  const int tw_i = id % a.tiles_w; id /= a.tiles_w;
-  const int th_i = id % a.tiles_h; id /= a.tiles_h;
-  const int tn_i = id % a.tiles_n; id /= a.tiles_n;
-  const int g = id % a.groups;
-  const int b = id / a.groups;
+  const int co_tile = __builtin_amdgcn_readfirstlane(id % a.tiles_co); id /= a.tiles_co;
+  const int tw_i = __builtin_amdgcn_readfirstlane(id % a.tiles_w); id /= a.tiles_w;
+  const int th_i = __builtin_amdgcn_readfirstlane(id % a.tiles_h); id /= a.tiles_h;
+  const int tn_i = __builtin_amdgcn_readfirstlane(id % a.tiles_n); id /= a.tiles_n;
+  const int g = __builtin_amdgcn_readfirstlane(id % a.groups);
+  const int b = __builtin_amdgcn_readfirstlane(id / a.groups);
   const int n0 = tn_i * TN, h0 = th_i * TH, w0 = tw_i * TW;
   const int co0 = co_tile * CO;  // within group
   const long plane = (long)a.N * a.H * a.W;
@@ -142,44 +162,69 @@ __global__ void __launch_bounds__(256, 2) conv3d_mfma_kernel(const ConvArgs a) {
 
   const float* wp_g = a.wp + (long)g * a.cin_g * G::TAPS * a.cout_g;
 
+  float bias_v[MSUB];  // epilogue bias, fetched now so that its latency is long gone when it is needed
+#pragma unroll
+  for (int m = 0; m < MSUB; ++m) {
+    const int col = min(co0 + m * 32 + l31, a.cout_g - 1);
+    const float* bp = a.bias ? a.bias + g * a.cout_g + col : a.wp;  // always a valid address
+    const float raw = *bp;
+    bias_v[m] = a.bias ? a.bias_scale * raw : 0.f;
+  }
+
   // prefetch registers of the chunk in flight
   float xr[KC][G::EPT];
   float wr[G::W4][4];  // (scalars, not float4[]: an array of vectors is left in scratch by SROA here)
-  float shr[KC], scr[KC];
+  float ssv = 0.f;     // lane l < KC: shift of channel cn+l; KC <= l < 2KC: scale of channel cn+l-KC
   bool cval[KC];
 
-  // Software pipeline, one barrier per chunk, two LDS stages.  Iteration `it`:
-  //   1. issue the global loads of chunk it+1 (registers xr / wr; they fly under the MFMAs),
-  //   2. run the K-steps of chunk it from stage it&1, fetching the LDS operands one K-step ahead,
-  //   3. hand chunk it+1 to stage (it+1)&1 in NPIECE small pieces (prologue math + ds_write) that are
-  //      slotted between the K-steps of the second half of step 2, i.e. issued in the shadow of MFMAs,
-  //   4. barrier.
-  // All loads are unconditional (out-of-range elements read a clamped, valid address and are zeroed by a
-  // select when staged): a branch around a load would split the MFMA basic block and force vmcnt(0) waits.
-  constexpr int NPIECE = KC * G::EPT + G::W4;
+  // Software pipeline, one barrier per chunk, two LDS stages.  While the K-steps of chunk `it` run from stage
+  // it&1, chunk it+1 is brought in behind them.  The unit of interleaving is ONE MFMA: the fp32 32x32x2 MFMA
+  // holds the matrix pipe for 64 cycles, in which the wave can issue ~a dozen other instructions for free, so
+  // every MFMA is followed by a "slot" that carries at most a small work item:
+  //   slot 0 of a K-step        : LDS operand fetch for the NEXT K-step,
+  //   early aux slots           : the global loads of chunk it+1 (registers xr / wr / ssv), one per slot,
+  //   late aux slots            : the register -> LDS hand-off (prologue math, then ds_write) to stage (it+1)&1.
+  // sched_barrier(0) pins that order (hipcc otherwise sinks the loads next to their uses and bunches the
+  // hand-off after the MFMAs).  Every load is unconditional (out-of-range elements read a clamped, valid address
+  // and are zeroed by a select when staged): a branch around a load would force vmcnt(0) waits.  Per-channel
+  // shift / scale come through ONE vector load + v_readlane, not scalar loads: SMEM shares lgkmcnt with LDS.
+  constexpr int MF = NS * MSUB;                      // MFMAs per K-step
   constexpr int KSTEPS = (KC / 2) * G::TAPS;
-  constexpr int PIECE0 = KSTEPS > NPIECE ? KSTEPS - NPIECE : 0;  // first K-step that carries a piece
+  constexpr int AUX = KSTEPS * (MF - 1);             // aux slots per chunk
+  constexpr int NL = 1 + KC + KC * G::EPT + G::W4;   // load items: ssv, KC source pointers, inputs, weights
+  constexpr int NP = 2 * KC * G::EPT + G::W4;        // hand-off items: (math, write) per input element, weights
+  constexpr int LSPAN = AUX / 2 < NL ? (AUX / 2 > 0 ? AUX / 2 : 1) : NL;
+  constexpr int PSPAN = AUX - AUX / 2 < NP ? (AUX - AUX / 2 > 0 ? AUX - AUX / 2 : 1) : NP;
+  static_assert(MF >= 2, "need at least one aux slot per K-step");
 
-  auto issue_loads = [&](int cn) {
-#pragma unroll
-    for (int ci = 0; ci < KC; ++ci) {
+  const float* srcp[KC];
+  auto load_item = [&](auto qc, int cn) __attribute__((always_inline)) {
+    constexpr int q = decltype(qc)::value;
+    if constexpr (q == 0) {
+      const bool is_shift = lane < KC;
+      const float* sp = is_shift ? a.in_shift : a.in_scale;
+      const long row = (long)b * (is_shift ? a.shift_stride : a.scale_stride);
+      const int cl = min(cn + (lane % KC), a.cin_g - 1);
+      const float* sp2 = sp ? sp + row + g * a.cin_g + cl : a.wp;  // always a valid address
+      const float raw = *sp2;
+      ssv = (sp && lane < 2 * KC) ? raw : (is_shift ? 0.f : 1.f);
+    } else if constexpr (q <= KC) {
+      constexpr int ci = q - 1;
       const int cl = cn + ci;  // channel within group
       cval[ci] = FAST || cl < a.cin_g;
-      const int cg = g * a.cin_g + (cval[ci] ? cl : 0);  // channel within the concatenated input (clamped)
-      shr[ci] = a.in_shift ? a.in_shift[(long)b * a.shift_stride + cg] : 0.f;
-      scr[ci] = a.in_scale ? a.in_scale[(long)b * a.scale_stride + cg] : 1.f;
-      int cs = cg, segc = a.seg_c[0];  // which concat segment holds channel cg (no dynamic kernarg indexing)
-      const float* base = a.seg_x[0];
-      if (a.nseg > 1 && cs >= segc) {
-        cs -= segc; base = a.seg_x[1]; segc = a.seg_c[1];
-        if (a.nseg > 2 && cs >= segc) { cs -= segc; base = a.seg_x[2]; segc = a.seg_c[2]; }
-      }
-      const float* src = base + ((long)b * segc + cs) * plane;
-#pragma unroll
-      for (int i = 0; i < G::EPT; ++i) xr[ci][i] = src[goff[i]];
-    }
-#pragma unroll
-    for (int j = 0; j < G::W4; ++j) {
+      const int cs = g * a.cin_g + (cval[ci] ? cl : 0);  // channel within the concatenated input (clamped)
+      // which concat segment holds it: selects between COMPUTED addresses (a select between the kernel-argument
+      // fields themselves becomes a dependent s_load + lgkmcnt(0) inside the MFMA stream)
+      const int c0 = a.seg_c[0], c1 = a.seg_c[1], c2 = a.seg_c[2];
+      const float* e0 = a.seg_x[0] + ((long)b * c0 + cs) * plane;
+      const float* e1 = a.seg_x[1] + ((long)b * c1 + (cs - c0)) * plane;
+      const float* e2 = a.seg_x[2] + ((long)b * c2 + (cs - c0 - c1)) * plane;
+      srcp[ci] = cs < c0 ? e0 : (cs < c0 + c1 ? e1 : e2);
+    } else if constexpr (q <= KC + KC * G::EPT) {
+      constexpr int ci = (q - 1 - KC) / G::EPT, i = (q - 1 - KC) % G::EPT;
+      xr[ci][i] = srcp[ci][goff[i]];
+    } else {
+      constexpr int j = q - 1 - KC - KC * G::EPT;
       const int row = min(wrow0 + j * WSTEP, KC * G::TAPS - 1);
       if constexpr (FAST) {
         const float4 v = *reinterpret_cast<const float4*>(wp_g + ((long)cn * G::TAPS + row) * a.cout_g + co0 + wcol);
@@ -203,45 +248,51 @@ __global__ void __launch_bounds__(256, 2) conv3d_mfma_kernel(const ConvArgs a) {
     }
   };
 
-  // piece `pc` of the register -> LDS hand-off of the chunk starting at channel cn
-  auto stage_piece = [&](int pc, float* st, int cn) {
-    if (pc < KC * G::EPT) {
-      const int ci = pc / G::EPT, i = pc % G::EPT;
+  // hand-off item `pc` of the chunk starting at channel cn -> LDS stage st
+  auto stage_item = [&](auto pcc, float* st, int cn) __attribute__((always_inline)) {
+    constexpr int pc = decltype(pcc)::value;
+    if constexpr (pc < 2 * KC * G::EPT) {
+      constexpr int ci = (pc / 2) / G::EPT, i = (pc / 2) % G::EPT;
       const int e = tid + 256 * i;
-      if (e < G::TILE_ELEMS) {
-        float t = xr[ci][i] + shr[ci];
-        if (a.in_act) t = tmdiff::silu_f(t);
-        t *= scr[ci];
-        if (a.in_mask && cval[ci])  // dropout mask (training only): read here, not prefetched
-          t *= a.in_mask[((long)b * a.Cin + g * a.cin_g + cn + ci) * plane + goff[i]];
-        // halo / out-of-range elements are exactly zero: the conv pads the ACTIVATED tensor
-        st[ci * G::TILE_ELEMS + e] = (gok[i] && cval[ci]) ? t : 0.f;
+      if constexpr (pc % 2 == 0) {  // prologue math, in place in the prefetch register
+        const float sh = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(ssv), ci));
+        const float sc = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(ssv), KC + ci));
+        float t = xr[ci][i] + sh;
+        const float ta = tmdiff::silu_f(t);
+        t = (a.in_act ? ta : t) * sc;
+        if constexpr (MASK)  // dropout mask (training only): read here, not prefetched
+          if (cval[ci]) t *= a.in_mask[((long)b * a.Cin + g * a.cin_g + cn + ci) * plane + goff[i]];
+        xr[ci][i] = t;
+      } else {
+        // halo / out-of-range elements are exactly zero: the conv pads the ACTIVATED tensor.  Lanes past the end
+        // of the box write the stage's sink word instead of branching (a branch would split the MFMA block).
+        st[e < G::TILE_ELEMS ? ci * G::TILE_ELEMS + e : G::DUMMY] = (gok[i] && cval[ci]) ? xr[ci][i] : 0.f;
       }
     } else {
-      const int j = pc - KC * G::EPT;
+      constexpr int j = pc - 2 * KC * G::EPT;
       const int row = wrow0 + j * WSTEP;
-      if (row < KC * G::TAPS)
-        *reinterpret_cast<float4*>(st + G::LDS_IN + row * CO + wcol) = make_float4(wr[j][0], wr[j][1], wr[j][2], wr[j][3]);
+      *reinterpret_cast<float4*>(st + (row < KC * G::TAPS ? G::LDS_IN + row * CO + wcol : G::DUMMY)) =
+          make_float4(wr[j][0], wr[j][1], wr[j][2], wr[j][3]);
     }
   };
 
   // prologue: chunk 0 -> stage 0
-  issue_loads(0);
-#pragma unroll
-  for (int pc = 0; pc < NPIECE; ++pc) stage_piece(pc, lds, 0);
+  static_for<0, NL>([&](auto qc) __attribute__((always_inline)) { load_item(qc, 0); });
+  static_for<0, NP>([&](auto pcc) __attribute__((always_inline)) { stage_item(pcc, lds, 0); });
   __syncthreads();
 
   for (int it = 0;; ++it) {
-    const int cn = (it + 1) * KC;  // first channel of the chunk to prefetch
+    const int cn = (it + 1) * KC;  // first channel of the chunk brought in during this iteration
     const bool more = cn < a.cin_g;
-    if (more) issue_loads(cn);
+    const int cn_ld = more ? cn : 0;  // last chunk: re-load chunk 0 (valid addresses, result unused) -> no branches
     const float* st = lds + (it & 1) * G::STAGE;
     float* st_next = lds + ((it + 1) & 1) * G::STAGE;
 
-    auto fetch = [&](int ks, float (&av)[MSUB], float (&bv)[NS]) {
-      const int kp = ks / G::TAPS, tap = ks % G::TAPS;
-      const int dn = tap / (KS * KS), dh = (tap / KS) % KS, dw = tap % KS;
-      const int toff = (dn * G::HH + dh) * G::HW + dw;
+    auto fetch = [&](auto ksc, float (&av)[MSUB], float (&bv)[NS]) __attribute__((always_inline)) {
+      constexpr int ks = decltype(ksc)::value;
+      constexpr int kp = ks / G::TAPS, tap = ks % G::TAPS;
+      constexpr int dn = tap / (KS * KS), dh = (tap / KS) % KS, dw = tap % KS;
+      constexpr int toff = (dn * G::HH + dh) * G::HW + dw;
       const float* ap = st + aoff + (kp * 2 * G::TAPS + tap) * CO;
       if constexpr (MSUB == 1) {
         av[0] = ap[0];
@@ -256,26 +307,33 @@ __global__ void __launch_bounds__(256, 2) conv3d_mfma_kernel(const ConvArgs a) {
       for (int s = 0; s < NS; ++s) bv[s] = st[boff[s] + kp * 2 * G::TILE_ELEMS + toff];
     };
     float av[2][MSUB], bv[2][NS];
-    fetch(0, av[0], bv[0]);
-#pragma unroll
-    for (int ks = 0; ks < KSTEPS; ++ks) {
-      if (ks + 1 < KSTEPS) fetch(ks + 1, av[(ks + 1) & 1], bv[(ks + 1) & 1]);
-      __builtin_amdgcn_sched_barrier(0);  // keep the prefetch ahead of this step's MFMAs (hipcc sinks it otherwise)
-#pragma unroll
-      for (int s = 0; s < NS; ++s)
-#pragma unroll
-        for (int m = 0; m < MSUB; ++m)
-          acc[s][m] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[ks & 1][m], bv[ks & 1][s], acc[s][m], 0, 0, 0);
-      __builtin_amdgcn_sched_barrier(0);
-      // hand-off pieces ride behind the MFMAs just issued (on the last chunk they stage stale registers into the
-      // unused stage: harmless, and it keeps this block free of branches)
-      if (ks >= PIECE0) {
-#pragma unroll
-        for (int pc = (ks - PIECE0) * NPIECE / (KSTEPS - PIECE0); pc < (ks + 1 - PIECE0) * NPIECE / (KSTEPS - PIECE0); ++pc)
-          stage_piece(pc, st_next, cn);
+    fetch(std::integral_constant<int, 0>{}, av[0], bv[0]);
+    __builtin_amdgcn_sched_barrier(0);
+    static_for<0, KSTEPS>([&](auto ksc) __attribute__((always_inline)) {
+      constexpr int ks = decltype(ksc)::value;
+      static_for<0, MF>([&](auto jc) __attribute__((always_inline)) {
+        constexpr int j = decltype(jc)::value;
+        constexpr int s = j / MSUB, m = j % MSUB;
+        acc[s][m] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[ks & 1][m], bv[ks & 1][s], acc[s][m], 0, 0, 0);
         __builtin_amdgcn_sched_barrier(0);
-      }
-    }
+        if constexpr (j == 0) {
+          if constexpr (ks + 1 < KSTEPS) fetch(std::integral_constant<int, ks + 1>{}, av[(ks + 1) & 1], bv[(ks + 1) & 1]);
+        } else {
+          constexpr int ax = ks * (MF - 1) + (j - 1);  // aux slot index
+          // load items q with floor(q*LSPAN/NL) == ax, hand-off items pc with AUX-PSPAN+floor(pc*PSPAN/NP) == ax
+          if constexpr (ax < LSPAN && !(TMDIFF_CONV_DEBUG & 1)) {
+              static_for<(ax * NL + LSPAN - 1) / LSPAN, ((ax + 1) * NL + LSPAN - 1) / LSPAN>(
+                  [&](auto qc) __attribute__((always_inline)) { load_item(qc, cn_ld); });
+          }
+          if constexpr (ax >= AUX - PSPAN && !(TMDIFF_CONV_DEBUG & 2)) {
+            constexpr int ps = ax - (AUX - PSPAN);
+              static_for<(ps * NP + PSPAN - 1) / PSPAN, ((ps + 1) * NP + PSPAN - 1) / PSPAN>(
+                  [&](auto pcc) __attribute__((always_inline)) { stage_item(pcc, st_next, cn_ld); });
+          }
+        }
+        __builtin_amdgcn_sched_barrier(0);
+      });
+    });
     if (!more) break;
     __syncthreads();
   }
@@ -284,12 +342,15 @@ __global__ void __launch_bounds__(256, 2) conv3d_mfma_kernel(const ConvArgs a) {
   // Loads first (bias rows, then all residual elements of a sub-tile), then the stores: no load->store chains.
 #pragma unroll
   for (int m = 0; m < MSUB; ++m) {
+    // lane l31 holds the bias of channel co0 + m*32 + l31 (one coalesced load, issued before the main loop);
+    // accumulator register r of a lane needs row (r&3) + 8*(r>>2) + 4*khalf of it -> v_readlane + select.
     float bias_r[16];
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
-      const int col = co0 + m * 32 + (r & 3) + 8 * (r >> 2) + 4 * khalf;  // channel within group
-      const int cglob = g * a.cout_g + min(col, a.cout_g - 1);
-      bias_r[r] = a.bias ? a.bias_scale * a.bias[cglob] : 0.f;
+      const int row = (r & 3) + 8 * (r >> 2);
+      const float b0 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(bias_v[m]), row));
+      const float b1 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(bias_v[m]), row + 4));
+      bias_r[r] = khalf ? b1 : b0;
     }
 #pragma unroll
     for (int s = 0; s < NS; ++s) {
@@ -356,10 +417,12 @@ int launch(ConvArgs& a, hipStream_t st) {
   if (blocks <= 0 || blocks > 0x7fffffffL) return tmdiff::fail(TMDIFF_E_INVALID, "conv3d: grid of %ld blocks", blocks);
   a.total_blocks = (unsigned)blocks;
   const bool fast = a.cin_g % KC == 0 && a.cout_g % CO == 0 && a.w_vec4;
-  if (fast)
-    conv3d_mfma_kernel<KS, NS, MSUB, KC, TN, TH, TW, true><<<(unsigned)blocks, 256, 0, st>>>(a);
+  if (a.in_mask)  // training (dropout) path
+    conv3d_mfma_kernel<KS, NS, MSUB, KC, TN, TH, TW, false, true><<<(unsigned)blocks, 256, 0, st>>>(a);
+  else if (fast)
+    conv3d_mfma_kernel<KS, NS, MSUB, KC, TN, TH, TW, true, false><<<(unsigned)blocks, 256, 0, st>>>(a);
   else
-    conv3d_mfma_kernel<KS, NS, MSUB, KC, TN, TH, TW, false><<<(unsigned)blocks, 256, 0, st>>>(a);
+    conv3d_mfma_kernel<KS, NS, MSUB, KC, TN, TH, TW, false, false><<<(unsigned)blocks, 256, 0, st>>>(a);
   return tmdiff::check_launch("conv3d_fwd");
 }
 
@@ -410,13 +473,17 @@ extern "C" int tmdiff_conv3d_fwd(const tmdiff_conv3d_desc* d, tmdiff_stream_t st
   a.Cin = d->Cin; a.Cout = d->Cout; a.groups = d->groups;
   a.cin_g = d->Cin / d->groups; a.cout_g = d->Cout / d->groups;
   a.nseg = d->nseg;
-  for (int i = 0; i < 3; ++i) { a.seg_c[i] = i < d->nseg ? d->seg_c[i] : 0; a.seg_x[i] = i < d->nseg ? d->seg_x[i] : nullptr; }
+  for (int i = 0; i < 3; ++i) {  // unused segments: never selected (huge channel count), but with a valid pointer
+    a.seg_c[i] = i < d->nseg ? d->seg_c[i] : (1 << 28);
+    a.seg_x[i] = i < d->nseg ? d->seg_x[i] : d->seg_x[0];
+  }
   a.wp = d->w_packed; a.bias = d->bias; a.bias_scale = d->bias_scale;
   a.in_shift = d->in_shift; a.in_scale = d->in_scale; a.in_mask = d->in_mask; a.in_act = d->in_act;
   a.shift_stride = d->in_shift_stride > 0 ? d->in_shift_stride : (d->in_shift_stride < 0 ? 0 : d->Cin);
   a.scale_stride = d->in_scale_stride > 0 ? d->in_scale_stride : (d->in_scale_stride < 0 ? 0 : d->Cin);
   a.residual = d->residual; a.out_scale = d->out_scale; a.y = d->y;
   a.w_vec4 = (a.cout_g % 4 == 0) && aligned16(d->w_packed);
+  a.dbg = 0;
   hipStream_t st = as_stream(stream);
 
   // Tile choice.  <NS, MSUB>: 2x2 = 256 positions x 64 channels when the channel count is a multiple of 64
