@@ -488,9 +488,13 @@ extern "C" int tmdiff_conv3d_fwd(const tmdiff_conv3d_desc* d, tmdiff_stream_t st
 
   // Tile choice.  <NS, MSUB>: 2x2 = 256 positions x 64 channels when the channel count is a multiple of 64
   // (the packed rows are then sub-tile interleaved, see packed_col); otherwise 32-channel tiles, 512 positions
-  // (4x1) on planes at least 16 wide, else 256 positions (2x1).
+  // (4x1) on planes at least 16 wide, else 256 positions (2x1).  Layers whose 256-position grid would leave CUs
+  // idle or badly quantised (the 8x8x8 level: 128-384 workgroups) use 128-position tiles (1x2) instead.
   const bool c64 = a.cout_g % 64 == 0;
+  const long wg256 = (long)d->B * d->groups * ((d->N + 3) / 4) * ((d->H + 7) / 8) * ((d->W + 7) / 8) * ((a.cout_g + 63) / 64);
+  const bool small_grid = c64 && wg256 < 2 * 256 && d->N > 2;
   if (d->ksize == 3) {
+    if (small_grid) return launch<3, 1, 2, 4, 2, 8, 8>(a, st);
     if (c64) return launch<3, 2, 2, 4, 4, 8, 8>(a, st);
     return d->W >= 16 ? launch<3, 4, 1, 4, 4, 8, 16>(a, st) : launch<3, 2, 1, 4, 4, 8, 8>(a, st);
   }
