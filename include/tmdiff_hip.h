@@ -79,6 +79,32 @@ int tmdiff_conv3d_pack_weights(const float* w, float* packed, int32_t Cout, int3
                                int32_t groups, int32_t mode, tmdiff_stream_t stream);
 int tmdiff_conv3d_fwd(const tmdiff_conv3d_desc* d, tmdiff_stream_t stream);
 
+/* ---- backward of the fused convolution (finetune path) ----------------------------------
+ * With x' = prologue(x) and y = (conv(x', w) + bias_scale*bias + residual) * out_scale, and g = dL/dy * out_scale:
+ *   dL/dresidual = g;  dL/dbias = bias_scale * sum_{b,pos} g      -> tmdiff_channel_sum
+ *   dL/dx'       = conv3d_fwd(g, pack_weights(w, mode 1))          (same kernel, roles of Cin/Cout swapped)
+ *   dL/dw        = tmdiff_conv3d_wgrad                             (fp32 MFMA, split over the batch/boxes)
+ *   dL/dx, dL/dshift, dL/dscale = tmdiff_conv3d_prologue_bwd(dL/dx', x, ...)
+ * ATen computes these inside autograd for F.conv3d / nn.Conv3d (Hyper_unet_general.py:74, :244, :372...). */
+
+/* dw [Cout, Cin/groups, k,k,k] (PyTorch layout) = sum_{b,pos} g[b,co,pos] * x'[b,ci,pos+tap]; x' is formed from
+ * the segments / shift / scale / mask / act of `d` exactly as in the forward (d->y, residual, bias, w_packed are
+ * ignored).  `g` is [B, Cout, N, H, W].  workspace: tmdiff_conv3d_wgrad_workspace_bytes(d) bytes (partial sums). */
+size_t tmdiff_conv3d_wgrad_workspace_bytes(const tmdiff_conv3d_desc* d);
+int tmdiff_conv3d_wgrad(const tmdiff_conv3d_desc* d, const float* g, float* dw, void* workspace,
+                        tmdiff_stream_t stream);
+
+/* out[c] = scale * sum_{b, p} x[b, c, p]   (x is [B, C, P]); bias gradients. */
+int tmdiff_channel_sum(const float* x, float* out, int32_t B, int32_t C, int64_t P, float scale,
+                       tmdiff_stream_t stream);
+
+/* Backward of the prologue x' = act(x + shift[b,c]) * scale[b,c] * mask: given gp = dL/dx' [B,Cin,N,H,W] and the
+ * forward descriptor `d` (segments, shift, scale, mask, act), writes dL/dx into dx_seg[i] (same segmenting as
+ * d->seg_x; NULL = not needed; accumulate[i] != 0 adds to the existing contents) and the per-(b,c) reductions
+ * d_shift[B,Cin], d_scale[B,Cin] (NULL = not needed, dense rows). */
+int tmdiff_conv3d_prologue_bwd(const tmdiff_conv3d_desc* d, const float* gp, float* const dx_seg[3],
+                               const int32_t accumulate[3], float* d_shift, float* d_scale, tmdiff_stream_t stream);
+
 /* ------------------------------------------------------------------------------------
  * Stem / head pointwise convolutions (bandwidth kernels):
  *  stem: y[b,co,p] = SiLU(w[co]*x[b,p] + bias[co])            AdaptionModulateBEST.conv20 + act (:169-170)
@@ -91,6 +117,15 @@ int tmdiff_stem_fwd(const float* xin, const float* pan, const float* ms, const f
                     tmdiff_stream_t stream);
 int tmdiff_head_fwd(const float* x, const float* w, const float* scale, int32_t scale_stride, float* y, int32_t B,
                     int32_t C, int64_t P, tmdiff_stream_t stream); /* scale_stride as in_scale_stride above */
+/* stem backward: with u = w[co]*x + bias[co], y = SiLU(u): dwb[b, co, 0] = sum_p gy*SiLU'(u)*x and
+ * dwb[b, co, 1] = sum_p gy*SiLU'(u) (per-sample partials [B, Cout, 2]; the caller sums over b).
+ * head backward: dx[b,c,p] = gy[b,p]*w[c]*scale[b,c]*SiLU'(x); dws[b,c] = sum_p gy[b,p]*SiLU(x[b,c,p])
+ * (dL/d(w[c]*scale[b,c])); scale rows dense [B,C] or NULL (= 1). */
+int tmdiff_stem_bwd(const float* xin, const float* pan, const float* ms, const float* w, const float* bias,
+                    const float* gy, float* dwb, int32_t B, int32_t Cout, int32_t N, int32_t H, int32_t W,
+                    tmdiff_stream_t stream);
+int tmdiff_head_bwd(const float* x, const float* w, const float* scale, const float* gy, float* dx, float* dws,
+                    int32_t B, int32_t C, int64_t P, tmdiff_stream_t stream);
 
 /* ------------------------------------------------------------------------------------
  * 2-D Haar DWT / IDWT on the (H, W) axes of [B*C*N, H, W] planes.
@@ -102,7 +137,8 @@ int tmdiff_head_fwd(const float* x, const float* w, const float* scale, int32_t 
  *        high bands (the two iwt calls with 2*h and 2*x at :383-386 are one launch).  The high
  *        bands may be channel slices of one [B, 3C, N, h, w] tensor (the convH_0 output, :381-384):
  *        hi_planes_per_batch = C*N planes per sample, hi_batch_stride = floats between samples
- *        (0 = dense [planes, h, w] bands).
+ *        (0 = dense [planes, h, w] bands).  lh/hl/hh may all be NULL = zero high bands (the adjoint of an
+ *        LL-only dwt).
  * The adjoint of dwt is idwt and vice versa (orthonormal transform), which is how the
  * backward passes are served.
  * ------------------------------------------------------------------------------------ */
@@ -124,6 +160,12 @@ int tmdiff_linear_fwd(const float* x, const float* w, const float* bias, float* 
                       int32_t act, tmdiff_stream_t stream);
 int tmdiff_gamma_embedding(const float* t, const float* freqs, float* emb, int32_t B, int32_t dim,
                            tmdiff_stream_t stream);
+/* backward of y = act(x @ w^T + bias): gu = gy * act'(u) with the pre-activation u recomputed into gu_scratch
+ * [B, O] (only needed when act != 0); dx[b,i] = sum_o gu[b,o] w[o,i]; dw[o,i] = sum_b gu[b,o] x[b,i];
+ * db[o] = sum_b gu[b,o].  Any of dx / dw / db may be NULL. */
+int tmdiff_linear_bwd(const float* x, const float* w, const float* bias, const float* gy, float* gu_scratch,
+                      float* dx, float* dw, float* db, int32_t B, int32_t I, int32_t O, int32_t act,
+                      tmdiff_stream_t stream);
 
 /* ------------------------------------------------------------------------------------
  * Sampler elementwise updates.

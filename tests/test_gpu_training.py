@@ -1,0 +1,176 @@
+"""GPU parity of the finetune path: backward kernels against PyTorch CPU autograd, the whole training loss and
+its parameter gradients against the reference fixture (tests/golden/train.npz) and the oracle."""
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+from conftest import assert_close
+from oracle import unet_ref as U
+from oracle.diffusion_ref import GeneralDiffusionRef
+from oracle.make_golden import TINY, case_inputs, randn
+
+pytestmark = pytest.mark.gpu
+
+
+def cu(t):
+    return t.detach().cuda().contiguous()
+
+
+CASES = [  # B, Cin, Cout, N, H, W, k, groups
+    (2, 8, 8, 4, 8, 8, 3, 1), (1, 5, 7, 4, 6, 6, 3, 1), (2, 32, 64, 8, 16, 16, 3, 1), (3, 4, 12, 8, 2, 2, 3, 1),
+    (2, 12, 8, 3, 10, 12, 3, 1), (2, 16, 32, 8, 16, 16, 1, 1), (1, 5, 3, 4, 6, 6, 1, 1), (2, 24, 12, 8, 8, 8, 3, 3),
+    (1, 40, 96, 4, 8, 8, 3, 1),
+]
+
+
+@pytest.mark.parametrize("case", CASES)
+def test_fused_conv_backward(case):
+    from tmdiff_amd import autograd as A
+    b, ci, co, n, h, w, k, g = case
+    nseg = 3 if (ci % 3 == 0 and g == 3) else (2 if ci % 2 == 0 and g == 1 else 1)
+    cs = [ci // nseg] * nseg
+    segs = [randn(10 + i, b, c, n, h, w).requires_grad_(True) for i, c in enumerate(cs)]
+    wt = (randn(2, co, ci // g, k, k, k) / (ci // g * k ** 3) ** 0.5).requires_grad_(True)
+    bias = randn(3, co).requires_grad_(True)
+    shift = randn(4, b, ci).requires_grad_(True)
+    scale = (1 + 0.3 * randn(5, b, ci)).requires_grad_(True)
+    res = randn(6, b, co, n, h, w).requires_grad_(True)
+    mask = (torch.rand(b, ci, n, h, w, generator=torch.Generator().manual_seed(7)) > 0.2).float() / 0.8
+    gy = randn(8, b, co, n, h, w)
+    xp = U.silu(torch.cat(segs, 1) + shift[:, :, None, None, None]) * scale[:, :, None, None, None] * mask
+    y = (F.conv3d(xp, wt, None, 1, k // 2, 1, g) + 2.0 * bias[None, :, None, None, None] + res) * 0.5
+    y.backward(gy)
+    dsegs = [cu(s).requires_grad_(True) for s in segs]
+    dw, db, dsh, dsc, dres = (cu(t).requires_grad_(True) for t in (wt, bias, shift, scale, res))
+    yd = A.conv3d(dsegs, dw, db, bias_scale=2.0, shift=dsh, scale=dsc, act=True, mask=cu(mask), residual=dres,
+                  groups=g, out_scale=0.5)
+    assert_close(yd.detach().cpu(), y.detach(), 1e-5, 1e-5, "fused conv forward")
+    yd.backward(cu(gy))
+    for name, got, want in [("dw", dw, wt), ("dbias", db, bias), ("dshift", dsh, shift), ("dscale", dsc, scale),
+                            ("dres", dres, res)] + [(f"dx{i}", a, s) for i, (a, s) in enumerate(zip(dsegs, segs))]:
+        assert_close(got.grad.cpu(), want.grad, 3e-5, 3e-5, f"{name} {case}")
+
+
+def test_small_op_backward():
+    from tmdiff_amd import autograd as A
+    # Haar DWT (all bands / LL only) and the paired IDWT
+    x = randn(1, 2, 3, 4, 8, 8).requires_grad_(True)
+    from oracle.haar_ref import haar_dwt2d, haar_idwt2d
+    bands = haar_dwt2d(x)
+    gs = [randn(2 + i, *bands[0].shape) for i in range(4)]
+    torch.autograd.backward([0.5 * bands[0], *bands[1:]], gs)
+    xd = cu(x).requires_grad_(True)
+    bd = A.haar_dwt2d(xd, want_high=True, ll_scale=0.5)
+    torch.autograd.backward(bd, [cu(g) for g in gs])
+    assert_close(xd.grad.cpu(), x.grad, 1e-6, 1e-6, "dwt backward")
+    x.grad = None
+    (0.5 * haar_dwt2d(x)[0]).backward(gs[0])
+    xd = cu(x).requires_grad_(True)
+    A.haar_dwt2d(xd, want_high=False, ll_scale=0.5)[0].backward(cu(gs[0]))
+    assert_close(xd.grad.cpu(), x.grad, 1e-6, 1e-6, "LL-only dwt backward")
+    b, c, n, h, w = 2, 3, 4, 4, 4
+    hb, xb = randn(10, b, c, n, h, w).requires_grad_(True), randn(11, b, c, n, h, w).requires_grad_(True)
+    st = randn(12, b, 3 * c, n, h, w).requires_grad_(True)
+    fold = lambda v: v.reshape(b, -1, h, w)
+    hi = [fold(st[:, i * c:(i + 1) * c]) for i in range(3)]
+    o1 = haar_idwt2d(2.0 * fold(hb), *hi).reshape(b, c, n, 2 * h, 2 * w)
+    o2 = haar_idwt2d(2.0 * fold(xb), *hi).reshape(b, c, n, 2 * h, 2 * w)
+    g1, g2 = randn(13, *o1.shape), randn(14, *o2.shape)
+    torch.autograd.backward([o1, o2], [g1, g2])
+    hd, xd, sd = (cu(t).requires_grad_(True) for t in (hb, xb, st))
+    p1, p2 = A.haar_idwt2d_pair(hd, xd, sd, in_scale=2.0)
+    assert_close(p1.detach().cpu(), o1.detach(), 1e-6, 1e-6, "paired idwt")
+    torch.autograd.backward([p1, p2], [cu(g1), cu(g2)])
+    for name, got, want in (("dh", hd, hb), ("dx", xd, xb), ("dbands", sd, st)):
+        assert_close(got.grad.cpu(), want.grad, 1e-6, 1e-6, f"paired idwt {name}")
+    # stem, head, linear
+    d = case_inputs(5, 2, 8, 16)
+    wt, bias = randn(20, 6, 1, 1, 1, 1).requires_grad_(True), randn(21, 6).requires_grad_(True)
+    cond = (d["PAN"].repeat(1, 8, 1, 1) - d["MS"]).unsqueeze(1)
+    y = U.silu(F.conv3d(cond, wt, bias))
+    gy = randn(22, *y.shape)
+    y.backward(gy)
+    wd, bd_ = cu(wt).requires_grad_(True), cu(bias).requires_grad_(True)
+    yd = A.stem(wd, bd_, pan=cu(d["PAN"]), ms=cu(d["MS"]))
+    yd.backward(cu(gy))
+    assert_close(wd.grad.cpu(), wt.grad, 1e-5, 1e-5, "stem dw")
+    assert_close(bd_.grad.cpu(), bias.grad, 1e-5, 1e-5, "stem dbias")
+    x5 = randn(23, 2, 6, 8, 16, 16).requires_grad_(True)
+    w24 = randn(24, 1, 6, 1, 1, 1).requires_grad_(True)
+    sc = (1 + 0.2 * randn(25, 2, 6)).requires_grad_(True)
+    y = U.modconv3d(U.silu(x5), w24, sc[:, :, None, None], 0).squeeze(1)
+    gy = randn(26, *y.shape)
+    y.backward(gy)
+    xd, wd, sd = (cu(t).requires_grad_(True) for t in (x5, w24, sc))
+    A.head(xd, wd, sd).backward(cu(gy))
+    for name, got, want in (("dx", xd, x5), ("dw", wd, w24), ("dscale", sd, sc)):
+        assert_close(got.grad.cpu(), want.grad, 1e-5, 1e-5, f"head {name}")
+    for act in (False, True):
+        x, wl, bl = randn(30, 5, 128).requires_grad_(True), (randn(31, 300, 128) / 11).requires_grad_(True), randn(32, 300).requires_grad_(True)
+        y = F.linear(x, wl, bl)
+        y = U.silu(y) if act else y
+        gy = randn(33, *y.shape)
+        y.backward(gy)
+        xd, wd, bd_ = (cu(t).requires_grad_(True) for t in (x, wl, bl))
+        A.linear(xd, wd, bd_, act=act).backward(cu(gy))
+        for name, got, want in (("dx", xd, x), ("dw", wd, wl), ("db", bd_, bl)):
+            assert_close(got.grad.cpu(), want.grad, 1e-5, 1e-5, f"linear act={act} {name}")
+
+
+def test_training_loss_and_gradients_vs_reference(golden):
+    """p_losses_dynamic end to end (dropout off via eval(), as in the fixture): loss value and per-parameter
+    gradient checksums against the real reference; 56 parameters must stay gradient-free."""
+    from tmdiff_amd.Hyper_unet_general import WavBEST
+    from tmdiff_amd.diffusion_general import GeneralDiffusion
+    g = golden("train")
+    ref_net = U.fill_weights_(U.WavBESTRef(channels=TINY)).eval()
+    net = WavBEST(channels=TINY)
+    net.load_state_dict(ref_net.state_dict())
+    net = net.cuda().eval()
+    diff = GeneralDiffusion(net, "l1", noise_fn=lambda like: torch.randn(like.shape)).cuda()
+    diff.set_loss("cuda")
+    diff.set_new_noise_schedule({"schedule": "cosine", "n_timestep": 1000}, "cuda")
+    for b in (3, 1):
+        d = {k: cu(v) for k, v in case_inputs(132 + b, b, 8, 16).items()}
+        np.random.seed(5)
+        torch.manual_seed(6)
+        net.zero_grad()
+        loss = diff(d, "WV3")
+        loss.backward()
+        assert abs(float(loss) - float(g[f"loss_b{b}"])) <= 1e-4 * abs(float(g[f"loss_b{b}"]))
+        ref = g[f"gsum_b{b}"]
+        n_nograd = 0
+        for i, (name, p) in enumerate(net.named_parameters()):
+            if p.grad is None:
+                assert np.isnan(ref[i, 0]), name
+                n_nograd += 1
+                continue
+            assert not np.isnan(ref[i, 0]), f"{name}: gradient here but none in the reference"
+            got = np.array([float(p.grad.sum()), float(p.grad.abs().sum())])
+            assert np.allclose(got, ref[i], rtol=2e-3, atol=2e-3 * max(ref[i, 1], 1e-6)), (name, got, ref[i])
+        assert n_nograd == 56
+
+
+def test_training_step_with_dropout_runs_and_descends():
+    """train() mode: dropout masks active; a few AdamW steps on one batch reduce the loss."""
+    from tmdiff_amd.Hyper_unet_general import WavBEST
+    from tmdiff_amd.diffusion_general import GeneralDiffusion
+    from tmdiff_amd.util import fill_weights_
+    torch.manual_seed(0)
+    net = fill_weights_(WavBEST(channels=TINY)).cuda().train()
+    diff = GeneralDiffusion(net, "l1").cuda()
+    diff.set_loss("cuda")
+    diff.set_new_noise_schedule({"schedule": "cosine", "n_timestep": 1000}, "cuda")
+    opt = torch.optim.AdamW([p for p in net.parameters()], lr=1e-3, weight_decay=1e-4)
+    d = {k: cu(v) for k, v in case_inputs(1, 4, 8, 16).items()}
+    losses = []
+    for it in range(8):
+        np.random.seed(it % 2)
+        opt.zero_grad()
+        loss = diff(d, "WV3").sum()
+        loss.backward()
+        opt.step()
+        losses.append(float(loss))
+    assert all(np.isfinite(losses))
+    assert min(losses[4:]) < losses[0]

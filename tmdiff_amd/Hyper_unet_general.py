@@ -341,3 +341,114 @@ class WavBEST(nn.Module):
             h = self._resblock(P, S, f"final.conv2{k}", [h], flag=False)
         sc = self._scale(P, S, "final.dense2")
         return ops.head(h, self.final.conv24.weight.detach().reshape(-1), sc["in_scale"], sc["scale_stride"])
+
+    # ---- training path (finetune): same graph through the autograd-wrapped HIP ops ----------------------------
+    def _drop_mask(self, like_shape, p, device):
+        if not self.training or p <= 0.0:
+            return None
+        return (torch.rand(like_shape, device=device) >= p).float() / (1.0 - p)     # nn.Dropout(p) semantics
+
+    def _t_resblock(self, name, segs, shifts, scales, flag):
+        from . import autograd as A
+        rb = self.get_submodule(name)
+        b, _, n, h, w = segs[0].shape
+        cin = sum(s.shape[1] for s in segs)
+        dev = segs[0].device
+        t1 = A.conv3d(segs, rb.conv20.weight, rb.conv20.bias, shift=None if flag else shifts[name + ".dense1"],
+                      act=True, mask=self._drop_mask((b, cin, n, h, w), rb.dropout.p, dev))
+        if isinstance(rb.res_conv, nn.Conv3d):
+            res = A.conv3d(segs, rb.res_conv.weight, rb.res_conv.bias)
+        else:
+            res = segs[0]
+        return A.conv3d([t1], rb.conv21.weight, None, scale=scales[name + ".dense2"], act=True,
+                        mask=self._drop_mask(t1.shape, rb.dropout.p, dev), residual=res)
+
+    def _t_wavelet_tail(self, name, wl, h_in, x_in, shifts, scales, flag):
+        from . import autograd as A
+        return A.conv3d([h_in], wl.Conv_1.weight, None, shift=None if flag else shifts[name + ".Dense_0"],
+                        scale=scales[name + ".dense1"], act=True,
+                        mask=self._drop_mask(h_in.shape, wl.Dropout_0.p, h_in.device), residual=x_in)
+
+    def _t_down(self, name, x, shifts, scales, flag, want_high):
+        from . import autograd as A
+        wl = self.get_submodule(name)
+        hh = A.conv3d([x], wl.Conv_0.weight, wl.Conv_0.bias, act=True)
+        xx = A.conv3d([x], wl.Conv_2.weight, wl.Conv_2.bias)
+        hll, lh, hl, hhh = A.haar_dwt2d(hh, want_high=want_high, ll_scale=0.5)
+        xll = A.haar_dwt2d(xx, want_high=False, ll_scale=0.5)[0]
+        return self._t_wavelet_tail(name, wl, hll, xll, shifts, scales, flag), (lh, hl, hhh)
+
+    def _t_up(self, name, x, skip, shifts, scales):
+        from . import autograd as A
+        wl = self.get_submodule(name)
+        hh = A.conv3d([x], wl.Conv_0.weight, wl.Conv_0.bias, act=True)
+        xx = A.conv3d([x], wl.Conv_2.weight, wl.Conv_2.bias)
+        ch = wl.convH_0[0]
+        bands = A.conv3d(list(skip), ch.weight, ch.bias, bias_scale=2.0, groups=3)      # convH_0(cat/2)*2
+        h_up, x_up = A.haar_idwt2d_pair(hh, xx, bands, in_scale=2.0)
+        return self._t_wavelet_tail(name, wl, h_up, x_up, shifts, scales, False)
+
+    def forward_train(self, x_t, t_input, PAN=None, MS=None, prompt=None):
+        """Differentiable forward (dropout active when ``self.training``); used by
+        ``GeneralDiffusion.p_losses_dynamic``.  Same graph as ``forward``, nothing cached."""
+        from . import autograd as A
+        dev = x_t.device
+        if dev.type != "cuda":
+            raise RuntimeError("tmdiff_amd.WavBEST runs on the HIP kernels only: move the module to a GPU (.cuda())")
+        b = x_t.shape[0]
+        lin = lambda seq, i, x, act: A.linear(x, seq[i].weight, seq[i].bias, act=act)
+        pe = self._prompt_rows(prompt, b, dev)
+        pemb = lin(self.embed2, 4, lin(self.embed2, 2, lin(self.embed2, 0, pe, True), True), True)
+        t = t_input.reshape(-1).to(device=dev, dtype=torch.float32)
+        t = (t if t.numel() == b else t.expand(b)).contiguous()
+        g = ops.gamma_embedding(t, self._freqs_cpu.to(dev), self.inter_dim)
+        temb = lin(self.embed, 2, lin(self.embed, 0, g, True), True)
+
+        shift_layers, scale_layers = [], []
+        for name, m in self.named_modules():
+            if isinstance(m, ResBlockModulateBEST):
+                scale_layers.append((name + ".dense2", m.dense2.dense))
+                if not m.flag:
+                    shift_layers.append((name + ".dense1", m.dense1.dense))
+            elif isinstance(m, WaveletUPorDown):
+                scale_layers.append((name + ".dense1", m.dense1.dense))
+                if not m.flag:
+                    shift_layers.append((name + ".Dense_0", m.Dense_0))
+            elif isinstance(m, (AdaptionModulateBEST, FinalBlockModulateBEST)):
+                scale_layers.append((name + ".dense2", m.dense2.dense))
+
+        def bank(x, layers):     # one launch for all projections of x; autograd splits the gradient back
+            out = A.linear(x, torch.cat([l.weight for _, l in layers]), torch.cat([l.bias for _, l in layers]))
+            res, off = {}, 0
+            for n_, l in layers:
+                res[n_] = out[:, off:off + l.out_features]
+                off += l.out_features
+            return res
+
+        shifts, scales = bank(temb, shift_layers), bank(pemb, scale_layers)
+
+        def stem_block(blk, name, **inp):
+            a0 = A.stem(blk.conv20.weight, blk.conv20.bias, **inp)
+            return A.conv3d([a0], blk.conv21.weight, None, scale=scales[name + ".dense2"])
+
+        cond = {0: stem_block(self.conv1, "conv1", pan=PAN.contiguous(), ms=MS.contiguous())}
+        skips = {}
+        h = cond[0]
+        for lvl, dn in enumerate(("down1_1", "down2_1", "down3_1"), start=1):
+            h = self._t_resblock(dn + ".conv20", [h], shifts, scales, True)
+            h, skips[lvl] = self._t_down(dn + ".down", h, shifts, scales, True, True)
+            cond[lvl] = h
+        hs = [stem_block(self.conv2, "conv2", xin=x_t.contiguous())]
+        h = hs[0]
+        for dn in ("down1", "down2", "down3"):
+            h = self._t_resblock(dn + ".conv20", [h], shifts, scales, False)
+            h, _ = self._t_down(dn + ".down", h, shifts, scales, False, False)
+            hs.append(h)
+        h = self._t_resblock("middle1", [hs[3]], shifts, scales, False)
+        for lvl, upn in ((3, "up1"), (2, "up2"), (1, "up3")):
+            h = self._t_resblock(upn + ".conv20", [h, cond[lvl], hs[lvl]], shifts, scales, False)
+            h = self._t_up(upn + ".up1", h, skips[lvl], shifts, scales)
+        h = self._t_resblock("final.conv20", [h, cond[0], hs[0]], shifts, scales, False)
+        for k in (1, 2, 3):
+            h = self._t_resblock(f"final.conv2{k}", [h], shifts, scales, False)
+        return A.head(h, self.final.conv24.weight, scales["final.dense2"])

@@ -35,6 +35,13 @@ SIGNATURES = {
     "tmdiff_last_error_string": (C.c_char_p, []),
     "tmdiff_conv3d_pack_weights": (C.c_int, [vp, vp, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32, vp]),
     "tmdiff_conv3d_fwd": (C.c_int, [C.POINTER(Conv3dDesc), vp]),
+    "tmdiff_conv3d_wgrad_workspace_bytes": (C.c_size_t, [C.POINTER(Conv3dDesc)]),
+    "tmdiff_conv3d_wgrad": (C.c_int, [C.POINTER(Conv3dDesc), vp, vp, vp, vp]),
+    "tmdiff_channel_sum": (C.c_int, [vp, vp, C.c_int32, C.c_int32, C.c_int64, C.c_float, vp]),
+    "tmdiff_conv3d_prologue_bwd": (C.c_int, [C.POINTER(Conv3dDesc), vp, vp * 3, C.c_int32 * 3, vp, vp, vp]),
+    "tmdiff_stem_bwd": (C.c_int, [vp, vp, vp, vp, vp, vp, vp, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32, vp]),
+    "tmdiff_head_bwd": (C.c_int, [vp, vp, vp, vp, vp, vp, C.c_int32, C.c_int32, C.c_int64, vp]),
+    "tmdiff_linear_bwd": (C.c_int, [vp, vp, vp, vp, vp, vp, vp, vp, C.c_int32, C.c_int32, C.c_int32, C.c_int32, vp]),
     "tmdiff_stem_fwd": (C.c_int, [vp, vp, vp, vp, vp, vp, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32,
                                   C.c_int32, vp]),
     "tmdiff_head_fwd": (C.c_int, [vp, vp, vp, C.c_int32, vp, C.c_int32, C.c_int32, C.c_int64, vp]),

@@ -1,0 +1,188 @@
+"""torch.autograd.Function wrappers of the fused HIP ops: the finetune (training) path of WavBEST.
+
+Forward and backward both run in libtmdiff_hip.so; autograd only wires the graph ("each HIP op is
+wrapped in a torch.autograd.Function with explicit backward").  Reference semantics being differentiated:
+GeneralModel/Hyper_unet_general.py:51-77 (modulated conv), :237-249 (ResBlock), :369-414 (wavelet block),
+DWT_IDWT/DWT_IDWT_Functions.py:60-69, :104-112 (hand-written DWT/IDWT backward = the transposed transform).
+"""
+import ctypes as C
+
+import torch
+
+from . import ops
+from ._lib import check, lib
+
+
+class _FusedConv3d(torch.autograd.Function):
+    """y = (conv3d(act(cat(segs) + shift) * scale * mask, w) + bias_scale*bias + residual) * out_scale"""
+
+    @staticmethod
+    def forward(ctx, meta, weight, bias, shift, scale, residual, mask, *segs):
+        act, groups, bias_scale, out_scale = meta
+        segs = [s.contiguous() for s in segs]
+        w = weight.contiguous()
+        cout, ksize = w.shape[0], w.shape[2]
+        wp = ops.pack_conv_weight(w, groups=groups, mode=0)
+        y = ops.conv3d(segs, wp, cout, ksize, groups=groups, bias=bias, bias_scale=bias_scale, in_shift=shift,
+                       in_scale=scale, in_act=act, in_mask=mask, residual=residual, out_scale=out_scale)
+        ctx.meta = meta
+        ctx.nseg = len(segs)
+        ctx.has = (bias is not None, shift is not None, scale is not None, residual is not None, mask is not None)
+        ctx.save_for_backward(w, *(t for t in (shift, scale, mask) if t is not None), *segs)
+        return y
+
+    @staticmethod
+    def backward(ctx, gy):
+        act, groups, bias_scale, out_scale = ctx.meta
+        has_bias, has_shift, has_scale, has_res, has_mask = ctx.has
+        saved = list(ctx.saved_tensors)
+        w = saved.pop(0)
+        shift = saved.pop(0) if has_shift else None
+        scale = saved.pop(0) if has_scale else None
+        mask = saved.pop(0) if has_mask else None
+        segs = saved
+        need = ctx.needs_input_grad  # (meta, weight, bias, shift, scale, residual, mask, *segs)
+        g = gy.contiguous()
+        if out_scale != 1.0:
+            g = ops.axpby([g], [out_scale])
+        cout, cin_g, ksize = w.shape[0], w.shape[1], w.shape[2]
+        cin = cin_g * groups
+        b, _, n, h, wd = segs[0].shape
+        d_bias = ops.channel_sum(g, bias_scale) if (has_bias and need[2]) else None
+        d_res = g if (has_res and need[5]) else None
+        # descriptor of the forward prologue (what x' was): used by wgrad and by the prologue backward
+        dummy = torch.empty(b, cout, n, h, wd, device=g.device, dtype=torch.float32) if False else g
+        desc = ops.make_conv_desc(segs, 0, cout, ksize, dummy, groups=groups, in_shift=shift, in_scale=scale,
+                                  in_act=act, in_mask=mask)
+        d_w = ops.conv3d_wgrad(desc, g, tuple(w.shape)) if need[1] else None
+        need_x = any(need[7:]) or (has_shift and need[3]) or (has_scale and need[4])
+        d_shift = d_scale = None
+        d_segs = [None] * len(segs)
+        if need_x:
+            wp_t = ops.pack_conv_weight(w, groups=groups, mode=1)
+            gp = ops.conv3d([g], wp_t, cin, ksize, groups=groups)          # dL/dx'
+            outs = [torch.empty_like(s) if need[7 + i] else None for i, s in enumerate(segs)]
+            d_shift, d_scale = ops.conv3d_prologue_bwd(desc, gp, outs, [False] * len(segs),
+                                                       has_shift and need[3], has_scale and need[4])
+            d_segs = outs
+        return (None, d_w, d_bias, d_shift, d_scale, d_res, None, *d_segs)
+
+
+def conv3d(segs, weight, bias=None, bias_scale=1.0, shift=None, scale=None, act=False, mask=None, residual=None,
+           groups=1, out_scale=1.0):
+    """Differentiable fused convolution; shift / scale are dense [B, Cin] tensors."""
+    b = segs[0].shape[0]
+    fix = lambda t: None if t is None else (t.expand(b, t.shape[1]) if t.shape[0] != b else t).contiguous()
+    return _FusedConv3d.apply((bool(act), int(groups), float(bias_scale), float(out_scale)), weight, bias, fix(shift),
+                              fix(scale), residual, mask, *segs)
+
+
+class _HaarDWT(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, want_high, ll_scale):
+        ctx.want_high, ctx.ll_scale = want_high, ll_scale
+        outs = ops.haar_dwt2d(x.contiguous(), want_high=want_high, ll_scale=ll_scale)
+        return tuple(o for o in outs if o is not None)
+
+    @staticmethod
+    def backward(ctx, *grads):
+        g_ll = grads[0].contiguous()
+        if ctx.want_high and any(g is not None for g in grads[1:]):
+            hi = [g.contiguous() if g is not None else torch.zeros_like(g_ll) for g in grads[1:]]
+            dx = ops.haar_idwt2d([g_ll], *hi, in_scale=ctx.ll_scale)[0]
+        else:
+            dx = ops.haar_idwt2d([g_ll], None, None, None, in_scale=ctx.ll_scale)[0]
+        return dx, None, None
+
+
+def haar_dwt2d(x, want_high=True, ll_scale=1.0):
+    outs = _HaarDWT.apply(x, want_high, ll_scale)
+    return tuple(outs) + (None,) * (4 - len(outs))
+
+
+class _HaarIDWT2(torch.autograd.Function):
+    """(h_up, x_up) = (IDWT(s*h, bands), IDWT(s*x, bands)); bands = stacked [B, 3C, N, h, w]"""
+
+    @staticmethod
+    def forward(ctx, h, x, bands, in_scale):
+        ctx.in_scale = in_scale
+        return tuple(ops.haar_idwt2d([h.contiguous(), x.contiguous()], None, None, None, in_scale=in_scale,
+                                     stacked_bands=bands.contiguous()))
+
+    @staticmethod
+    def backward(ctx, g_h, g_x):
+        ah = ops.haar_dwt2d(g_h.contiguous(), want_high=True, ll_scale=ctx.in_scale)
+        ax = ops.haar_dwt2d(g_x.contiguous(), want_high=True, ll_scale=ctx.in_scale)
+        d_bands = torch.cat([ops.add(ah[k], ax[k]) for k in (1, 2, 3)], dim=1)
+        return ah[0], ax[0], d_bands, None
+
+
+def haar_idwt2d_pair(h, x, bands, in_scale=1.0):
+    return _HaarIDWT2.apply(h, x, bands, in_scale)
+
+
+class _Stem(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, weight, bias, xin, pan, ms):
+        c0 = weight.shape[0]
+        w = weight.reshape(-1).contiguous()
+        y = ops.stem(w, bias, c0, xin=xin, pan=pan, ms=ms)
+        ctx.save_for_backward(w, bias, *(t for t in (xin, pan, ms) if t is not None))
+        ctx.mode = xin is not None
+        ctx.wshape = weight.shape
+        return y
+
+    @staticmethod
+    def backward(ctx, gy):
+        w, bias, *ins = ctx.saved_tensors
+        kw = {"xin": ins[0]} if ctx.mode else {"pan": ins[0], "ms": ins[1]}
+        dwb = ops.stem_bwd(w, bias, gy.contiguous(), **kw).sum(0)       # [C0, 2], tiny
+        return dwb[:, 0].reshape(ctx.wshape), dwb[:, 1].contiguous(), None, None, None
+
+
+def stem(weight, bias, xin=None, pan=None, ms=None):
+    return _Stem.apply(weight, bias, xin, pan, ms)
+
+
+class _Head(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, weight, scale):
+        w = weight.reshape(-1).contiguous()
+        x = x.contiguous()
+        scale = scale.expand(x.shape[0], scale.shape[1]).contiguous()
+        ctx.save_for_backward(x, w, scale)
+        ctx.wshape = weight.shape
+        return ops.head(x, w, scale)
+
+    @staticmethod
+    def backward(ctx, gy):
+        x, w, scale = ctx.saved_tensors
+        dx, dws = ops.head_bwd(x, w, scale, gy.contiguous(), need_dx=ctx.needs_input_grad[0])
+        d_w = (dws * scale).sum(0).reshape(ctx.wshape)     # [B, C] elementwise on tiny tensors
+        d_scale = dws * w[None, :]
+        return dx, d_w, d_scale
+
+
+def head(x, weight, scale):
+    return _Head.apply(x, weight, scale)
+
+
+class _Linear(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, weight, bias, act):
+        x, weight = x.contiguous(), weight.contiguous()
+        ctx.act = act
+        ctx.save_for_backward(x, weight, bias)
+        return ops.linear(x, weight, bias, act=act)
+
+    @staticmethod
+    def backward(ctx, gy):
+        x, w, bias = ctx.saved_tensors
+        n = ctx.needs_input_grad
+        dx, dw, db = ops.linear_bwd(x, w, bias, gy.contiguous(), act=ctx.act, need_dx=n[0], need_dw=n[1],
+                                    need_db=n[2] and bias is not None)
+        return dx, dw, db, None
+
+
+def linear(x, weight, bias=None, act=False):
+    return _Linear.apply(x, weight, bias, act)

@@ -1,0 +1,503 @@
+// Backward kernels of the finetune path for gfx950.
+//
+// The reference gets these from ATen autograd (F.conv3d / nn.Conv3d / nn.Linear backward, elementwise
+// SiLU / add / mul backward: GeneralModel/Hyper_unet_general.py:51-77, :100-113, :158-273, :334-414).  Here:
+//   dL/dx'  : the forward MFMA kernel on g with data-gradient packed weights (conv3d.hip, pack mode 1)
+//   dL/dw   : conv3d_wgrad_kernel below (fp32 MFMA; K = batch x positions, split over workgroups, then reduced)
+//   dL/dx, dL/dshift, dL/dscale : prologue_bwd_kernel (HBM-bound, one workgroup per (b, c) plane)
+//   bias grads, stem / head / linear backward: small HBM-bound reductions.
+#include "common.h"
+
+namespace {
+
+using f32x16 = __attribute__((ext_vector_type(16))) float;
+
+__device__ __forceinline__ float silu_grad(float t) {  // d/dt [t * sigmoid(t)]
+  const float s = 1.0f / (1.0f + __expf(-t));
+  return s * (1.0f + t * (1.0f - s));
+}
+
+__device__ __forceinline__ float block_sum_256(float v, float* red) {
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
+  const int w = threadIdx.x >> 6;
+  __syncthreads();
+  if ((threadIdx.x & 63) == 0) red[w] = v;
+  __syncthreads();
+  return red[0] + red[1] + red[2] + red[3];
+}
+
+// ---------------------------------------------------------------------------------------------------
+// wgrad.  GEMM view per (group, tap):  dW[co, ci] = sum_{b,pos} g[b,co,pos] * x'[b,ci,pos+tap]
+//   MFMA rows (A) = 32 output channels : lane l holds g[co = l&31][k = l>>5]
+//   MFMA cols (B) = 32 input channels  : lane l holds x'[ci = l&31] at position k = l>>5, shifted by the tap
+//   K step = 2 positions.
+// A workgroup owns a 32x32 (co, ci) tile and walks a list of 2x8x8 position boxes; per box it stages the g box
+// [32][128] and the haloed, prologue-applied x' box [32][4*10*10] in LDS (odd row strides: conflict-free
+// column reads).  KS=3: wave w accumulates taps w, w+4, ... (7 accumulators, the g operand is shared by all of
+// them); KS=1: the four waves split the positions of the box and their partials are separate splits.
+// Partials go to workspace[split][g][tap][co][ci]; wgrad_reduce_kernel sums the splits into PyTorch layout.
+// ---------------------------------------------------------------------------------------------------
+struct WgradArgs {
+  int B, N, H, W, Cin, Cout, cin_g, cout_g, groups, nseg;
+  int seg_c[3];
+  const float* seg_x[3];
+  const float* in_shift;
+  const float* in_scale;
+  int shift_stride, scale_stride;
+  const float* in_mask;
+  int in_act;
+  const float* g;
+  float* ws;
+  int nbn, nbh, nbw;       // boxes per sample along n, h, w
+  int tiles_co, tiles_ci;  // per group
+  int splits, boxes_per_split;
+  long total_boxes;
+};
+
+template <int KS>
+__global__ void __launch_bounds__(256, 2) conv3d_wgrad_kernel(const WgradArgs a) {
+  constexpr int TAPS = KS * KS * KS, HALO = KS / 2;
+  constexpr int BN = 2, BH = 8, BW = 8, POSB = BN * BH * BW;            // 128 positions per box
+  constexpr int HN = BN + 2 * HALO, HH = BH + 2 * HALO, HW = BW + 2 * HALO;
+  constexpr int XE = HN * HH * HW;                                      // haloed box elements
+  constexpr int GS = POSB + 1, XS = XE | 1;                             // odd LDS row strides
+  constexpr int NT = KS == 3 ? 7 : 1;                                   // accumulators per wave
+  __shared__ float gt[32 * GS];
+  __shared__ float xt[32 * XS];
+
+  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, l31 = lane & 31, khalf = lane >> 5;
+  int id = blockIdx.x;
+  const int split = id % a.splits; id /= a.splits;
+  const int ci_t = id % a.tiles_ci; id /= a.tiles_ci;
+  const int co_t = id % a.tiles_co;
+  const int g = id / a.tiles_co;
+  const int co0 = co_t * 32, ci0 = ci_t * 32;
+  const long plane = (long)a.N * a.H * a.W;
+
+  f32x16 acc[NT];
+#pragma unroll
+  for (int j = 0; j < NT; ++j)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[j][r] = 0.f;
+
+  const long box_lo = (long)split * a.boxes_per_split;
+  const long box_hi = min(box_lo + a.boxes_per_split, a.total_boxes);
+  for (long bx = box_lo; bx < box_hi; ++bx) {
+    long t = bx;
+    const int bw_i = (int)(t % a.nbw); t /= a.nbw;
+    const int bh_i = (int)(t % a.nbh); t /= a.nbh;
+    const int bn_i = (int)(t % a.nbn);
+    const int b = (int)(t / a.nbn);
+    const int n0 = bn_i * BN, h0 = bh_i * BH, w0 = bw_i * BW;
+    __syncthreads();  // previous box fully consumed
+    // ---- stage g box: [32 co][128 pos] ---------------------------------------------------------------------
+    for (int e = tid; e < 32 * POSB; e += 256) {
+      const int co = e / POSB, p = e % POSB;
+      const int n = n0 + p / (BH * BW), h = h0 + (p / BW) % BH, w = w0 + p % BW;
+      float v = 0.f;
+      if (co0 + co < a.cout_g && n < a.N && h < a.H && w < a.W)
+        v = a.g[((long)b * a.Cout + g * a.cout_g + co0 + co) * plane + ((long)n * a.H + h) * a.W + w];
+      gt[co * GS + p] = v;
+    }
+    // ---- stage x' box: [32 ci][haloed], prologue applied once per element, padding exactly zero ------------
+    for (int ci = 0; ci < 32; ++ci) {
+      const int cl = ci0 + ci;
+      const bool cvalid = cl < a.cin_g;
+      const int cg = g * a.cin_g + (cvalid ? cl : 0);
+      float sh = 0.f, sc = 1.f;
+      if (a.in_shift) sh = a.in_shift[(long)b * a.shift_stride + cg];
+      if (a.in_scale) sc = a.in_scale[(long)b * a.scale_stride + cg];
+      int cs = cg, segc = a.seg_c[0];
+      const float* base = a.seg_x[0];
+      if (a.nseg > 1 && cs >= segc) {
+        cs -= segc; base = a.seg_x[1]; segc = a.seg_c[1];
+        if (a.nseg > 2 && cs >= segc) { cs -= segc; base = a.seg_x[2]; segc = a.seg_c[2]; }
+      }
+      const float* src = base + ((long)b * segc + cs) * plane;
+      const float* msk = a.in_mask ? a.in_mask + ((long)b * a.Cin + cg) * plane : nullptr;
+      for (int e = tid; e < XE; e += 256) {
+        const int wz = e % HW, hz = (e / HW) % HH, nz = e / (HW * HH);
+        const int n = n0 + nz - HALO, h = h0 + hz - HALO, w = w0 + wz - HALO;
+        float v = 0.f;
+        if (cvalid && n >= 0 && n < a.N && h >= 0 && h < a.H && w >= 0 && w < a.W) {
+          const long o = ((long)n * a.H + h) * a.W + w;
+          v = src[o] + sh;
+          if (a.in_act) v = tmdiff::silu_f(v);
+          v *= sc;
+          if (msk) v *= msk[o];
+        }
+        xt[ci * XS + e] = v;
+      }
+    }
+    __syncthreads();
+    // ---- K loop over the positions of the box ------------------------------------------------------------------
+    const int ks_lo = KS == 3 ? 0 : wv * (POSB / 8), ks_hi = KS == 3 ? POSB / 2 : (wv + 1) * (POSB / 8);
+    for (int ks = ks_lo; ks < ks_hi; ++ks) {
+      const int p = 2 * ks + khalf;
+      const int pn = p / (BH * BW), ph = (p / BW) % BH, pw = p % BW;
+      const float av = gt[l31 * GS + p];
+      const int xb = l31 * XS + (pn * HH + ph) * HW + pw;
+#pragma unroll
+      for (int j = 0; j < NT; ++j) {
+        const int tap = KS == 3 ? wv + 4 * j : 0;
+        if (tap < TAPS) {  // wave-uniform
+          const int dn = tap / (KS * KS), dh = (tap / KS) % KS, dw = tap % KS;
+          const float bv = xt[xb + (dn * HH + dh) * HW + dw];
+          acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bv, acc[j], 0, 0, 0);
+        }
+      }
+    }
+  }
+  // ---- partial sums -> workspace[slot][g][tap][co][ci]; D layout: col = l31 (ci), row = co ----------------------
+  const int slot = KS == 3 ? split : split * 4 + wv;
+#pragma unroll
+  for (int j = 0; j < NT; ++j) {
+    const int tap = KS == 3 ? wv + 4 * j : 0;
+    if (tap >= TAPS) continue;
+    float* dst = a.ws + (((long)slot * a.groups + g) * TAPS + tap) * a.cout_g * a.cin_g;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int co = co0 + (r & 3) + 8 * (r >> 2) + 4 * khalf, ci = ci0 + l31;
+      if (co < a.cout_g && ci < a.cin_g) dst[(long)co * a.cin_g + ci] = acc[j][r];
+    }
+  }
+}
+
+// dw[g*cout_g + co][ci][tap] = sum_slot ws[slot][g][tap][co][ci]
+__global__ void __launch_bounds__(256) wgrad_reduce_kernel(const float* __restrict__ ws, float* __restrict__ dw,
+                                                           int slots, int groups, int taps, int cout_g, int cin_g,
+                                                           long total) {
+  const long per_slot = (long)groups * taps * cout_g * cin_g;
+  for (long i = blockIdx.x * 256L + threadIdx.x; i < total; i += 256L * gridDim.x) {
+    // i enumerates the workspace order [g][tap][co][ci] (coalesced reads)
+    const int ci = (int)(i % cin_g);
+    long r = i / cin_g;
+    const int co = (int)(r % cout_g); r /= cout_g;
+    const int tap = (int)(r % taps);
+    const int g = (int)(r / taps);
+    float s = 0.f;
+    for (int k = 0; k < slots; ++k) s += ws[k * per_slot + i];
+    dw[(((long)g * cout_g + co) * cin_g + ci) * taps + tap] = s;
+  }
+}
+
+// out[c] = scale * sum_{b,p} x[b,c,p]; one workgroup per channel
+__global__ void __launch_bounds__(256) channel_sum_kernel(const float* __restrict__ x, float* __restrict__ out, int B,
+                                                          int C, long P, float scale) {
+  __shared__ float red[4];
+  const int c = blockIdx.x;
+  float s = 0.f;
+  for (int b = 0; b < B; ++b) {
+    const float* p = x + ((long)b * C + c) * P;
+    for (long i = threadIdx.x; i < P; i += 256) s += p[i];
+  }
+  s = block_sum_256(s, red);
+  if (threadIdx.x == 0) out[c] = scale * s;
+}
+
+struct PrologueBwdArgs {
+  int B, Cin, nseg;
+  int seg_c[3];
+  const float* seg_x[3];
+  float* dx[3];
+  int accumulate[3];
+  const float* in_shift;
+  const float* in_scale;
+  int shift_stride, scale_stride;
+  const float* in_mask;
+  int in_act;
+  const float* gp;
+  float* d_shift;
+  float* d_scale;
+  long plane;
+};
+
+// one workgroup per (b, c) plane
+__global__ void __launch_bounds__(256) prologue_bwd_kernel(const PrologueBwdArgs a) {
+  __shared__ float red[4];
+  const int c = blockIdx.x, b = blockIdx.y;
+  const float sh = a.in_shift ? a.in_shift[(long)b * a.shift_stride + c] : 0.f;
+  const float sc = a.in_scale ? a.in_scale[(long)b * a.scale_stride + c] : 1.f;
+  int cs = c, seg = 0;
+  if (a.nseg > 1 && cs >= a.seg_c[0]) { cs -= a.seg_c[0]; seg = 1; }
+  if (seg == 1 && a.nseg > 2 && cs >= a.seg_c[1]) { cs -= a.seg_c[1]; seg = 2; }
+  const int segc = seg == 0 ? a.seg_c[0] : (seg == 1 ? a.seg_c[1] : a.seg_c[2]);
+  const float* xs = (seg == 0 ? a.seg_x[0] : (seg == 1 ? a.seg_x[1] : a.seg_x[2])) + ((long)b * segc + cs) * a.plane;
+  float* dxs = seg == 0 ? a.dx[0] : (seg == 1 ? a.dx[1] : a.dx[2]);
+  const int accum = seg == 0 ? a.accumulate[0] : (seg == 1 ? a.accumulate[1] : a.accumulate[2]);
+  if (dxs) dxs += ((long)b * segc + cs) * a.plane;
+  const float* gp = a.gp + ((long)b * a.Cin + c) * a.plane;
+  const float* msk = a.in_mask ? a.in_mask + ((long)b * a.Cin + c) * a.plane : nullptr;
+  float s_sh = 0.f, s_sc = 0.f;
+  for (long i = threadIdx.x; i < a.plane; i += 256) {
+    const float t = xs[i] + sh;
+    const float act = a.in_act ? tmdiff::silu_f(t) : t;
+    const float dact = a.in_act ? silu_grad(t) : 1.f;
+    const float gm = msk ? gp[i] * msk[i] : gp[i];
+    s_sc += gm * act;
+    const float dt = gm * sc * dact;
+    s_sh += dt;
+    if (dxs) dxs[i] = accum ? dxs[i] + dt : dt;
+  }
+  if (a.d_shift) {
+    const float v = block_sum_256(s_sh, red);
+    if (threadIdx.x == 0) a.d_shift[(long)b * a.Cin + c] = v;
+  }
+  if (a.d_scale) {
+    const float v = block_sum_256(s_sc, red);
+    if (threadIdx.x == 0) a.d_scale[(long)b * a.Cin + c] = v;
+  }
+}
+
+// stem backward: one workgroup per (co, b): partial sums over the sample's positions
+__global__ void __launch_bounds__(256) stem_bwd_kernel(const float* __restrict__ xin, const float* __restrict__ pan,
+                                                       const float* __restrict__ ms, const float* __restrict__ w,
+                                                       const float* __restrict__ bias, const float* __restrict__ gy,
+                                                       float* __restrict__ dwb, int Cout, long P, long HW) {
+  __shared__ float red[4];
+  const int co = blockIdx.x, b = blockIdx.y;
+  const float wc = w[co], bc = bias ? bias[co] : 0.f;
+  const float* g = gy + ((long)b * Cout + co) * P;
+  float sw = 0.f, sb = 0.f;
+  for (long p = threadIdx.x; p < P; p += 256) {
+    const float x = ms ? pan[b * HW + p % HW] - ms[b * P + p] : xin[b * P + p];
+    const float u = __fadd_rn(__fmul_rn(wc, x), bc);
+    const float gu = g[p] * silu_grad(u);
+    sw += gu * x;
+    sb += gu;
+  }
+  const float tw = block_sum_256(sw, red);
+  const float tb = block_sum_256(sb, red);
+  if (threadIdx.x == 0) {
+    dwb[((long)b * Cout + co) * 2 + 0] = tw;
+    dwb[((long)b * Cout + co) * 2 + 1] = tb;
+  }
+}
+
+// head backward: one workgroup per (c, b)
+__global__ void __launch_bounds__(256) head_bwd_kernel(const float* __restrict__ x, const float* __restrict__ w,
+                                                       const float* __restrict__ scale, const float* __restrict__ gy,
+                                                       float* __restrict__ dx, float* __restrict__ dws, int C, long P) {
+  __shared__ float red[4];
+  const int c = blockIdx.x, b = blockIdx.y;
+  const float wsv = scale ? __fmul_rn(w[c], scale[(long)b * C + c]) : w[c];
+  const float* xs = x + ((long)b * C + c) * P;
+  float* dxs = dx ? dx + ((long)b * C + c) * P : nullptr;
+  const float* g = gy + (long)b * P;
+  float s = 0.f;
+  for (long p = threadIdx.x; p < P; p += 256) {
+    const float v = xs[p], gp = g[p];
+    s += gp * tmdiff::silu_f(v);
+    if (dxs) dxs[p] = gp * wsv * silu_grad(v);
+  }
+  const float tot = block_sum_256(s, red);
+  if (threadIdx.x == 0 && dws) dws[(long)b * C + c] = tot;
+}
+
+// linear backward.  gu[b,o] = gy[b,o] * act'(u[b,o]), u = x @ w^T + bias (recomputed when act != 0).
+// kernel 1: gu (B x O), one wave per (o) like the forward.   kernel 2: dx / dw / db from gu.
+__global__ void __launch_bounds__(256) linear_gu_kernel(const float* __restrict__ x, const float* __restrict__ w,
+                                                        const float* __restrict__ bias, const float* __restrict__ gy,
+                                                        float* __restrict__ gu, int B, int I, int O, int act) {
+  const int lane = threadIdx.x & 63;
+  const int o = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (o >= O) return;
+  for (int b = 0; b < B; ++b) {
+    float v = gy[(long)b * O + o];
+    if (act) {
+      float s = 0.f;
+      for (int i = lane; i < I; i += 64) s = fmaf(w[(long)o * I + i], x[(long)b * I + i], s);
+#pragma unroll
+      for (int off = 32; off > 0; off >>= 1) s += __shfl_xor(s, off, 64);
+      v *= silu_grad(s + (bias ? bias[o] : 0.f));
+    }
+    if (lane == 0) gu[(long)b * O + o] = v;
+  }
+}
+
+__global__ void __launch_bounds__(256) linear_dw_kernel(const float* __restrict__ x, const float* __restrict__ gu,
+                                                        float* __restrict__ dw, float* __restrict__ db, int B, int I,
+                                                        int O) {
+  const long i = blockIdx.x * 256L + threadIdx.x;  // over O*I
+  if (i < (long)O * I) {
+    const int o = (int)(i / I), k = (int)(i % I);
+    float s = 0.f;
+    for (int b = 0; b < B; ++b) s = fmaf(gu[(long)b * O + o], x[(long)b * I + k], s);
+    if (dw) dw[i] = s;
+  }
+  if (db && i < O) {
+    float s = 0.f;
+    for (int b = 0; b < B; ++b) s += gu[(long)b * O + i];
+    db[i] = s;
+  }
+}
+
+__global__ void __launch_bounds__(256) linear_dx_kernel(const float* __restrict__ w, const float* __restrict__ gu,
+                                                        float* __restrict__ dx, int B, int I, int O) {
+  const long i = blockIdx.x * 256L + threadIdx.x;  // over B*I
+  if (i >= (long)B * I) return;
+  const int b = (int)(i / I), k = (int)(i % I);
+  float s = 0.f;
+  for (int o = 0; o < O; ++o) s = fmaf(gu[(long)b * O + o], w[(long)o * I + k], s);
+  dx[i] = s;
+}
+
+struct WgradPlan {
+  int taps, nbn, nbh, nbw, tiles_co, tiles_ci, splits, boxes_per_split, slots;
+  long total_boxes;
+};
+
+inline WgradPlan plan_wgrad(const tmdiff_conv3d_desc* d) {
+  WgradPlan p;
+  p.taps = d->ksize * d->ksize * d->ksize;
+  p.nbn = (d->N + 1) / 2; p.nbh = (d->H + 7) / 8; p.nbw = (d->W + 7) / 8;
+  p.total_boxes = (long)d->B * p.nbn * p.nbh * p.nbw;
+  const int cout_g = d->Cout / d->groups, cin_g = d->Cin / d->groups;
+  p.tiles_co = (cout_g + 31) / 32; p.tiles_ci = (cin_g + 31) / 32;
+  const long tiles = (long)d->groups * p.tiles_co * p.tiles_ci;
+  long splits = (1024 + tiles - 1) / tiles;  // ~4 workgroups per CU
+  if (splits > p.total_boxes) splits = p.total_boxes;
+  if (splits < 1) splits = 1;
+  p.boxes_per_split = (int)((p.total_boxes + splits - 1) / splits);
+  p.splits = (int)((p.total_boxes + p.boxes_per_split - 1) / p.boxes_per_split);
+  p.slots = d->ksize == 3 ? p.splits : p.splits * 4;
+  return p;
+}
+
+}  // namespace
+
+extern "C" size_t tmdiff_conv3d_wgrad_workspace_bytes(const tmdiff_conv3d_desc* d) {
+  if (!d || d->B <= 0 || d->groups <= 0 || (d->ksize != 1 && d->ksize != 3)) return 0;
+  const WgradPlan p = plan_wgrad(d);
+  return (size_t)p.slots * d->Cout * (d->Cin / d->groups) * p.taps * sizeof(float);
+}
+
+extern "C" int tmdiff_conv3d_wgrad(const tmdiff_conv3d_desc* d, const float* g, float* dw, void* workspace,
+                                   tmdiff_stream_t stream) {
+  using namespace tmdiff;
+  TMDIFF_REQUIRE(d && g && dw, "conv3d_wgrad: NULL pointer");
+  TMDIFF_REQUIRE(d->ksize == 1 || d->ksize == 3, "conv3d_wgrad: ksize=%d", d->ksize);
+  TMDIFF_REQUIRE(d->groups == 1 || d->groups == 3, "conv3d_wgrad: groups=%d", d->groups);
+  TMDIFF_REQUIRE(d->B > 0 && d->N > 0 && d->H > 0 && d->W > 0 && d->Cin > 0 && d->Cout > 0 &&
+                     d->Cin % d->groups == 0 && d->Cout % d->groups == 0, "conv3d_wgrad: bad extents");
+  TMDIFF_REQUIRE(d->nseg >= 1 && d->nseg <= 3, "conv3d_wgrad: nseg=%d", d->nseg);
+  int csum = 0;
+  for (int i = 0; i < d->nseg; ++i) {
+    TMDIFF_REQUIRE(d->seg_x[i] && d->seg_c[i] > 0, "conv3d_wgrad: segment %d is empty", i);
+    csum += d->seg_c[i];
+  }
+  TMDIFF_REQUIRE(csum == d->Cin, "conv3d_wgrad: segments hold %d channels, Cin=%d", csum, d->Cin);
+  TMDIFF_REQUIRE(workspace != nullptr, "conv3d_wgrad: NULL workspace");
+  const WgradPlan p = plan_wgrad(d);
+  WgradArgs a;
+  a.B = d->B; a.N = d->N; a.H = d->H; a.W = d->W; a.Cin = d->Cin; a.Cout = d->Cout;
+  a.groups = d->groups; a.cin_g = d->Cin / d->groups; a.cout_g = d->Cout / d->groups; a.nseg = d->nseg;
+  for (int i = 0; i < 3; ++i) { a.seg_c[i] = i < d->nseg ? d->seg_c[i] : 0; a.seg_x[i] = i < d->nseg ? d->seg_x[i] : nullptr; }
+  a.in_shift = d->in_shift; a.in_scale = d->in_scale; a.in_mask = d->in_mask; a.in_act = d->in_act;
+  a.shift_stride = d->in_shift_stride > 0 ? d->in_shift_stride : (d->in_shift_stride < 0 ? 0 : d->Cin);
+  a.scale_stride = d->in_scale_stride > 0 ? d->in_scale_stride : (d->in_scale_stride < 0 ? 0 : d->Cin);
+  a.g = g; a.ws = reinterpret_cast<float*>(workspace);
+  a.nbn = p.nbn; a.nbh = p.nbh; a.nbw = p.nbw; a.tiles_co = p.tiles_co; a.tiles_ci = p.tiles_ci;
+  a.splits = p.splits; a.boxes_per_split = p.boxes_per_split; a.total_boxes = p.total_boxes;
+  const long blocks = (long)d->groups * p.tiles_co * p.tiles_ci * p.splits;
+  hipStream_t st = as_stream(stream);
+  if (d->ksize == 3)
+    conv3d_wgrad_kernel<3><<<(unsigned)blocks, 256, 0, st>>>(a);
+  else
+    conv3d_wgrad_kernel<1><<<(unsigned)blocks, 256, 0, st>>>(a);
+  int rc = check_launch("conv3d_wgrad");
+  if (rc) return rc;
+  const long total = (long)d->Cout * a.cin_g * p.taps;
+  long rb = (total + 255) / 256;
+  if (rb > 4096) rb = 4096;
+  wgrad_reduce_kernel<<<(unsigned)rb, 256, 0, st>>>(a.ws, dw, p.slots, d->groups, p.taps, a.cout_g, a.cin_g, total);
+  return check_launch("conv3d_wgrad(reduce)");
+}
+
+extern "C" int tmdiff_channel_sum(const float* x, float* out, int32_t B, int32_t C, int64_t P, float scale,
+                                  tmdiff_stream_t stream) {
+  using namespace tmdiff;
+  TMDIFF_REQUIRE(x && out && B >= 0 && C > 0 && P > 0, "channel_sum: bad arguments");
+  channel_sum_kernel<<<C, 256, 0, as_stream(stream)>>>(x, out, B, C, P, scale);
+  return check_launch("channel_sum");
+}
+
+extern "C" int tmdiff_conv3d_prologue_bwd(const tmdiff_conv3d_desc* d, const float* gp, float* const dx_seg[3],
+                                          const int32_t accumulate[3], float* d_shift, float* d_scale,
+                                          tmdiff_stream_t stream) {
+  using namespace tmdiff;
+  TMDIFF_REQUIRE(d && gp && dx_seg && accumulate, "prologue_bwd: NULL pointer");
+  TMDIFF_REQUIRE(d->B > 0 && d->Cin > 0 && d->B <= 65535 && d->nseg >= 1 && d->nseg <= 3, "prologue_bwd: bad extents");
+  PrologueBwdArgs a;
+  a.B = d->B; a.Cin = d->Cin; a.nseg = d->nseg;
+  int csum = 0;
+  for (int i = 0; i < 3; ++i) {
+    a.seg_c[i] = i < d->nseg ? d->seg_c[i] : 0;
+    a.seg_x[i] = i < d->nseg ? d->seg_x[i] : nullptr;
+    a.dx[i] = i < d->nseg ? dx_seg[i] : nullptr;
+    a.accumulate[i] = i < d->nseg ? accumulate[i] : 0;
+    if (i < d->nseg) {
+      TMDIFF_REQUIRE(d->seg_x[i] != nullptr, "prologue_bwd: segment %d is NULL", i);
+      csum += d->seg_c[i];
+    }
+  }
+  TMDIFF_REQUIRE(csum == d->Cin, "prologue_bwd: segments hold %d channels, Cin=%d", csum, d->Cin);
+  a.in_shift = d->in_shift; a.in_scale = d->in_scale; a.in_mask = d->in_mask; a.in_act = d->in_act;
+  a.shift_stride = d->in_shift_stride > 0 ? d->in_shift_stride : (d->in_shift_stride < 0 ? 0 : d->Cin);
+  a.scale_stride = d->in_scale_stride > 0 ? d->in_scale_stride : (d->in_scale_stride < 0 ? 0 : d->Cin);
+  a.gp = gp; a.d_shift = d_shift; a.d_scale = d_scale;
+  a.plane = (long)d->N * d->H * d->W;
+  prologue_bwd_kernel<<<dim3(d->Cin, d->B), 256, 0, as_stream(stream)>>>(a);
+  return check_launch("conv3d_prologue_bwd");
+}
+
+extern "C" int tmdiff_stem_bwd(const float* xin, const float* pan, const float* ms, const float* w, const float* bias,
+                               const float* gy, float* dwb, int32_t B, int32_t Cout, int32_t N, int32_t H, int32_t W,
+                               tmdiff_stream_t stream) {
+  using namespace tmdiff;
+  TMDIFF_REQUIRE(w && gy && dwb, "stem_bwd: NULL pointer");
+  TMDIFF_REQUIRE((ms && pan) || (!ms && xin), "stem_bwd: give either (pan, ms) or xin");
+  TMDIFF_REQUIRE(B > 0 && B <= 65535 && Cout > 0 && N > 0 && H > 0 && W > 0, "stem_bwd: bad extents");
+  const long HW = (long)H * W;
+  stem_bwd_kernel<<<dim3(Cout, B), 256, 0, as_stream(stream)>>>(xin, pan, ms, w, bias, gy, dwb, Cout, HW * N, HW);
+  return check_launch("stem_bwd");
+}
+
+extern "C" int tmdiff_head_bwd(const float* x, const float* w, const float* scale, const float* gy, float* dx,
+                               float* dws, int32_t B, int32_t C, int64_t P, tmdiff_stream_t stream) {
+  using namespace tmdiff;
+  TMDIFF_REQUIRE(x && w && gy, "head_bwd: NULL pointer");
+  TMDIFF_REQUIRE(B > 0 && B <= 65535 && C > 0 && P > 0, "head_bwd: bad extents");
+  head_bwd_kernel<<<dim3(C, B), 256, 0, as_stream(stream)>>>(x, w, scale, gy, dx, dws, C, P);
+  return check_launch("head_bwd");
+}
+
+extern "C" int tmdiff_linear_bwd(const float* x, const float* w, const float* bias, const float* gy, float* gu_scratch,
+                                 float* dx, float* dw, float* db, int32_t B, int32_t I, int32_t O, int32_t act,
+                                 tmdiff_stream_t stream) {
+  using namespace tmdiff;
+  TMDIFF_REQUIRE(x && w && gy, "linear_bwd: NULL pointer");
+  TMDIFF_REQUIRE(B > 0 && I > 0 && O > 0, "linear_bwd: bad extents");
+  TMDIFF_REQUIRE(!act || gu_scratch, "linear_bwd: act != 0 needs a [B, O] scratch buffer");
+  hipStream_t st = as_stream(stream);
+  const float* gu = gy;
+  if (act) {  // gu = gy * SiLU'(x @ w^T + bias), pre-activation recomputed
+    linear_gu_kernel<<<(O + 3) / 4, 256, 0, st>>>(x, w, bias, gy, gu_scratch, B, I, O, act);
+    int rc = check_launch("linear_bwd(gu)");
+    if (rc) return rc;
+    gu = gu_scratch;
+  }
+  if (dw || db) {
+    const long n = (long)O * I;
+    linear_dw_kernel<<<(unsigned)((n + 255) / 256), 256, 0, st>>>(x, gu, dw, db, B, I, O);
+    int rc = check_launch("linear_bwd(dw)");
+    if (rc) return rc;
+  }
+  if (dx) {
+    const long n = (long)B * I;
+    linear_dx_kernel<<<(unsigned)((n + 255) / 256), 256, 0, st>>>(w, gu, dx, B, I, O);
+    return check_launch("linear_bwd(dx)");
+  }
+  return TMDIFF_OK;
+}

@@ -105,7 +105,10 @@ __global__ void __launch_bounds__(256) idwt2d_kernel(const float* __restrict__ l
     // high bands may be channel slices of a [B, 3C, N, h, w] tensor: sample stride != planes*h*w
     const long hoff = hi_bstride ? (plane / hi_ppb) * hi_bstride + ((plane % hi_ppb) * h + r) * (long)w + V * j : off;
     float b1[V], b2[V], b3[V];
-    if constexpr (V == 4) {
+    if (lh == nullptr) {  // zero high bands (adjoint of an LL-only dwt)
+#pragma unroll
+      for (int c = 0; c < V; ++c) b1[c] = b2[c] = b3[c] = 0.f;
+    } else if constexpr (V == 4) {
       *reinterpret_cast<float4*>(b1) = *reinterpret_cast<const float4*>(lh + hoff);
       *reinterpret_cast<float4*>(b2) = *reinterpret_cast<const float4*>(hl + hoff);
       *reinterpret_cast<float4*>(b3) = *reinterpret_cast<const float4*>(hh + hoff);
@@ -171,7 +174,8 @@ extern "C" int tmdiff_haar_idwt2d(const float* const ll[2], int32_t n_ll, const 
                                   tmdiff_stream_t stream) {
   using namespace tmdiff;
   TMDIFF_REQUIRE(n_ll == 1 || n_ll == 2, "haar_idwt2d: n_ll=%d must be 1 or 2", n_ll);
-  TMDIFF_REQUIRE(ll && out && ll[0] && out[0] && lh && hl && hh, "haar_idwt2d: NULL band/output");
+  TMDIFF_REQUIRE(ll && out && ll[0] && out[0], "haar_idwt2d: NULL band/output");
+  TMDIFF_REQUIRE((lh && hl && hh) || (!lh && !hl && !hh), "haar_idwt2d: give all three high bands or none");
   TMDIFF_REQUIRE(n_ll == 1 || (ll[1] && out[1]), "haar_idwt2d: second low band / output is NULL");
   TMDIFF_REQUIRE(planes >= 0 && h > 0 && w > 0, "haar_idwt2d: bad sizes");
   TMDIFF_REQUIRE(hi_batch_stride == 0 || (hi_planes_per_batch > 0 && planes % hi_planes_per_batch == 0 &&

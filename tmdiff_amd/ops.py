@@ -217,3 +217,64 @@ def q_sample(x0, noise, a, out=None):
     check(lib.tmdiff_q_sample(_chk(x0, "x0"), _chk(noise, "noise"), _chk(a, "a"), _chk(y, "out"), b,
                               x0.numel() // b, stream_ptr()), "q_sample")
     return y
+
+
+# ---- backward-side wrappers (finetune path) -----------------------------------------------------------
+def conv3d_wgrad(desc, g, weight_shape):
+    """dL/dw [Cout, Cin/g, k,k,k] for the convolution described by `desc` (a filled Conv3dDesc) given g = dL/dy."""
+    dw = torch.empty(weight_shape, device=g.device, dtype=torch.float32)
+    nbytes = lib.tmdiff_conv3d_wgrad_workspace_bytes(C.byref(desc))
+    ws = torch.empty(max(1, nbytes // 4), device=g.device, dtype=torch.float32)
+    check(lib.tmdiff_conv3d_wgrad(C.byref(desc), _chk(g, "g"), dw.data_ptr(), ws.data_ptr(), stream_ptr()),
+          "conv3d_wgrad")
+    return dw
+
+
+def channel_sum(x, scale=1.0):
+    """x [B, C, ...] -> [C]: scale * sum over batch and positions."""
+    b, c = x.shape[:2]
+    out = torch.empty(c, device=x.device, dtype=torch.float32)
+    check(lib.tmdiff_channel_sum(_chk(x, "x"), out.data_ptr(), b, c, x.numel() // (b * c), scale, stream_ptr()),
+          "channel_sum")
+    return out
+
+
+def conv3d_prologue_bwd(desc, gp, dx_segs, accumulate, want_shift, want_scale):
+    b, cin = desc.B, desc.Cin
+    d_shift = torch.empty(b, cin, device=gp.device, dtype=torch.float32) if want_shift else None
+    d_scale = torch.empty(b, cin, device=gp.device, dtype=torch.float32) if want_scale else None
+    dxp = (C.c_void_p * 3)(*[_chk(t, "dx") for t in dx_segs], *([None] * (3 - len(dx_segs))))
+    acc = (C.c_int32 * 3)(*[1 if a else 0 for a in accumulate], *([0] * (3 - len(accumulate))))
+    check(lib.tmdiff_conv3d_prologue_bwd(C.byref(desc), _chk(gp, "gp"), dxp, acc, _chk(d_shift, "d_shift"),
+                                         _chk(d_scale, "d_scale"), stream_ptr()), "conv3d_prologue_bwd")
+    return d_shift, d_scale
+
+
+def stem_bwd(w, bias, gy, xin=None, pan=None, ms=None):
+    b, c0, n, h, wd = gy.shape
+    dwb = torch.empty(b, c0, 2, device=gy.device, dtype=torch.float32)
+    check(lib.tmdiff_stem_bwd(_chk(xin, "xin"), _chk(pan, "pan"), _chk(ms, "ms"), _chk(w, "w"), _chk(bias, "bias"),
+                              _chk(gy, "gy"), dwb.data_ptr(), b, c0, n, h, wd, stream_ptr()), "stem_bwd")
+    return dwb
+
+
+def head_bwd(x, w, scale, gy, need_dx=True):
+    b, c, n, h, wd = x.shape
+    dx = torch.empty_like(x) if need_dx else None
+    dws = torch.empty(b, c, device=x.device, dtype=torch.float32)
+    check(lib.tmdiff_head_bwd(_chk(x, "x"), _chk(w, "w"), _chk(scale, "scale"), _chk(gy, "gy"), _chk(dx, "dx"),
+                              dws.data_ptr(), b, c, n * h * wd, stream_ptr()), "head_bwd")
+    return dx, dws
+
+
+def linear_bwd(x, w, bias, gy, act=False, need_dx=True, need_dw=True, need_db=True):
+    b, i = x.shape
+    o = w.shape[0]
+    dx = torch.empty(b, i, device=x.device, dtype=torch.float32) if need_dx else None
+    dw = torch.empty(o, i, device=x.device, dtype=torch.float32) if need_dw else None
+    db = torch.empty(o, device=x.device, dtype=torch.float32) if need_db else None
+    gu = torch.empty(b, o, device=x.device, dtype=torch.float32) if act else None
+    check(lib.tmdiff_linear_bwd(_chk(x, "x"), _chk(w, "w"), _chk(bias, "bias"), _chk(gy, "gy"), _chk(gu, "gu"),
+                                _chk(dx, "dx"), _chk(dw, "dw"), _chk(db, "db"), b, i, o, 1 if act else 0,
+                                stream_ptr()), "linear_bwd")
+    return dx, dw, db
