@@ -1,0 +1,88 @@
+"""world_size-2 gloo tests (CPU) of the multi-process path: batch sharding, gradient all-reduce with the
+reference's SUM semantics, bucket layout with gradient-free parameters, result gathering."""
+import os
+import socket
+
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+
+def _free_port():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def _worker(rank, world, port, q):
+    os.environ.update({"MASTER_ADDR": "127.0.0.1", "MASTER_PORT": str(port), "RANK": str(rank),
+                       "WORLD_SIZE": str(world)})
+    from tmdiff_amd import dist as D
+    assert D.init_from_env("gloo") == world
+    torch.manual_seed(0)
+    net = torch.nn.Sequential(torch.nn.Linear(6, 5), torch.nn.Linear(5, 3), torch.nn.Linear(3, 2))
+    for p in net[2].parameters():            # a gradient-free tail, like the 56 unused WavBEST tensors
+        p.requires_grad_(True)
+    data = {"x": torch.arange(8 * 6, dtype=torch.float32).reshape(8, 6) / 10, "tag": "keep"}
+    shard = D.shard_batch(data)
+    assert shard["tag"] == "keep" and shard["x"].shape[0] == 4
+    loss = net[1](net[0](shard["x"])).abs().mean()        # net[2] unused -> grad None
+    loss.backward()
+    local = [p.grad.clone() if p.grad is not None else None for p in net.parameters()]
+    nb = D.allreduce_gradients(net, op="sum", bucket_bytes=64)      # tiny buckets: several all-reduces
+    summed = [p.grad.clone() if p.grad is not None else None for p in net.parameters()]
+    for p, l in zip(net.parameters(), local):
+        if l is not None:
+            p.grad.copy_(l)
+    D.allreduce_gradients(net, op="mean")
+    mean = [p.grad.clone() if p.grad is not None else None for p in net.parameters()]
+    gathered = D.gather_images(shard["x"] * (rank + 1))
+    npy = lambda ts: [None if t is None else t.numpy().copy() for t in ts]      # by value: no shared-memory handles
+    q.put((rank, nb, npy(local), npy(summed), npy(mean), gathered.numpy().copy()))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_allreduce_and_sharding_world2():
+    world, port = 2, _free_port()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = sorted((q.get(timeout=120) for _ in range(world)), key=lambda t: t[0])
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    ten = lambda ts: [None if t is None else torch.from_numpy(t) for t in ts]
+    res = [(r, nb, ten(a), ten(b), ten(c), torch.from_numpy(g)) for r, nb, a, b, c, g in res]
+    (_, nb0, loc0, sum0, mean0, gat0), (_, nb1, loc1, sum1, mean1, gat1) = res
+    assert nb0 == nb1 and nb0 > 1
+    for a, b, s0, s1, m0 in zip(loc0, loc1, sum0, sum1, mean0):
+        if a is None:
+            assert b is None and s0 is None and s1 is None          # untouched on every rank
+            continue
+        assert torch.allclose(s0, a + b) and torch.equal(s0, s1)      # SUM, identical on both ranks
+        assert torch.allclose(m0, (a + b) / 2)
+    assert torch.equal(gat0, gat1) and gat0.shape[0] == 8
+    x = torch.arange(8 * 6, dtype=torch.float32).reshape(8, 6) / 10
+    assert torch.allclose(gat0, torch.cat([x[:4] * 1, x[4:] * 2]))
+    # the all-reduced SUM equals the gradient of the sum of the two replica mean-losses (reference DataParallel)
+    torch.manual_seed(0)
+    net = torch.nn.Sequential(torch.nn.Linear(6, 5), torch.nn.Linear(5, 3), torch.nn.Linear(3, 2))
+    total = net[1](net[0](x[:4])).abs().mean() + net[1](net[0](x[4:])).abs().mean()
+    total.backward()
+    for p, s in zip(net.parameters(), sum0):
+        if s is not None:
+            assert torch.allclose(p.grad, s, atol=1e-6)
+
+
+def test_single_process_is_a_noop():
+    from tmdiff_amd import dist as D
+    net = torch.nn.Linear(3, 2)
+    net(torch.ones(1, 3)).sum().backward()
+    g = net.weight.grad.clone()
+    assert D.allreduce_gradients(net) == 0 and torch.equal(net.weight.grad, g)
+    t = torch.ones(2, 3)
+    assert D.gather_images(t) is t
+    assert D.shard_batch({"x": torch.arange(6.0).reshape(6, 1)}, rank=1, world=3)["x"].flatten().tolist() == [2.0, 3.0]
