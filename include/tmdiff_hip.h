@@ -197,6 +197,29 @@ int tmdiff_add(const float* a, const float* b, float* out, int64_t n, float sign
 int tmdiff_q_sample(const float* x0, const float* noise, const float* a, float* out, int32_t B, int64_t n_per_sample,
                     tmdiff_stream_t stream);
 
+/* ------------------------------------------------------------------------------------
+ * Standalone attention operators of core/Attention.py (imported by nothing in the reference; built because the
+ * north star names them).  All fp32.
+ *  attn_fwd : out = softmax(q k^T * scale [key mask]) v per (batch, head); fp32 MFMA, online softmax.
+ *             q/k/v/out are addressed as base + b*strides[0] + head*strides[1] + row*strides[2] + d (elements),
+ *             which covers both the '(b h) n d' split of CrossAttention (:186) and the channel-major
+ *             [B, C, HW] tensors of SpatialSelfAttention (:143-153, via a transposed view prepared by the caller).
+ *             key_mask [B, Nk] bytes (1 = keep) or NULL; head dim D even, <= 128.
+ *  gemm_nt  : C[M,N] = A[M,K] W[N,K]^T + bias[N] + residual[M,N]   (nn.Linear on token-major activations)
+ *  group_norm (:108-109, eps 1e-6, affine), layer_norm (:279-281), geglu / gelu (:69-76, :84-87).
+ * ------------------------------------------------------------------------------------ */
+int tmdiff_attn_fwd(const float* q, const float* k, const float* v, float* out, const unsigned char* key_mask,
+                    int32_t B, int32_t H, int32_t Nq, int32_t Nk, int32_t D, const int64_t q_strides[3],
+                    const int64_t k_strides[3], const int64_t v_strides[3], const int64_t o_strides[3], float scale,
+                    tmdiff_stream_t stream);
+int tmdiff_gemm_nt(const float* A, const float* Wt, const float* bias, const float* residual, float* C, int64_t M,
+                   int32_t N, int32_t K, tmdiff_stream_t stream);
+int tmdiff_group_norm(const float* x, const float* gamma, const float* beta, float* y, int32_t B, int32_t C,
+                      int64_t P, int32_t groups, float eps, tmdiff_stream_t stream);
+int tmdiff_layer_norm(const float* x, const float* gamma, const float* beta, float* y, int64_t rows, int32_t D,
+                      float eps, tmdiff_stream_t stream);
+int tmdiff_geglu(const float* u, float* y, int64_t rows, int32_t inner, int32_t gelu_only, tmdiff_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -57,6 +57,12 @@ SIGNATURES = {
     "tmdiff_abs_quantile_workspace_bytes": (C.c_size_t, [C.c_int32, C.c_int64]),
     "tmdiff_abs_quantile_clamp": (C.c_int, [vp, C.c_int32, C.c_int64, C.c_float, C.c_float, vp, vp]),
     "tmdiff_add": (C.c_int, [vp, vp, vp, C.c_int64, C.c_float, vp]),
+    "tmdiff_attn_fwd": (C.c_int, [vp, vp, vp, vp, vp, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32,
+                                  C.c_int64 * 3, C.c_int64 * 3, C.c_int64 * 3, C.c_int64 * 3, C.c_float, vp]),
+    "tmdiff_gemm_nt": (C.c_int, [vp, vp, vp, vp, vp, C.c_int64, C.c_int32, C.c_int32, vp]),
+    "tmdiff_group_norm": (C.c_int, [vp, vp, vp, vp, C.c_int32, C.c_int32, C.c_int64, C.c_int32, C.c_float, vp]),
+    "tmdiff_layer_norm": (C.c_int, [vp, vp, vp, vp, C.c_int64, C.c_int32, C.c_float, vp]),
+    "tmdiff_geglu": (C.c_int, [vp, vp, C.c_int64, C.c_int32, C.c_int32, vp]),
     "tmdiff_q_sample": (C.c_int, [vp, vp, vp, vp, C.c_int32, C.c_int64, vp]),
 }
 

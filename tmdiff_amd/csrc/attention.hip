@@ -1,0 +1,302 @@
+// Standalone attention operators of core/Attention.py on gfx950.  These modules are
+// imported by nothing in the reference; they are built as operators because the north star names them.
+//   attn_fwd_kernel : softmax(Q K^T * scale [+ key mask]) V, fp32 MFMA (v_mfma_f32_32x32x2_f32), online softmax
+//                     (SpatialSelfAttention :145-157, CrossAttention :186-213)
+//   gemm_nt_kernel  : C[M,N] = A[M,K] W[N,K]^T + bias (+ residual), fp32 MFMA -- the token-major Linear layers
+//                     (to_q/k/v/out, FeedForward, proj_in/out with use_linear) :172-181, :69-96
+//   group_norm, layer_norm, geglu : wave-shuffle reductions / elementwise (:108-109, :279-281, :69-76)
+// 1x1 Conv2d projections on [B,C,H,W] reuse tmdiff_conv3d_fwd with ksize 1 (N = 1).
+//
+// Attention layout trick: the score tile is computed TRANSPOSED, S^T[key, query] = K Q^T, so a lane owns one
+// query column: its 16 accumulator registers are 16 keys of that query.  Row statistics (max, sum) are then
+// in-lane reductions plus one exchange between the two half-waves, the rescale of the output accumulator
+// O^T[d, query] is a per-lane multiply, and P^T feeds the second product O^T += V^T P^T directly from the
+// accumulator registers: register r of half-wave h is key (r&3)+8(r>>2)+4h, exactly the K-pair of MFMA step r.
+#include "common.h"
+
+namespace {
+
+using f32x16 = __attribute__((ext_vector_type(16))) float;
+
+// ---------------------------------------------------------------------------------------------------------
+// attention.  q [BH, Nq, D], k [BH, Nk, D], v [BH, Nk, D] with arbitrary row / head strides (elements).
+// One workgroup = 4 waves = 128 queries of one (batch, head); K/V tiles of 32 keys are staged in LDS once per
+// workgroup; D <= 256, D % 2 == 0.
+// ---------------------------------------------------------------------------------------------------------
+struct AttnArgs {
+  const float* q; const float* k; const float* v; float* o;
+  const unsigned char* mask;  // [B, Nk] key mask (1 = keep) or NULL
+  long q_bs, q_hs, q_rs;      // batch / head / row strides of q (elements); same for k, v, o
+  long k_bs, k_hs, k_rs, v_bs, v_hs, v_rs, o_bs, o_hs, o_rs;
+  int H, Nq, Nk, D;
+  float scale;
+};
+
+template <int DT>  // DT = ceil(D / 32): 32-row tiles of the transposed output accumulator
+__global__ void __launch_bounds__(256) attn_fwd_kernel(const AttnArgs a) {
+  constexpr int DP = DT * 32;       // padded head dim
+  constexpr int KS = DP + 1;        // odd LDS row stride: lanes read one row each without bank conflicts
+  __shared__ float qs[128 * KS];    // this workgroup's queries   [128][DP]
+  __shared__ float ks[32 * KS];     // current key tile            [32][DP]
+  __shared__ float vs[32 * KS];     // current value tile          [32][DP]
+  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, l31 = lane & 31, h = lane >> 5;
+  const int bh = blockIdx.y, b = bh / a.H, hd = bh % a.H;
+  const int q0 = blockIdx.x * 128;
+  const float* qb = a.q + b * a.q_bs + hd * a.q_hs;
+  const float* kb = a.k + b * a.k_bs + hd * a.k_hs;
+  const float* vb = a.v + b * a.v_bs + hd * a.v_hs;
+
+  for (int e = tid; e < 128 * DP; e += 256) {
+    const int r = e / DP, c = e % DP;
+    qs[r * KS + c] = (q0 + r < a.Nq && c < a.D) ? qb[(long)(q0 + r) * a.q_rs + c] * a.scale : 0.f;
+  }
+  f32x16 oacc[DT];
+#pragma unroll
+  for (int t = 0; t < DT; ++t)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) oacc[t][r] = 0.f;
+  float m_run = -3.0e38f, l_run = 0.f;  // running max / sum of this lane's query (both half-waves keep a copy)
+  const float* qrow = qs + (wv * 32 + l31) * KS;
+
+  for (int k0 = 0; k0 < a.Nk; k0 += 32) {
+    __syncthreads();
+    for (int e = tid; e < 32 * DP; e += 256) {
+      const int r = e / DP, c = e % DP;
+      const bool ok = k0 + r < a.Nk && c < a.D;
+      ks[r * KS + c] = ok ? kb[(long)(k0 + r) * a.k_rs + c] : 0.f;
+      vs[r * KS + c] = ok ? vb[(long)(k0 + r) * a.v_rs + c] : 0.f;
+    }
+    __syncthreads();
+    // S^T[key, query] = sum_d K[key, d] * (scale Q)[query, d]
+    f32x16 s;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) s[r] = 0.f;
+    const float* krow = ks + l31 * KS;
+    for (int d = 0; d < DP; d += 2) s = __builtin_amdgcn_mfma_f32_32x32x2f32(krow[d + h], qrow[d + h], s, 0, 0, 0);
+    // mask keys past Nk (and masked keys); register r of half h is key (r&3) + 8(r>>2) + 4h
+    float mx = -3.0e38f;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int key = k0 + (r & 3) + 8 * (r >> 2) + 4 * h;
+      bool keep = key < a.Nk;
+      if (keep && a.mask) keep = a.mask[(long)b * a.Nk + key] != 0;
+      s[r] = keep ? s[r] : -3.4028234e38f;   // masked_fill(-finfo.max), ref :203-204
+      mx = fmaxf(mx, s[r]);
+    }
+    mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+    const float m_new = fmaxf(m_run, mx);
+    const float alpha = __expf(m_run - m_new);
+    float psum = 0.f;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      s[r] = __expf(s[r] - m_new);
+      psum += s[r];
+    }
+    psum += __shfl_xor(psum, 32, 64);
+    l_run = l_run * alpha + psum;
+    m_run = m_new;
+    // O^T[d, query] = alpha * O^T + sum_key V[key, d] * P^T[key, query]; P^T comes straight from s[r]
+#pragma unroll
+    for (int t = 0; t < DT; ++t) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) oacc[t][r] *= alpha;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int key = (r & 3) + 8 * (r >> 2) + 4 * h;
+        oacc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(vs[key * KS + t * 32 + l31], s[r], oacc[t], 0, 0, 0);
+      }
+    }
+  }
+  // out[query, d] = O^T[d, query] / l; transpose through LDS (reuse the query buffer) for coalesced stores
+  __syncthreads();
+  const float inv = 1.f / l_run;
+  float* ot = qs + wv * 32 * KS;
+#pragma unroll
+  for (int t = 0; t < DT; ++t)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) ot[l31 * KS + t * 32 + (r & 3) + 8 * (r >> 2) + 4 * h] = oacc[t][r] * inv;
+  __syncthreads();
+  float* ob = a.o + b * a.o_bs + hd * a.o_hs;
+  for (int e = tid; e < 128 * DP; e += 256) {
+    const int r = e / DP, c = e % DP;
+    if (q0 + r < a.Nq && c < a.D) ob[(long)(q0 + r) * a.o_rs + c] = qs[r * KS + c];
+  }
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// C[M,N] = A[M,K] W[N,K]^T (+ bias[N]) (+ residual[M,N]); 64x64 tile per workgroup, each wave a 32x32 block.
+// MFMA rows = 32 rows of A (lane holds A[row][k]), cols = 32 output features (lane holds W[feature][k]).
+// ---------------------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256) gemm_nt_kernel(const float* __restrict__ A, const float* __restrict__ Wt,
+                                                      const float* __restrict__ bias, const float* __restrict__ res,
+                                                      float* __restrict__ Cm, int M, int N, int K) {
+  constexpr int BK = 32, LS = BK + 1;
+  __shared__ float as[64 * LS];
+  __shared__ float ws[64 * LS];
+  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, l31 = lane & 31, h = lane >> 5;
+  const int m0 = blockIdx.y * 64, n0 = blockIdx.x * 64;
+  const int wm = (wv >> 1) * 32, wn = (wv & 1) * 32;
+  f32x16 acc;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+  for (int k0 = 0; k0 < K; k0 += BK) {
+    __syncthreads();
+    for (int e = tid; e < 64 * BK; e += 256) {
+      const int r = e / BK, c = e % BK;
+      as[r * LS + c] = (m0 + r < M && k0 + c < K) ? A[(long)(m0 + r) * K + k0 + c] : 0.f;
+      ws[r * LS + c] = (n0 + r < N && k0 + c < K) ? Wt[(long)(n0 + r) * K + k0 + c] : 0.f;
+    }
+    __syncthreads();
+    const float* ar = as + (wm + l31) * LS;
+    const float* wr = ws + (wn + l31) * LS;
+#pragma unroll
+    for (int k = 0; k < BK; k += 2) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(ar[k + h], wr[k + h], acc, 0, 0, 0);
+  }
+  // D layout: col = l31 (feature), row = (r&3)+8(r>>2)+4h (row of A)
+  const int n = n0 + wn + l31;
+  if (n >= N) return;
+  const float bv = bias ? bias[n] : 0.f;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) {
+    const int m = m0 + wm + (r & 3) + 8 * (r >> 2) + 4 * h;
+    if (m < M) {
+      float t = acc[r] + bv;
+      if (res) t += res[(long)m * N + n];
+      Cm[(long)m * N + n] = t;
+    }
+  }
+}
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
+  return v;
+}
+
+__device__ __forceinline__ float block_sum(float v, float* red) {
+  v = wave_sum(v);
+  __syncthreads();
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = v;
+  __syncthreads();
+  return red[0] + red[1] + red[2] + red[3];
+}
+
+// GroupNorm over [B, C, P]: one workgroup per (b, group); two passes (mean, then centred variance).
+__global__ void __launch_bounds__(256) group_norm_kernel(const float* __restrict__ x, const float* __restrict__ gamma,
+                                                         const float* __restrict__ beta, float* __restrict__ y, int C,
+                                                         long P, int groups, float eps) {
+  __shared__ float red[4];
+  const int g = blockIdx.x, b = blockIdx.y, cpg = C / groups;
+  const long n = (long)cpg * P;
+  const float* xs = x + ((long)b * C + g * cpg) * P;
+  float* ys = y + ((long)b * C + g * cpg) * P;
+  float s = 0.f;
+  for (long i = threadIdx.x; i < n; i += 256) s += xs[i];
+  const float mean = block_sum(s, red) / (float)n;
+  float v = 0.f;
+  for (long i = threadIdx.x; i < n; i += 256) { const float d = xs[i] - mean; v += d * d; }
+  const float rstd = rsqrtf(block_sum(v, red) / (float)n + eps);
+  for (long i = threadIdx.x; i < n; i += 256) {
+    const int c = g * cpg + (int)(i / P);
+    ys[i] = (xs[i] - mean) * rstd * (gamma ? gamma[c] : 1.f) + (beta ? beta[c] : 0.f);
+  }
+}
+
+// LayerNorm over the last dim of [rows, D]: one wave per row.
+__global__ void __launch_bounds__(256) layer_norm_kernel(const float* __restrict__ x, const float* __restrict__ gamma,
+                                                         const float* __restrict__ beta, float* __restrict__ y,
+                                                         long rows, int D, float eps) {
+  const long row = blockIdx.x * 4L + (threadIdx.x >> 6);
+  const int lane = threadIdx.x & 63;
+  if (row >= rows) return;
+  const float* xs = x + row * D;
+  float s = 0.f;
+  for (int i = lane; i < D; i += 64) s += xs[i];
+  const float mean = wave_sum(s) / D;
+  float v = 0.f;
+  for (int i = lane; i < D; i += 64) { const float d = xs[i] - mean; v += d * d; }
+  const float rstd = rsqrtf(wave_sum(v) / D + eps);
+  for (int i = lane; i < D; i += 64) y[row * D + i] = (xs[i] - mean) * rstd * gamma[i] + beta[i];
+}
+
+// GEGLU: y[r, j] = u[r, j] * gelu(u[r, inner + j]) (exact erf GELU, F.gelu default), u = [rows, 2*inner]
+__global__ void __launch_bounds__(256) geglu_kernel(const float* __restrict__ u, float* __restrict__ y, long rows,
+                                                    int inner, int gate_only) {
+  const long i = blockIdx.x * 256L + threadIdx.x;
+  if (i >= rows * inner) return;
+  const long r = i / inner;
+  const int j = (int)(i % inner);
+  if (gate_only) {  // plain GELU on [rows, inner]
+    const float gte = u[i];
+    y[i] = 0.5f * gte * (1.f + erff(gte * 0.70710678118654752440f));
+    return;
+  }
+  const float a = u[r * 2 * inner + j], gte = u[r * 2 * inner + inner + j];
+  y[i] = a * (0.5f * gte * (1.f + erff(gte * 0.70710678118654752440f)));
+}
+
+}  // namespace
+
+extern "C" int tmdiff_attn_fwd(const float* q, const float* k, const float* v, float* out, const unsigned char* key_mask,
+                               int32_t B, int32_t H, int32_t Nq, int32_t Nk, int32_t D, const int64_t q_strides[3],
+                               const int64_t k_strides[3], const int64_t v_strides[3], const int64_t o_strides[3],
+                               float scale, tmdiff_stream_t stream) {
+  using namespace tmdiff;
+  TMDIFF_REQUIRE(q && k && v && out && q_strides && k_strides && v_strides && o_strides, "attn_fwd: NULL pointer");
+  TMDIFF_REQUIRE(B > 0 && H > 0 && Nq > 0 && Nk > 0 && (long)B * H <= 65535, "attn_fwd: bad extents");
+  TMDIFF_REQUIRE(D >= 2 && D <= 128 && D % 2 == 0, "attn_fwd: head dim %d (even, <= 128)", D);
+  AttnArgs a;
+  a.q = q; a.k = k; a.v = v; a.o = out; a.mask = key_mask;
+  a.q_bs = q_strides[0]; a.q_hs = q_strides[1]; a.q_rs = q_strides[2];
+  a.k_bs = k_strides[0]; a.k_hs = k_strides[1]; a.k_rs = k_strides[2];
+  a.v_bs = v_strides[0]; a.v_hs = v_strides[1]; a.v_rs = v_strides[2];
+  a.o_bs = o_strides[0]; a.o_hs = o_strides[1]; a.o_rs = o_strides[2];
+  a.H = H; a.Nq = Nq; a.Nk = Nk; a.D = D; a.scale = scale;
+  dim3 grid((Nq + 127) / 128, B * H);
+  hipStream_t st = as_stream(stream);
+  switch ((D + 31) / 32) {
+    case 1: attn_fwd_kernel<1><<<grid, 256, 0, st>>>(a); break;
+    case 2: attn_fwd_kernel<2><<<grid, 256, 0, st>>>(a); break;
+    case 3: attn_fwd_kernel<3><<<grid, 256, 0, st>>>(a); break;
+    default: attn_fwd_kernel<4><<<grid, 256, 0, st>>>(a); break;
+  }
+  return check_launch("attn_fwd");
+}
+
+extern "C" int tmdiff_gemm_nt(const float* A, const float* Wt, const float* bias, const float* residual, float* Cm,
+                              int64_t M, int32_t N, int32_t K, tmdiff_stream_t stream) {
+  using namespace tmdiff;
+  TMDIFF_REQUIRE(A && Wt && Cm && M >= 0 && N > 0 && K > 0 && M < (1L << 31), "gemm_nt: bad arguments");
+  if (M == 0) return TMDIFF_OK;
+  dim3 grid((N + 63) / 64, (unsigned)((M + 63) / 64));
+  gemm_nt_kernel<<<grid, 256, 0, as_stream(stream)>>>(A, Wt, bias, residual, Cm, (int)M, N, K);
+  return check_launch("gemm_nt");
+}
+
+extern "C" int tmdiff_group_norm(const float* x, const float* gamma, const float* beta, float* y, int32_t B, int32_t C,
+                                 int64_t P, int32_t groups, float eps, tmdiff_stream_t stream) {
+  using namespace tmdiff;
+  TMDIFF_REQUIRE(x && y && B > 0 && B <= 65535 && C > 0 && P > 0 && groups > 0 && C % groups == 0,
+                 "group_norm: bad arguments (C=%d groups=%d)", C, groups);
+  group_norm_kernel<<<dim3(groups, B), 256, 0, as_stream(stream)>>>(x, gamma, beta, y, C, P, groups, eps);
+  return check_launch("group_norm");
+}
+
+extern "C" int tmdiff_layer_norm(const float* x, const float* gamma, const float* beta, float* y, int64_t rows,
+                                 int32_t D, float eps, tmdiff_stream_t stream) {
+  using namespace tmdiff;
+  TMDIFF_REQUIRE(x && gamma && beta && y && rows >= 0 && D > 0, "layer_norm: bad arguments");
+  if (rows == 0) return TMDIFF_OK;
+  layer_norm_kernel<<<(unsigned)((rows + 3) / 4), 256, 0, as_stream(stream)>>>(x, gamma, beta, y, rows, D, eps);
+  return check_launch("layer_norm");
+}
+
+extern "C" int tmdiff_geglu(const float* u, float* y, int64_t rows, int32_t inner, int32_t gelu_only,
+                            tmdiff_stream_t stream) {
+  using namespace tmdiff;
+  TMDIFF_REQUIRE(u && y && rows >= 0 && inner > 0, "geglu: bad arguments");
+  if (rows == 0) return TMDIFF_OK;
+  const long n = rows * inner;
+  geglu_kernel<<<(unsigned)((n + 255) / 256), 256, 0, as_stream(stream)>>>(u, y, rows, inner, gelu_only);
+  return check_launch("geglu");
+}

@@ -278,3 +278,57 @@ def linear_bwd(x, w, bias, gy, act=False, need_dx=True, need_dw=True, need_db=Tr
                                 _chk(dx, "dx"), _chk(dw, "dw"), _chk(db, "db"), b, i, o, 1 if act else 0,
                                 stream_ptr()), "linear_bwd")
     return dx, dw, db
+
+
+# ---- standalone attention operators (core/Attention.py) ----------------------------------------------------
+def attention(q, k, v, scale, heads=1, key_mask=None, layout="bnd"):
+    """softmax(q k^T * scale) v.  layout 'bnd': q [B, Nq, H*D], k/v [B, Nk, H*D] (heads split along the last
+    dim, as CrossAttention's 'b n (h d)'); returns [B, Nq, H*D]."""
+    assert layout == "bnd"
+    b, nq, hd = q.shape
+    nk = k.shape[1]
+    d = hd // heads
+    out = torch.empty_like(q)
+    st = lambda n: (C.c_int64 * 3)(n * hd, d, hd)          # batch, head, row strides in elements
+    m = None
+    if key_mask is not None:
+        m = key_mask.to(device=q.device, dtype=torch.uint8).contiguous()
+    check(lib.tmdiff_attn_fwd(_chk(q, "q"), _chk(k, "k"), _chk(v, "v"), out.data_ptr(),
+                              m.data_ptr() if m is not None else None, b, heads, nq, nk, d, st(nq), st(nk), st(nk),
+                              st(nq), scale, stream_ptr()), "attn_fwd")
+    return out
+
+
+def gemm_nt(a, w, bias=None, residual=None):
+    """a [..., K] @ w[N, K]^T + bias + residual -> [..., N]"""
+    k = a.shape[-1]
+    m = a.numel() // k
+    n = w.shape[0]
+    out = torch.empty(*a.shape[:-1], n, device=a.device, dtype=torch.float32)
+    check(lib.tmdiff_gemm_nt(_chk(a, "a"), _chk(w, "w"), _chk(bias, "bias"), _chk(residual, "residual"),
+                             out.data_ptr(), m, n, k, stream_ptr()), "gemm_nt")
+    return out
+
+
+def group_norm(x, gamma, beta, groups=32, eps=1e-6):
+    b, c = x.shape[:2]
+    y = torch.empty_like(x)
+    check(lib.tmdiff_group_norm(_chk(x, "x"), _chk(gamma, "gamma"), _chk(beta, "beta"), y.data_ptr(), b, c,
+                                x.numel() // (b * c), groups, eps, stream_ptr()), "group_norm")
+    return y
+
+
+def layer_norm(x, gamma, beta, eps=1e-5):
+    d = x.shape[-1]
+    y = torch.empty_like(x)
+    check(lib.tmdiff_layer_norm(_chk(x, "x"), _chk(gamma, "gamma"), _chk(beta, "beta"), y.data_ptr(),
+                                x.numel() // d, d, eps, stream_ptr()), "layer_norm")
+    return y
+
+
+def geglu(u, gelu_only=False):
+    inner = u.shape[-1] if gelu_only else u.shape[-1] // 2
+    y = torch.empty(*u.shape[:-1], inner, device=u.device, dtype=torch.float32)
+    check(lib.tmdiff_geglu(_chk(u, "u"), y.data_ptr(), u.numel() // u.shape[-1], inner, 1 if gelu_only else 0,
+                           stream_ptr()), "geglu")
+    return y
