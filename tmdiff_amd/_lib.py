@@ -7,7 +7,7 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libtmdiff_hip.so")
+LIB_PATH = os.environ.get("TMDIFF_HIP_LIB") or os.path.join(_HERE, "libtmdiff_hip.so")   # override: diagnostic builds
 
 c_float_p = C.POINTER(C.c_float)
 vp = C.c_void_p

@@ -201,13 +201,14 @@ __global__ void __launch_bounds__(256, 2) conv3d_mfma_kernel(const ConvArgs a) {
   auto load_item = [&](auto qc, int cn) __attribute__((always_inline)) {
     constexpr int q = decltype(qc)::value;
     if constexpr (q == 0) {
+      // (the loaded value is NOT touched here -- no select on it -- or the wave would sit in vmcnt(0) for the full
+      //  memory latency in the middle of the MFMA stream; absent shift / scale are substituted at the point of use)
       const bool is_shift = lane < KC;
       const float* sp = is_shift ? a.in_shift : a.in_scale;
       const long row = (long)b * (is_shift ? a.shift_stride : a.scale_stride);
       const int cl = min(cn + (lane % KC), a.cin_g - 1);
-      const float* sp2 = sp ? sp + row + g * a.cin_g + cl : a.wp;  // always a valid address
-      const float raw = *sp2;
-      ssv = (sp && lane < 2 * KC) ? raw : (is_shift ? 0.f : 1.f);
+      const float* sp2 = (sp && lane < 2 * KC) ? sp + row + g * a.cin_g + cl : a.wp;  // always a valid address
+      ssv = *sp2;
     } else if constexpr (q <= KC) {
       constexpr int ci = q - 1;
       const int cl = cn + ci;  // channel within group
@@ -255,8 +256,8 @@ __global__ void __launch_bounds__(256, 2) conv3d_mfma_kernel(const ConvArgs a) {
       constexpr int ci = (pc / 2) / G::EPT, i = (pc / 2) % G::EPT;
       const int e = tid + 256 * i;
       if constexpr (pc % 2 == 0) {  // prologue math, in place in the prefetch register
-        const float sh = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(ssv), ci));
-        const float sc = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(ssv), KC + ci));
+        const float sh = a.in_shift ? __int_as_float(__builtin_amdgcn_readlane(__float_as_int(ssv), ci)) : 0.f;
+        const float sc = a.in_scale ? __int_as_float(__builtin_amdgcn_readlane(__float_as_int(ssv), KC + ci)) : 1.f;
         float t = xr[ci][i] + sh;
         const float ta = tmdiff::silu_f(t);
         t = (a.in_act ? ta : t) * sc;
