@@ -174,3 +174,42 @@ def test_training_step_with_dropout_runs_and_descends():
         losses.append(float(loss))
     assert all(np.isfinite(losses))
     assert min(losses[4:]) < losses[0]
+
+
+def test_trainer_wrapper_roundtrip(tmp_path):
+    """DDPM wrapper (reference model.py API): train steps, EMA, save -> load into a fresh wrapper, test()."""
+    import copy
+    from tmdiff_amd.model import DDPM, EmaUpdater, create_model
+    opt = {"phase": "train", "gpu_ids": [0], "distributed": False,
+           "path": {"resume": None, "checkpoint": str(tmp_path)},
+           "model": {"unet": {"channel_multiplier": TINY}, "diffusion": {"loss_type": "l1"}, "init_type": "orthogonal"},
+           "train": {"optimizer": {"lr": 1e-3}, "max_iter": 100}}
+    torch.manual_seed(1)
+    m = create_model(opt)
+    ema = EmaUpdater(m, copy.deepcopy(m), decay=0.9)
+    m.set_new_noise_schedule({"schedule": "cosine", "n_timestep": 10}, "train")
+    d = case_inputs(3, 2, 8, 16)
+    d["LR"] = d["MS"].clone()
+    for it in range(3):
+        m.feed_data({k: v.clone() for k, v in d.items()})
+        m.optimize_parameters("WV3")
+        ema.update(it)
+    assert np.isfinite(float(m.get_current_log()["l_pix"])) and m.get_current_log()["lr"] > 0
+    p, pe = next(m.netG.denoise_fn.parameters()), next(ema.ema_model.netG.denoise_fn.parameters())
+    assert not torch.equal(p, pe)
+    m.save_network(3)
+    opt2 = dict(opt, path={"resume": str(tmp_path / "I3"), "checkpoint": str(tmp_path)})
+    m2 = DDPM(opt2)
+    assert m2.begin_step == 3
+    sd2 = m2.netG.state_dict()           # (no schedule buffers yet: they are not module state until a schedule is set)
+    n_cmp = 0
+    for k, a in m.netG.state_dict().items():
+        if k.startswith("denoise_fn."):
+            assert torch.equal(a.cpu(), sd2[k].cpu()), k
+            n_cmp += 1
+    assert n_cmp == 272
+    m2.set_new_noise_schedule({"schedule": "cosine", "n_timestep": 10}, "val")
+    m2.feed_data({k: v.clone() for k, v in d.items()})
+    m2.test(continous=False, prompt="WV3")
+    vis = m2.get_current_visuals()
+    assert vis["SR"].shape[1:] == (8, 16, 16) and torch.isfinite(vis["SR"]).all()
