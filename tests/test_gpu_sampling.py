@@ -190,3 +190,24 @@ def test_full_size_properties():
     want = c1 * (a * x - b * eps).clamp(-1, 1) + c2 * x
     got = diff.p_sample(x, 0, condition_x=d, prompt="WV3")
     assert (got - want).abs().max() <= 1e-5
+
+
+def test_tiled_scene_sampling(pair):
+    """BASELINE config 5 shape in miniature: a 4-band 64x64 scene cut into 16 tiles, sampled in batches."""
+    from tmdiff_amd.tiling import sample_tiled, split_tiles
+    ref_net, hip_net, GD = pair
+    diff = GD(hip_net, "l1", noise_fn=cpu_noise).cuda()
+    diff.set_new_noise_schedule({"schedule": "cosine", "n_timestep": 1000}, "cuda")
+    d = case_inputs(9, 1, 4, 64)
+    scene = {"MS": cu(d["MS"]), "PAN": cu(d["PAN"])}
+    torch.manual_seed(4)
+    fused = sample_tiled(diff, scene, "GF2", tile=16, method="dpmsolver", steps=6, max_batch=8)
+    assert fused.shape == (1, 4, 64, 64) and torch.isfinite(fused).all()
+    # tile 5 (row 1, col 1) alone, with the noise it saw in the batched run, gives the same pixels
+    torch.manual_seed(4)
+    first = torch.randn(8, 4, 16, 16)                      # batch 0 of 8 tiles
+    tiles = {"MS": split_tiles(scene["MS"], 16, 16)[5:6], "PAN": split_tiles(scene["PAN"], 16, 16)[5:6]}
+    tiles["Res"] = torch.zeros_like(tiles["MS"])
+    diff.noise_fn = lambda like: first[5:6]
+    alone = diff.sample_by_dpmsolver(tiles, "GF2", steps=6)
+    assert (alone[0] - fused[0, :, 16:32, 16:32]).abs().max() <= 1e-4

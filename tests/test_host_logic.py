@@ -133,3 +133,40 @@ def test_psnr_and_res2img():
     assert abs(psnr(a, b) - 40.0) < 1e-3          # fp32 (a+0.01)-a is 0.01 only to ~1e-6
     assert psnr(a, a) > 200
     assert torch.equal(img2res(res2img(a, b), b), (a + b) - b)
+
+
+def test_metrics_against_direct_formulas():
+    from tmdiff_amd import metrics as M
+    g = torch.Generator().manual_seed(0)
+    a = torch.rand(24, 20, 4, generator=g)
+    b = (a + 0.05 * torch.randn(24, 20, 4, generator=g)).clamp(0, 1)
+    want = np.mean([10 * np.log10(1.0 / float(((a[..., c] - b[..., c]) ** 2).mean())) for c in range(4)])
+    assert abs(M.mpsnr(a, b) - want) < 1e-6
+    ang = torch.arccos((a * b).sum(-1) / a.norm(dim=-1) / b.norm(dim=-1)).double()
+    assert abs(M.sam(a, b) - float(ang.mean() * 180 / np.pi)) < 1e-5
+    assert M.sam(a, a) < 0.05 and abs(M.ssim(a, a) - 1.0) < 1e-9
+    # SSIM: direct sliding-window evaluation of the skimage definition for one band
+    x, y = a[..., 0].double().numpy(), b[..., 0].double().numpy()
+    vals = []
+    for i in range(x.shape[0] - 6):
+        for j in range(x.shape[1] - 6):
+            p, q = x[i:i + 7, j:j + 7].ravel(), y[i:i + 7, j:j + 7].ravel()
+            ux, uy = p.mean(), q.mean()
+            vx, vy, vxy = p.var(ddof=1), q.var(ddof=1), np.cov(p, q, ddof=1)[0, 1]
+            vals.append((2 * ux * uy + 1e-4) * (2 * vxy + 9e-4) / ((ux * ux + uy * uy + 1e-4) * (vx + vy + 9e-4)))
+    assert abs(M.ssim(a[..., :1], b[..., :1]) - np.mean(vals)) < 1e-9
+    assert abs(M.mpsnr(a.permute(2, 0, 1), b.permute(2, 0, 1), hwc=False) - want) < 1e-6
+
+
+def test_tiling_helpers_roundtrip():
+    from tmdiff_amd import tiling as T
+    x = torch.arange(2 * 3 * 8 * 12, dtype=torch.float32).reshape(2, 3, 8, 12)
+    t = T.split_tiles(x, 4, 6)
+    assert t.shape == (8, 3, 4, 6)
+    assert torch.equal(t[1], x[0, :, 0:4, 6:12]) and torch.equal(t[6], x[1, :, 4:8, 0:6])     # row-major tile order
+    assert torch.equal(T.merge_tiles(t, 2, 2), x)
+    img = torch.rand(1, 4, 16, 16)
+    q = T.invPatch(img)
+    assert q.shape == (4, 4, 8, 8) and torch.equal(q[3], img[0, :, 8:, 8:])                   # reference order
+    cube = torch.rand(5, 32, 32)
+    assert torch.equal(T.patch_16(T.unpatch_16(cube)), cube) and T.unpatch_16(cube).shape == (16, 5, 8, 8)
