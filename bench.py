@@ -96,12 +96,17 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
     dist = None
+    ndev = torch.cuda.device_count()
+    local_dev = local % max(ndev, 1)      # (rehearsals on a 1-GPU box map every rank to device 0)
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local))
-    torch.cuda.set_device(local)
-    dev = torch.device("cuda", local)
+        # nccl == RCCL over xGMI; TMDIFF_BENCH_BACKEND=gloo lets the multi-rank path be rehearsed on one GPU
+        backend = os.environ.get("TMDIFF_BENCH_BACKEND", "nccl")
+        kw = {"device_id": torch.device("cuda", local_dev)} if backend == "nccl" else {}
+        dist.init_process_group(backend, **kw)
+    torch.cuda.set_device(local_dev)
+    dev = torch.device("cuda", local_dev)
 
     from tmdiff_amd import ops
     from tmdiff_amd.Hyper_unet_general import WavBEST
