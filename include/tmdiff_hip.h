@@ -220,6 +220,43 @@ int tmdiff_layer_norm(const float* x, const float* gamma, const float* beta, flo
                       float eps, tmdiff_stream_t stream);
 int tmdiff_geglu(const float* u, float* y, int64_t rows, int32_t inner, int32_t gelu_only, tmdiff_stream_t stream);
 
+/* ------------------------------------------------------------------------------------
+ * Per-operator names (SURVEY 8b "minimum exports").  Thin, argument-checked fronts of the entry points above for
+ * callers that bind one symbol per ATen call they replace:
+ *  conv3d_k{3,1}_fwd   = tmdiff_conv3d_fwd with d->ksize required to be 3 / 1            (F.conv3d / nn.Conv3d)
+ *  conv3d_k{3,1}_dgrad = the same kernel on mode-1 packed weights: d->seg_x[0] = dL/dy, d->y = dL/dx'
+ *  conv3d_k{3,1}_wgrad = tmdiff_conv3d_wgrad
+ *  haar_dwt2d_fwd / haar_idwt2d_fwd = the transforms; *_bwd = their adjoints
+ *    dwt2d_bwd : dx = IDWT(ll_scale*g_ll, hi_scale*(g_lh, g_hl, g_hh))  (DWTFunction_2D.backward, DWT_IDWT_Functions.py:60-69);
+ *                the three high-band gradients must be all NULL (LL-only forward) or all given, and then
+ *                hi_scale must be 1 (the hot path only ever scales the LL band, Hyper_unet_general.py:396).
+ *    idwt2d_bwd: g_ll = in_scale * LL(g_out), (g_lh, g_hl, g_hh) = high bands of DWT(g_out)               (IDWTFunction_2D.backward, :101-112)
+ *  dpm_axpby{2,3,4}: out = sum_k coef_k * in_k with exactly 2 / 3 / 4 terms (dpm_solver_pytorch.py:563-927).
+ * ------------------------------------------------------------------------------------ */
+int tmdiff_conv3d_k3_fwd(const tmdiff_conv3d_desc* d, tmdiff_stream_t stream);
+int tmdiff_conv3d_k3_dgrad(const tmdiff_conv3d_desc* d, tmdiff_stream_t stream);
+int tmdiff_conv3d_k3_wgrad(const tmdiff_conv3d_desc* d, const float* g, float* dw, void* workspace,
+                           tmdiff_stream_t stream);
+int tmdiff_conv3d_k1_fwd(const tmdiff_conv3d_desc* d, tmdiff_stream_t stream);
+int tmdiff_conv3d_k1_dgrad(const tmdiff_conv3d_desc* d, tmdiff_stream_t stream);
+int tmdiff_conv3d_k1_wgrad(const tmdiff_conv3d_desc* d, const float* g, float* dw, void* workspace,
+                           tmdiff_stream_t stream);
+int tmdiff_haar_dwt2d_fwd(const float* x, float* ll, float* lh, float* hl, float* hh, int64_t planes, int32_t H,
+                          int32_t W, float ll_scale, float hi_scale, tmdiff_stream_t stream);
+int tmdiff_haar_dwt2d_bwd(const float* g_ll, const float* g_lh, const float* g_hl, const float* g_hh, float* dx,
+                          int64_t planes, int32_t H, int32_t W, float ll_scale, float hi_scale,
+                          tmdiff_stream_t stream);
+int tmdiff_haar_idwt2d_fwd(const float* ll, const float* lh, const float* hl, const float* hh, float* out,
+                           int64_t planes, int32_t h, int32_t w, float in_scale, tmdiff_stream_t stream);
+int tmdiff_haar_idwt2d_bwd(const float* g_out, float* g_ll, float* g_lh, float* g_hl, float* g_hh, int64_t planes,
+                           int32_t h, int32_t w, float in_scale, tmdiff_stream_t stream);
+int tmdiff_dpm_axpby2(const float* x0, float c0, const float* x1, float c1, float* out, int64_t n,
+                      tmdiff_stream_t stream);
+int tmdiff_dpm_axpby3(const float* x0, float c0, const float* x1, float c1, const float* x2, float c2, float* out,
+                      int64_t n, tmdiff_stream_t stream);
+int tmdiff_dpm_axpby4(const float* x0, float c0, const float* x1, float c1, const float* x2, float c2,
+                      const float* x3, float c3, float* out, int64_t n, tmdiff_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

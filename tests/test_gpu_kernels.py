@@ -286,3 +286,62 @@ def test_unet_full_width_vs_reference_fixture(golden):
     for i in range(4):
         assert torch.equal(y4[i], y4[0])
     assert_close(y4[:1], y, 1e-6, 1e-6, "batch-4 vs batch-1")
+
+
+def test_per_operator_abi_names(ops):
+    """The one-symbol-per-operator fronts (include/tmdiff_hip.h) agree with the general entry points."""
+    import ctypes as C
+    from tmdiff_amd import _lib
+    L, S = _lib.lib, None
+    p = lambda t: C.c_void_p(t.data_ptr()) if t is not None else None
+    torch.manual_seed(5)
+    # conv k3 / k1 fronts: same result as conv3d_fwd; ksize mismatch is TMDIFF_E_INVALID
+    x, w3, w1 = cu(torch.randn(2, 8, 4, 8, 8)), cu(torch.randn(16, 8, 3, 3, 3)), cu(torch.randn(16, 8, 1, 1, 1))
+    for w, k, fn, bad in ((w3, 3, L.tmdiff_conv3d_k3_fwd, L.tmdiff_conv3d_k1_fwd), (w1, 1, L.tmdiff_conv3d_k1_fwd, L.tmdiff_conv3d_k3_dgrad)):
+        wp = ops.pack_conv_weight(w)
+        y0, y1 = ops.conv3d([x], wp, 16, k), torch.empty(2, 16, 4, 8, 8, device="cuda")
+        d = ops.make_conv_desc([x], wp, 16, k, y1)
+        assert fn(C.byref(d), S) == 0
+        assert torch.equal(y0, y1)
+        assert bad(C.byref(d), S) == -1 and b"ksize" in L.tmdiff_last_error_string()
+    # wgrad front
+    g = cu(torch.randn(2, 16, 4, 8, 8))
+    y = torch.empty(2, 16, 4, 8, 8, device="cuda")
+    d = ops.make_conv_desc([x], ops.pack_conv_weight(w3), 16, 3, y)
+    ws = torch.empty(max(1, L.tmdiff_conv3d_wgrad_workspace_bytes(C.byref(d))), dtype=torch.uint8, device="cuda")
+    dw = torch.empty_like(w3)
+    assert L.tmdiff_conv3d_k3_wgrad(C.byref(d), p(g), p(dw), p(ws), S) == 0
+    wd = w3.cpu().double().requires_grad_()
+    F.conv3d(x.cpu().double(), wd, padding=1).backward(g.cpu().double())
+    assert_close(dw.cpu(), wd.grad.float(), 2e-5, 2e-5, "k3_wgrad")
+    # haar fronts and their adjoints: <DWT(x), g> == <x, DWT_bwd(g)>, likewise for IDWT
+    xs = cu(torch.randn(6, 8, 12))
+    bands = [torch.empty(6, 4, 6, device="cuda") for _ in range(4)]
+    assert L.tmdiff_haar_dwt2d_fwd(p(xs), *[p(b) for b in bands], 6, 8, 12, 0.5, 1.0, S) == 0
+    ref_b = haar_dwt2d(xs.cpu())
+    for b, r, s in zip(bands, ref_b, (0.5, 1, 1, 1)):
+        assert_close(b.cpu(), r * s, 1e-6, 1e-6, "dwt2d_fwd")
+    gb = [cu(torch.randn(6, 4, 6)) for _ in range(4)]
+    dx = torch.empty_like(xs)
+    assert L.tmdiff_haar_dwt2d_bwd(*[p(b) for b in gb], p(dx), 6, 8, 12, 0.5, 1.0, S) == 0
+    lhs = sum((b.double() * g_.double()).sum() for b, g_ in zip(bands, gb))
+    assert abs(lhs - (xs.double() * dx.double()).sum()) < 1e-4 * abs(lhs) + 1e-5
+    rec = torch.empty_like(xs)
+    assert L.tmdiff_haar_idwt2d_fwd(*[p(b) for b in bands], p(rec), 6, 4, 6, 2.0, S) == 0
+    assert_close(rec, xs, 1e-6, 1e-6, "idwt2d_fwd inverts dwt2d_fwd")
+    gi = [torch.empty(6, 4, 6, device="cuda") for _ in range(4)]
+    assert L.tmdiff_haar_idwt2d_bwd(p(dx), *[p(b) for b in gi], 6, 4, 6, 2.0, S) == 0
+    ref_g = haar_dwt2d(dx.cpu())
+    for b, r, s in zip(gi, ref_g, (2.0, 1, 1, 1)):
+        assert_close(b.cpu(), r * s, 1e-6, 1e-6, "idwt2d_bwd")
+    assert L.tmdiff_haar_dwt2d_bwd(p(gb[0]), p(gb[1]), None, None, p(dx), 6, 8, 12, 0.5, 1.0, S) == -1
+    # dpm axpby 2/3/4
+    v = [cu(torch.randn(1000)) for _ in range(4)]
+    c = [0.3, -1.7, 2.5, 0.01]
+    out = torch.empty(1000, device="cuda")
+    assert L.tmdiff_dpm_axpby2(p(v[0]), c[0], p(v[1]), c[1], p(out), 1000, S) == 0
+    assert_close(out, c[0] * v[0] + c[1] * v[1], 1e-6, 1e-6, "axpby2")
+    assert L.tmdiff_dpm_axpby3(p(v[0]), c[0], p(v[1]), c[1], p(v[2]), c[2], p(out), 1000, S) == 0
+    assert_close(out, c[0] * v[0] + c[1] * v[1] + c[2] * v[2], 1e-6, 1e-6, "axpby3")
+    assert L.tmdiff_dpm_axpby4(p(v[0]), c[0], p(v[1]), c[1], p(v[2]), c[2], p(v[3]), c[3], p(out), 1000, S) == 0
+    assert_close(out, c[0] * v[0] + c[1] * v[1] + c[2] * v[2] + c[3] * v[3], 1e-6, 1e-6, "axpby4")

@@ -170,3 +170,91 @@ def test_tiling_helpers_roundtrip():
     assert q.shape == (4, 4, 8, 8) and torch.equal(q[3], img[0, :, 8:, 8:])                   # reference order
     cube = torch.rand(5, 32, 32)
     assert torch.equal(T.patch_16(T.unpatch_16(cube)), cube) and T.unpatch_16(cube).shape == (16, 5, 8, 8)
+
+
+def _tiny_clip_dir(path):
+    """A local 1-layer random CLIP text model + character-level tokenizer (stands in for clip-vit-large-patch14)."""
+    import json
+    from transformers import CLIPTextConfig, CLIPTextModel, CLIPTokenizer
+    chars = [chr(c) for c in range(ord("a"), ord("z") + 1)] + list("0123456789.,-():")
+    vocab = {}
+    for suffix in ("", "</w>"):
+        for ch in chars:
+            vocab[ch + suffix] = len(vocab)
+    vocab["<|startoftext|>"], vocab["<|endoftext|>"] = len(vocab), len(vocab) + 1
+    with open(os.path.join(path, "vocab.json"), "w") as f:
+        json.dump(vocab, f)
+    with open(os.path.join(path, "merges.txt"), "w") as f:
+        f.write("#version: 0.2\n")
+    CLIPTokenizer(os.path.join(path, "vocab.json"), os.path.join(path, "merges.txt")).save_pretrained(path)
+    eos = vocab["<|endoftext|>"]
+    cfg = CLIPTextConfig(vocab_size=len(vocab), hidden_size=768, intermediate_size=64, num_hidden_layers=1,
+                         num_attention_heads=4, max_position_embeddings=77, bos_token_id=vocab["<|startoftext|>"],
+                         eos_token_id=eos, pad_token_id=eos)
+    torch.manual_seed(0)
+    CLIPTextModel(cfg).eval().save_pretrained(path)
+
+
+def test_clip_embedder_and_embedding_cache(tmp_path):
+    """FrozenCLIPEmbedder (ref core/clip.py:15-59) from a local directory, the five-paragraph cache file, and its
+    injection into WavBEST (ref Hyper_unet_general.py:566-598)."""
+    from tmdiff_amd import clip
+    from tmdiff_amd.prompts import PROMPT_TEXT
+    from tmdiff_amd.Hyper_unet_general import WavBEST, PROMPTS
+    with pytest.raises(FileNotFoundError):
+        clip.FrozenCLIPEmbedder("openai/clip-vit-large-patch14", device="cpu")      # never downloads
+    d = str(tmp_path / "clip")
+    os.makedirs(d)
+    _tiny_clip_dir(d)
+    emb = clip.FrozenCLIPEmbedder(d, device="cpu")
+    assert not any(p.requires_grad for p in emb.parameters()) and not emb.transformer.training
+    z = emb.encode(PROMPT_TEXT["QB"])
+    assert z.shape == (1, 768) and torch.equal(z, emb.encode(PROMPT_TEXT["QB"]))
+    assert clip.FrozenCLIPEmbedder(d, device="cpu", layer="last").encode("a b").shape == (1, 768)
+    assert clip.FrozenCLIPEmbedder(d, device="cpu", layer="hidden", layer_idx=1).encode("a b").shape == (1, 77, 768)
+    table = clip.build_text_embeddings(emb)
+    assert set(table) == set(PROMPTS) == set(PROMPT_TEXT)
+    assert not torch.equal(table["QB"], table["GF2"])           # (77 character-tokens only reach the sensor name here)
+    out = str(tmp_path / "emb.pt")
+    clip.main(["--clip", d, "--out", out, "--device", "cpu"])
+    back = clip.load_text_embeddings(out)
+    for k in PROMPTS:
+        assert torch.equal(back[k], table[k])
+    net = WavBEST([4, 8, 16, 32], text_embeddings=out)
+    assert torch.equal(net.get_embeding("WV3"), table["WV3"]) and net.get_embeding("nope") is None
+    assert net.get_prompt("WV2").startswith("The GaoFen-2") and net.get_prompt("nope") is None
+    torch.save({"QB": table["QB"]}, out)
+    with pytest.raises(KeyError):
+        clip.load_text_embeddings(out)
+
+
+def test_val_dataset_writes_mat_and_scores(tmp_path):
+    """evaluate.val_dataset (ref driver :126-152) with a stand-in trainer: .mat key/scale/layout and SSIM/SAM."""
+    import scipy.io as scio
+    from tmdiff_amd import evaluate, metrics
+
+    class Trainer:
+        def feed_data(self, d):
+            self.d = d
+
+        def test(self, continous=False, prompt="QB"):
+            self.prompt = prompt
+            self.SR = torch.cat([torch.zeros_like(self.d["HR"]), self.d["HR"] * 1.5 - 0.2])   # stack; last = result
+
+        def get_current_visuals(self):
+            return {"SR": self.SR, "HR": self.d["HR"]}
+
+    g = torch.Generator().manual_seed(3)
+    loader = [{"HR": torch.rand(1, 4, 16, 16, generator=g)} for _ in range(2)]
+    t = Trainer()
+    score = evaluate.val_dataset(t, "GF2", loader, str(tmp_path), log=lambda *a: None)
+    assert t.prompt == "GF2"
+    m = scio.loadmat(os.path.join(str(tmp_path), "GF2", "output_mulExm_1.mat"))["sr"]
+    want = evaluate.to_hwc01(loader[1]["HR"] * 1.5 - 0.2)
+    assert m.shape == (16, 16, 4) and np.allclose(m, want * 1023.0, rtol=1e-6) and m.min() >= 0 and m.max() <= 1023.0
+    hr1 = evaluate.to_hwc01(loader[1]["HR"])
+    hr0, sr0 = evaluate.to_hwc01(loader[0]["HR"]), evaluate.to_hwc01(loader[0]["HR"] * 1.5 - 0.2)
+    assert abs(score["ssim_GF2"] - (metrics.ssim(hr0, sr0, 1) + metrics.ssim(hr1, want, 1)) / 2) < 1e-12
+    assert abs(score["sam_GF2"] - (metrics.sam(hr0, sr0) + metrics.sam(hr1, want)) / 2) < 1e-12
+    evaluate.val_dataset(t, "WV3", loader[:1], str(tmp_path), log=lambda *a: None)
+    assert np.allclose(scio.loadmat(os.path.join(str(tmp_path), "WV3", "output_mulExm_0.mat"))["sr"], sr0 * 2047.0, rtol=1e-6)

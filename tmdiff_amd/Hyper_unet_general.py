@@ -184,6 +184,11 @@ class WavBEST(nn.Module):
         self._cond = None        # pinned step-invariant tensors of the current image set
 
     # ---- reference-shaped helpers ---------------------------------------------------------------
+    def get_prompt(self, prompt):
+        """Sensor paragraph for a prompt name, ``None`` for an unknown one (ref :574-585)."""
+        from .prompts import PROMPT_TEXT
+        return PROMPT_TEXT.get(prompt)
+
     def get_embeding(self, prompt):
         return self.text_embeddings.get(prompt)
 

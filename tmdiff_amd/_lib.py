@@ -64,6 +64,20 @@ SIGNATURES = {
     "tmdiff_layer_norm": (C.c_int, [vp, vp, vp, vp, C.c_int64, C.c_int32, C.c_float, vp]),
     "tmdiff_geglu": (C.c_int, [vp, vp, C.c_int64, C.c_int32, C.c_int32, vp]),
     "tmdiff_q_sample": (C.c_int, [vp, vp, vp, vp, C.c_int32, C.c_int64, vp]),
+    # per-operator names (thin fronts of the entry points above)
+    "tmdiff_conv3d_k3_fwd": (C.c_int, [C.POINTER(Conv3dDesc), vp]),
+    "tmdiff_conv3d_k3_dgrad": (C.c_int, [C.POINTER(Conv3dDesc), vp]),
+    "tmdiff_conv3d_k3_wgrad": (C.c_int, [C.POINTER(Conv3dDesc), vp, vp, vp, vp]),
+    "tmdiff_conv3d_k1_fwd": (C.c_int, [C.POINTER(Conv3dDesc), vp]),
+    "tmdiff_conv3d_k1_dgrad": (C.c_int, [C.POINTER(Conv3dDesc), vp]),
+    "tmdiff_conv3d_k1_wgrad": (C.c_int, [C.POINTER(Conv3dDesc), vp, vp, vp, vp]),
+    "tmdiff_haar_dwt2d_fwd": (C.c_int, [vp, vp, vp, vp, vp, C.c_int64, C.c_int32, C.c_int32, C.c_float, C.c_float, vp]),
+    "tmdiff_haar_dwt2d_bwd": (C.c_int, [vp, vp, vp, vp, vp, C.c_int64, C.c_int32, C.c_int32, C.c_float, C.c_float, vp]),
+    "tmdiff_haar_idwt2d_fwd": (C.c_int, [vp, vp, vp, vp, vp, C.c_int64, C.c_int32, C.c_int32, C.c_float, vp]),
+    "tmdiff_haar_idwt2d_bwd": (C.c_int, [vp, vp, vp, vp, vp, C.c_int64, C.c_int32, C.c_int32, C.c_float, vp]),
+    "tmdiff_dpm_axpby2": (C.c_int, [vp, C.c_float, vp, C.c_float, vp, C.c_int64, vp]),
+    "tmdiff_dpm_axpby3": (C.c_int, [vp, C.c_float, vp, C.c_float, vp, C.c_float, vp, C.c_int64, vp]),
+    "tmdiff_dpm_axpby4": (C.c_int, [vp, C.c_float, vp, C.c_float, vp, C.c_float, vp, C.c_float, vp, C.c_int64, vp]),
 }
 
 
