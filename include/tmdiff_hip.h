@@ -57,7 +57,7 @@ typedef struct tmdiff_conv3d_desc {
   int32_t nseg;        /* 1..3 input segments */
   int32_t seg_c[3];    /* channels per segment, sum == Cin (groups==3: each Cin/3) */
   const float* seg_x[3];
-  const float* w_packed; /* from tmdiff_conv3d_pack_weights */
+  const float* w_packed; /* from tmdiff_conv3d_pack_weights (or _bf16 for tmdiff_conv3d_fwd_bf16) */
   const float* bias;     /* [Cout] or NULL */
   float bias_scale;
   const float* in_shift; /* [B, Cin] (row stride in_shift_stride floats) or NULL */
@@ -78,6 +78,19 @@ typedef struct tmdiff_conv3d_desc {
 int tmdiff_conv3d_pack_weights(const float* w, float* packed, int32_t Cout, int32_t Cin, int32_t ksize,
                                int32_t groups, int32_t mode, tmdiff_stream_t stream);
 int tmdiff_conv3d_fwd(const tmdiff_conv3d_desc* d, tmdiff_stream_t stream);
+
+/* ---- bf16 compute / fp32 accumulate (WorldView-3 inference) --------------------------
+ * Same descriptor and fused prologue / epilogue as tmdiff_conv3d_fwd; activations, bias, residual and output stay
+ * fp32 in memory.  The prologue result x' and the weights are rounded to bf16 (round to nearest even), products
+ * are accumulated in fp32 on v_mfma_f32_32x32x16_bf16.  d->w_packed must come from tmdiff_conv3d_pack_weights_bf16
+ * (tmdiff_conv3d_packed_bf16_bytes bytes; 0 = shape not supported).
+ * Supported: ksize 3, Cin/groups and every segment a multiple of 8 channels, Cout/groups a multiple of 32, no
+ * in_mask; anything else returns TMDIFF_E_UNSUPPORTED and the caller keeps using tmdiff_conv3d_fwd (forward only:
+ * training runs in fp32). */
+size_t tmdiff_conv3d_packed_bf16_bytes(int32_t Cout, int32_t Cin, int32_t groups);
+int tmdiff_conv3d_pack_weights_bf16(const float* w, void* packed, int32_t Cout, int32_t Cin, int32_t groups,
+                                    tmdiff_stream_t stream);
+int tmdiff_conv3d_fwd_bf16(const tmdiff_conv3d_desc* d, tmdiff_stream_t stream);
 
 /* ---- backward of the fused convolution (finetune path) ----------------------------------
  * With x' = prologue(x) and y = (conv(x', w) + bias_scale*bias + residual) * out_scale, and g = dL/dy * out_scale:

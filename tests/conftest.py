@@ -42,8 +42,8 @@ def golden():
 
 def rel_err(a, b):
     """max|a-b| / max|b| and relative L2 error."""
-    a = torch.as_tensor(np.asarray(a)).double()
-    b = torch.as_tensor(np.asarray(b)).double()
+    a, b = (t.detach().cpu() if isinstance(t, torch.Tensor) else torch.as_tensor(np.asarray(t)) for t in (a, b))
+    a, b = a.double(), b.double()
     assert a.shape == b.shape, (a.shape, b.shape)
     scale = b.abs().max().clamp_min(1e-30)
     return float((a - b).abs().max() / scale), float((a - b).norm() / b.norm().clamp_min(1e-30))

@@ -345,3 +345,70 @@ def test_per_operator_abi_names(ops):
     assert_close(out, c[0] * v[0] + c[1] * v[1] + c[2] * v[2], 1e-6, 1e-6, "axpby3")
     assert L.tmdiff_dpm_axpby4(p(v[0]), c[0], p(v[1]), c[1], p(v[2]), c[2], p(v[3]), c[3], p(out), 1000, S) == 0
     assert_close(out, c[0] * v[0] + c[1] * v[1] + c[2] * v[2] + c[3] * v[3], 1e-6, 1e-6, "axpby4")
+
+
+def _bf16_round(t):
+    return t.to(torch.bfloat16).to(torch.float64)
+
+
+@pytest.mark.parametrize("case", [
+    # B, Cin(segments), Cout, groups, N, H, W, shift, scale, act, bias, residual
+    dict(B=2, segs=[16], cout=64, g=1, N=4, H=8, W=8, shift=True, scale=True, act=True, bias=True, res=True),
+    dict(B=1, segs=[8, 16, 8], cout=32, g=1, N=8, H=16, W=32, shift=True, scale=False, act=True, bias=True, res=False),
+    dict(B=2, segs=[24], cout=32, g=1, N=4, H=6, W=10, shift=False, scale=True, act=False, bias=False, res=True),
+    dict(B=1, segs=[16, 16, 16], cout=96, g=3, N=8, H=8, W=8, shift=False, scale=False, act=False, bias=True, res=False),
+    dict(B=1, segs=[64], cout=128, g=1, N=8, H=20, W=12, shift=True, scale=True, act=True, bias=True, res=False),
+    dict(B=3, segs=[32], cout=32, g=1, N=2, H=5, W=7, shift=False, scale=True, act=True, bias=False, res=False),
+])
+def test_conv3d_bf16_operands_fp32_accumulate(ops, case):
+    """bf16-compute conv (config 3 mode): equals an fp64 convolution of the bf16-rounded prologue output with the
+    bf16-rounded weights up to fp32 accumulation error; and stays within the bf16 tolerance of the exact result."""
+    torch.manual_seed(17)
+    B, cin, cout, g = case["B"], sum(case["segs"]), case["cout"], case["g"]
+    shp = (case["N"], case["H"], case["W"])
+    segs = [torch.randn(B, c, *shp) for c in case["segs"]]
+    w = torch.randn(cout, cin // g, 3, 3, 3) / (cin // g * 27) ** 0.5
+    bias = torch.randn(cout) if case["bias"] else None
+    shift = torch.randn(B, cin) if case["shift"] else None
+    scale = torch.rand(B, cin) + 0.5 if case["scale"] else None
+    res = torch.randn(B, cout, *shp) if case["res"] else None
+    x = torch.cat(segs, 1).double()
+    if shift is not None:
+        x = (x.float() + shift[:, :, None, None, None]).double()      # the kernel adds in fp32
+    if case["act"]:
+        x = x * torch.sigmoid(x)
+    if scale is not None:
+        x = x * scale[:, :, None, None, None].double()
+    exact = F.conv3d(x, w.double(), None, padding=1, groups=g)
+    rounded = F.conv3d(_bf16_round(x.float()), _bf16_round(w), None, padding=1, groups=g)
+    for t in (exact, rounded):
+        if bias is not None:
+            t += 2.0 * bias.double()[None, :, None, None, None]
+        if res is not None:
+            t += res.double()
+        t *= 0.5
+    assert ops.bf16_conv_supported(cout, cin, 3, g, case["segs"])
+    wp = ops.pack_conv_weight_bf16(cu(w), groups=g)
+    y = ops.conv3d([cu(s) for s in segs], wp, cout, 3, groups=g, math="bf16", bias=cu(bias) if bias is not None else None,
+                   bias_scale=2.0, in_shift=cu(shift) if shift is not None else None,
+                   in_scale=cu(scale) if scale is not None else None, in_act=case["act"],
+                   residual=cu(res) if res is not None else None, out_scale=0.5)
+    # the prologue runs in fp32 on the GPU (fast exp), so a value may round to the neighbouring bf16: allow a few 1e-4
+    assert_close(y.cpu(), rounded.float(), 2e-3, 3e-4, "bf16 conv vs bf16-rounded fp64 conv")
+    assert_close(y.cpu(), exact.float(), 3e-2, 1e-2, "bf16 conv vs exact conv (bf16 tolerance)")
+
+
+def test_conv3d_bf16_rejects_unsupported(ops):
+    from tmdiff_amd._lib import TmdiffError
+    x = cu(torch.randn(1, 8, 4, 8, 8))
+    assert not ops.bf16_conv_supported(16, 8, 3) and not ops.bf16_conv_supported(32, 12, 3)
+    assert not ops.bf16_conv_supported(32, 8, 1) and not ops.bf16_conv_supported(32, 16, 3, 1, [4, 12])
+    with pytest.raises(ValueError):
+        ops.pack_conv_weight_bf16(cu(torch.randn(32, 12, 3, 3, 3)))
+    wp = ops.pack_conv_weight_bf16(cu(torch.randn(32, 8, 3, 3, 3)))
+    with pytest.raises(TypeError):
+        ops.conv3d([x], wp, 32, 3)                                     # bf16 packing handed to the fp32 kernel
+    with pytest.raises(TmdiffError):
+        ops.conv3d([x], wp, 32, 3, math="bf16", in_mask=torch.ones_like(x))
+    with pytest.raises(TmdiffError):
+        ops.conv3d([x], wp, 16, 3, math="bf16")                        # Cout not a multiple of 32

@@ -1,0 +1,352 @@
+// conv3d 3x3x3 with bf16 operands and fp32 accumulation on the bf16 matrix cores of gfx950
+// (v_mfma_f32_32x32x16_bf16: 32 cycles per 32x32x16 product, 16x the rate of the exact-fp32 MFMA).
+// This is the "bf16 compute / fp32 accumulate" mode of the WorldView-3 inference configuration
+// (SURVEY 8d, config 3); the default path stays the exact-fp32 kernel in conv3d.hip.
+//
+// Same contract as tmdiff_conv3d_fwd (include/tmdiff_hip.h): activations are fp32 in HBM, the fused
+// prologue  x' = act(x + shift[b,c]) * scale[b,c]  is evaluated in fp32 and x' is rounded to bf16
+// (round-to-nearest-even) when it is staged in LDS; the weights are rounded once at pack time;
+// products are accumulated in fp32 and the epilogue (bias, residual, scale) is fp32.
+//
+// GEMM view per (batch b, group g):  D[co, pos] = sum_{ci,tap} W[co][ci][tap] * X'[ci][pos + tap]
+//   MFMA rows (A) = 32 output channels, cols (B) = 32 output positions = 4 rows x 8 columns of one band plane,
+//   K = 16 = 8 input channels x 2 taps: lanes 0-31 take tap 2p, lanes 32-63 tap 2p+1 (27 taps + one zero tap).
+// A workgroup (4 waves) owns 4 bands x TH x TW positions x CO channels; wave w works on band w.
+// Per chunk of 8 input channels the LDS holds
+//   x : [halo position][8 ch] bf16 = one 16-byte unit per position, so a lane's B operand is ONE ds_read_b128;
+//       rows are 24 units apart (== 8 mod 16), which makes the 4x8-position reads bank-conflict free; for
+//       TW == 8 two band planes share a row (units 0-9 and 12-21);
+//   w : [tap][co][8 ci] bf16, copied verbatim from the packed weights (16-byte global loads).
+// Pipeline: the next chunk is loaded into registers while the MFMAs of this one run; between chunks the
+// registers go through the prologue into LDS (two barriers per chunk).  The other workgroups on the CU cover
+// that hand-off.
+#include <cstdint>
+
+#include "common.h"
+
+namespace {
+
+using f32x16 = __attribute__((ext_vector_type(16))) float;
+using bf16x8 = __attribute__((ext_vector_type(8))) __bf16;
+
+struct BfArgs {
+  int B, N, H, W;
+  int Cin, Cout, cin_g, cout_g, groups;
+  int seg_c[3];
+  const float* seg_x[3];
+  const uint4* wp;  // [g][chunk][28 taps][cout_g] units of 8 bf16
+  const float* bias;
+  float bias_scale;
+  const float* in_shift;
+  const float* in_scale;
+  int shift_stride, scale_stride;
+  int in_act;
+  const float* residual;
+  float out_scale;
+  float* y;
+  int tiles_n, tiles_h, tiles_w, tiles_co;
+  unsigned total_blocks;
+};
+
+__device__ __forceinline__ unsigned xcd_remap(unsigned bid, unsigned nwg) {
+  const unsigned q = nwg / 8, r = nwg % 8, xcd = bid % 8, k = bid / 8;
+  return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + k;
+}
+
+constexpr int TN = 4;    // bands per workgroup = waves
+constexpr int RS = 24;   // LDS row stride in 16-byte units
+constexpr int TAPS2 = 28;
+
+template <int TH, int TW>
+struct XLayout {
+  static constexpr bool ZPAIR = TW == 8;
+  static constexpr int HN = TN + 2, HH = TH + 2, HW = TW + 2;
+  static constexpr int UNITS = (ZPAIR ? HN / 2 : HN) * HH * RS;
+  static_assert(TW == 8 || TW == 16, "row of 24 units holds one 18-wide or two 10-wide halo rows");
+  __device__ static __forceinline__ int unit(int z, int y, int x) {
+    return ZPAIR ? ((z >> 1) * HH + y) * RS + (z & 1) * 12 + x : (z * HH + y) * RS + x;
+  }
+};
+
+template <int NS, int MSUB, int TH, int TW>
+__global__ void __launch_bounds__(256, 2) conv3d_bf16_kernel(const BfArgs a) {
+  using XL = XLayout<TH, TW>;
+  constexpr int CO = 32 * MSUB;
+  constexpr int HH = XL::HH, HW = XL::HW;
+  constexpr int HALO_POS = XL::HN * HH * HW;
+  constexpr int XI = (HALO_POS + 255) / 256;  // halo positions per thread
+  constexpr int WUNITS = TAPS2 * CO;
+  constexpr int WI = (WUNITS + 255) / 256;    // weight units per thread
+  constexpr int SINK = XL::UNITS + WUNITS;    // unit that absorbs the stores of idle staging slots
+  static_assert(TH * TW == 32 * NS, "a wave covers one band plane = NS tiles of 4x8 positions");
+  __shared__ uint4 lds[SINK + 1];
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63, wv = tid >> 6;
+  const int l31 = lane & 31, kg = lane >> 5;
+
+  unsigned id = xcd_remap(blockIdx.x, a.total_blocks);
+  const int co_tile = __builtin_amdgcn_readfirstlane(id % a.tiles_co); id /= a.tiles_co;
+  const int tw_i = __builtin_amdgcn_readfirstlane(id % a.tiles_w); id /= a.tiles_w;
+  const int th_i = __builtin_amdgcn_readfirstlane(id % a.tiles_h); id /= a.tiles_h;
+  const int tn_i = __builtin_amdgcn_readfirstlane(id % a.tiles_n); id /= a.tiles_n;
+  const int g = __builtin_amdgcn_readfirstlane(id % a.groups);
+  const int b = __builtin_amdgcn_readfirstlane(id / a.groups);
+  const int n0 = tn_i * TN, h0 = th_i * TH, w0 = tw_i * TW;
+  const int co0 = co_tile * CO;
+  const long plane = (long)a.N * a.H * a.W;
+  const int nchunks = a.cin_g / 8;
+
+  // ---- staging pattern of this thread: XI halo positions (all 8 channels of a chunk each), WI weight units ----
+  int goff[XI], xdst[XI];
+  bool inb[XI];
+#pragma unroll
+  for (int i = 0; i < XI; ++i) {
+    const int e = tid + 256 * i;
+    const int xz = e % HW, yz = (e / HW) % HH, zz = e / (HW * HH);
+    const int n = n0 + zz - 1, h = h0 + yz - 1, w = w0 + xz - 1;
+    const bool valid = e < HALO_POS;
+    inb[i] = valid && n >= 0 && n < a.N && h >= 0 && h < a.H && w >= 0 && w < a.W;
+    goff[i] = inb[i] ? (n * a.H + h) * a.W + w : 0;
+    xdst[i] = valid ? XL::unit(zz, yz, xz) : SINK;
+  }
+  int wsrc[WI], wdst[WI];
+#pragma unroll
+  for (int i = 0; i < WI; ++i) {
+    const int u = tid + 256 * i;
+    const bool valid = u < WUNITS;
+    const int tap = valid ? u / CO : 0, j = u % CO;
+    wsrc[i] = tap * a.cout_g + co0 + j;
+    wdst[i] = valid ? XL::UNITS + u : SINK;
+  }
+  const uint4* wg = a.wp + (long)g * nchunks * TAPS2 * a.cout_g;
+
+  // ---- operand addresses (16-byte units) ---------------------------------------------------------------------
+  // B: position (band wv, row r, column xl) of sub-tile s, tap (dz,dy,dx): unit(wv+dz, y0(s)+r+dy, x0(s)+xl+dx).
+  const int lane_pos = (l31 >> 3) * RS + (l31 & 7);
+  int baddr[TAPS2 / 2];
+#pragma unroll
+  for (int p = 0; p < TAPS2 / 2; ++p) {
+    const int t0 = 2 * p, t1 = 2 * p + 1 < 27 ? 2 * p + 1 : 26;  // tap 27 has zero weights; read anything valid
+    const int u0 = XL::unit(wv + t0 / 9, (t0 / 3) % 3, t0 % 3);
+    const int u1 = XL::unit(wv + t1 / 9, (t1 / 3) % 3, t1 % 3);
+    baddr[p] = lane_pos + (kg ? u1 : u0);
+  }
+  const int aaddr = XL::UNITS + kg * CO + l31;  // + (2p*CO + m*32)
+
+  // bias of channel co0 + m*32 + l31 (used in the epilogue through readlane)
+  float bias_v[MSUB];
+#pragma unroll
+  for (int m = 0; m < MSUB; ++m) bias_v[m] = a.bias ? a.bias[g * a.cout_g + co0 + m * 32 + l31] * a.bias_scale : 0.f;
+
+  f32x16 acc[NS][MSUB];
+#pragma unroll
+  for (int s = 0; s < NS; ++s)
+#pragma unroll
+    for (int m = 0; m < MSUB; ++m)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[s][m][r] = 0.f;
+
+  float xr[XI][8];
+  unsigned wr[WI][4];  // scalars, not uint4[]: vector-typed register arrays end up in scratch
+  auto load_chunk = [&](int c) __attribute__((always_inline)) {
+    // the 8 channels of a chunk lie in one input segment (segment sizes are multiples of 8)
+    const int cg = g * a.cin_g + c * 8;
+    const float* src;
+    int cl;
+    if (cg < a.seg_c[0]) src = a.seg_x[0], cl = cg;
+    else if (cg < a.seg_c[0] + a.seg_c[1]) src = a.seg_x[1], cl = cg - a.seg_c[0];
+    else src = a.seg_x[2], cl = cg - a.seg_c[0] - a.seg_c[1];
+    const int segc = cg < a.seg_c[0] ? a.seg_c[0] : (cg < a.seg_c[0] + a.seg_c[1] ? a.seg_c[1] : a.seg_c[2]);
+    const float* base = src + ((long)b * segc + cl) * plane;
+#pragma unroll
+    for (int i = 0; i < XI; ++i)
+#pragma unroll
+      for (int j = 0; j < 8; ++j) xr[i][j] = base[goff[i] + j * plane];
+    const uint4* wc = wg + (long)c * TAPS2 * a.cout_g;
+#pragma unroll
+    for (int i = 0; i < WI; ++i) {
+      const uint4 t = wc[wsrc[i]];
+      wr[i][0] = t.x, wr[i][1] = t.y, wr[i][2] = t.z, wr[i][3] = t.w;
+    }
+  };
+  auto stage_chunk = [&](int c) __attribute__((always_inline)) {
+    const int cg = g * a.cin_g + c * 8;
+    float sh[8], sc[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      sh[j] = a.in_shift ? a.in_shift[(long)b * a.shift_stride + cg + j] : 0.f;
+      sc[j] = a.in_scale ? a.in_scale[(long)b * a.scale_stride + cg + j] : 1.f;
+    }
+#pragma unroll
+    for (int i = 0; i < XI; ++i) {
+      union { bf16x8 h; uint4 u; } pk;
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        float v = xr[i][j] + sh[j];
+        if (a.in_act) v = tmdiff::silu_f(v);
+        v *= sc[j];
+        pk.h[j] = (__bf16)(inb[i] ? v : 0.f);
+      }
+      lds[xdst[i]] = pk.u;
+    }
+#pragma unroll
+    for (int i = 0; i < WI; ++i) lds[wdst[i]] = make_uint4(wr[i][0], wr[i][1], wr[i][2], wr[i][3]);
+  };
+
+  load_chunk(0);
+  for (int c = 0; c < nchunks; ++c) {
+    stage_chunk(c);
+    __syncthreads();
+    if (c + 1 < nchunks) load_chunk(c + 1);
+#pragma unroll
+    for (int p = 0; p < TAPS2 / 2; ++p) {
+      union { bf16x8 h; uint4 u; } av[MSUB], bv[NS];
+#pragma unroll
+      for (int m = 0; m < MSUB; ++m) av[m].u = lds[aaddr + 2 * p * CO + m * 32];
+#pragma unroll
+      for (int s = 0; s < NS; ++s) {
+        constexpr int per_row = TW / 8;  // sub-tiles side by side in a plane
+        bv[s].u = lds[baddr[p] + (s / per_row) * 4 * RS + (s % per_row) * 8];
+      }
+#pragma unroll
+      for (int s = 0; s < NS; ++s)
+#pragma unroll
+        for (int m = 0; m < MSUB; ++m)
+          acc[s][m] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av[m].h, bv[s].h, acc[s][m], 0, 0, 0);
+    }
+    __syncthreads();
+  }
+
+  // ---- epilogue: D layout col = lane&31 (position), row (r&3) + 8*(r>>2) + 4*kg (channel) ---------------------
+#pragma unroll
+  for (int m = 0; m < MSUB; ++m) {
+    float bias_r[16];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int row = (r & 3) + 8 * (r >> 2);
+      const float b0 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(bias_v[m]), row));
+      const float b1 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(bias_v[m]), row + 4));
+      bias_r[r] = kg ? b1 : b0;
+    }
+#pragma unroll
+    for (int s = 0; s < NS; ++s) {
+      constexpr int per_row = TW / 8;
+      const int n = n0 + wv, h = h0 + (s / per_row) * 4 + (l31 >> 3), w = w0 + (s % per_row) * 8 + (l31 & 7);
+      const bool pok = n < a.N && h < a.H && w < a.W;
+      const long sp = pok ? ((long)n * a.H + h) * a.W + w : 0;
+      const long obase = ((long)b * a.Cout + g * a.cout_g + co0 + m * 32 + 4 * kg) * plane + sp;
+      float res[16];
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int row = (r & 3) + 8 * (r >> 2);
+        res[r] = (a.residual && pok) ? a.residual[obase + row * plane] : 0.f;
+      }
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int row = (r & 3) + 8 * (r >> 2);
+        if (pok) a.y[obase + row * plane] = (acc[s][m][r] + bias_r[r] + res[r]) * a.out_scale;
+      }
+    }
+  }
+}
+
+// packed[g][chunk][tap 0..27][co][8 ci] (bf16, RNE) <- w[g*cout_g + co][chunk*8 + ci][tap]; tap 27 = 0
+__global__ void __launch_bounds__(256) pack_weights_bf16_kernel(const float* __restrict__ w, uint16_t* __restrict__ packed,
+                                                                int cout_g, int cin_g, int groups, long total) {
+  for (long i = blockIdx.x * 256L + threadIdx.x; i < total; i += 256L * gridDim.x) {
+    const int ci8 = (int)(i % 8);
+    long r = i / 8;
+    const int co = (int)(r % cout_g); r /= cout_g;
+    const int tap = (int)(r % TAPS2); r /= TAPS2;
+    const int chunk = (int)(r % (cin_g / 8));
+    const int g = (int)(r / (cin_g / 8));
+    float v = 0.f;
+    if (tap < 27) v = w[(((long)g * cout_g + co) * cin_g + chunk * 8 + ci8) * 27 + tap];
+    const __bf16 h = (__bf16)v;
+    packed[i] = *reinterpret_cast<const uint16_t*>(&h);
+  }
+}
+
+template <int NS, int MSUB, int TH, int TW>
+int launch(BfArgs& a, hipStream_t st) {
+  constexpr int CO = 32 * MSUB;
+  a.tiles_n = (a.N + TN - 1) / TN;
+  a.tiles_h = (a.H + TH - 1) / TH;
+  a.tiles_w = (a.W + TW - 1) / TW;
+  a.tiles_co = a.cout_g / CO;
+  const long blocks = (long)a.B * a.groups * a.tiles_n * a.tiles_h * a.tiles_w * a.tiles_co;
+  if (blocks <= 0 || blocks > 0x7fffffffL) return tmdiff::fail(TMDIFF_E_INVALID, "conv3d_bf16: grid of %ld blocks", blocks);
+  a.total_blocks = (unsigned)blocks;
+  conv3d_bf16_kernel<NS, MSUB, TH, TW><<<(unsigned)blocks, 256, 0, st>>>(a);
+  return tmdiff::check_launch("conv3d_fwd_bf16");
+}
+
+}  // namespace
+
+extern "C" size_t tmdiff_conv3d_packed_bf16_bytes(int32_t Cout, int32_t Cin, int32_t groups) {
+  if (groups < 1 || Cout <= 0 || Cin <= 0 || Cin % groups || (Cin / groups) % 8) return 0;
+  return (size_t)Cin / 8 * TAPS2 * (Cout / groups) * 16;
+}
+
+extern "C" int tmdiff_conv3d_pack_weights_bf16(const float* w, void* packed, int32_t Cout, int32_t Cin, int32_t groups,
+                                               tmdiff_stream_t stream) {
+  using namespace tmdiff;
+  TMDIFF_REQUIRE(w && packed, "pack_weights_bf16: NULL pointer");
+  TMDIFF_REQUIRE(groups >= 1 && Cout > 0 && Cin > 0 && Cout % groups == 0 && Cin % groups == 0,
+                 "pack_weights_bf16: Cout=%d Cin=%d groups=%d", Cout, Cin, groups);
+  TMDIFF_REQUIRE((Cin / groups) % 8 == 0, "pack_weights_bf16: Cin/groups=%d is not a multiple of 8", Cin / groups);
+  const long total = (long)(Cin / 8) * TAPS2 * (Cout / groups) * 8;
+  long blocks = (total + 255) / 256;
+  if (blocks > 4096) blocks = 4096;
+  pack_weights_bf16_kernel<<<(int)blocks, 256, 0, as_stream(stream)>>>(w, static_cast<uint16_t*>(packed), Cout / groups,
+                                                                      Cin / groups, groups, total);
+  return check_launch("conv3d_pack_weights_bf16");
+}
+
+extern "C" int tmdiff_conv3d_fwd_bf16(const tmdiff_conv3d_desc* d, tmdiff_stream_t stream) {
+  using namespace tmdiff;
+  TMDIFF_REQUIRE(d != nullptr, "conv3d_fwd_bf16: NULL descriptor");
+  TMDIFF_REQUIRE(d->B >= 0 && d->N > 0 && d->H > 0 && d->W > 0, "conv3d_fwd_bf16: bad extents B=%d N=%d H=%d W=%d", d->B,
+                 d->N, d->H, d->W);
+  TMDIFF_REQUIRE(d->groups == 1 || d->groups == 3, "conv3d_fwd_bf16: groups=%d (1 or 3)", d->groups);
+  TMDIFF_REQUIRE(d->Cin > 0 && d->Cout > 0 && d->Cin % d->groups == 0 && d->Cout % d->groups == 0,
+                 "conv3d_fwd_bf16: Cin=%d Cout=%d groups=%d", d->Cin, d->Cout, d->groups);
+  TMDIFF_REQUIRE(d->nseg >= 1 && d->nseg <= 3, "conv3d_fwd_bf16: nseg=%d", d->nseg);
+  if (d->ksize != 3) return fail(TMDIFF_E_UNSUPPORTED, "conv3d_fwd_bf16: ksize=%d (3x3x3 only)", d->ksize);
+  if (d->in_mask) return fail(TMDIFF_E_UNSUPPORTED, "conv3d_fwd_bf16: input masks (training) are fp32 only");
+  const int cin_g = d->Cin / d->groups, cout_g = d->Cout / d->groups;
+  if (cin_g % 8 || cout_g % 32)
+    return fail(TMDIFF_E_UNSUPPORTED, "conv3d_fwd_bf16: Cin/g=%d (multiple of 8) Cout/g=%d (multiple of 32)", cin_g, cout_g);
+  if (d->B == 0) return TMDIFF_OK;
+  int csum = 0;
+  for (int i = 0; i < d->nseg; ++i) {
+    TMDIFF_REQUIRE(d->seg_x[i] != nullptr && d->seg_c[i] > 0, "conv3d_fwd_bf16: segment %d is empty", i);
+    if (d->seg_c[i] % 8) return fail(TMDIFF_E_UNSUPPORTED, "conv3d_fwd_bf16: segment of %d channels", d->seg_c[i]);
+    csum += d->seg_c[i];
+  }
+  TMDIFF_REQUIRE(csum == d->Cin, "conv3d_fwd_bf16: segments hold %d channels, Cin=%d", csum, d->Cin);
+  if (d->groups == 3)
+    TMDIFF_REQUIRE(d->nseg == 1 || (d->nseg == 3 && d->seg_c[0] == d->seg_c[1] && d->seg_c[1] == d->seg_c[2]),
+                   "conv3d_fwd_bf16: groups=3 wants 1 segment or 3 equal ones");
+  TMDIFF_REQUIRE(d->w_packed && d->y, "conv3d_fwd_bf16: NULL weights/output");
+  TMDIFF_REQUIRE(aligned16(d->w_packed), "conv3d_fwd_bf16: packed weights must be 16-byte aligned");
+  TMDIFF_REQUIRE((long)d->N * d->H * d->W < (1L << 31), "conv3d_fwd_bf16: plane too large for 32-bit offsets");
+
+  BfArgs a;
+  a.B = d->B; a.N = d->N; a.H = d->H; a.W = d->W;
+  a.Cin = d->Cin; a.Cout = d->Cout; a.groups = d->groups; a.cin_g = cin_g; a.cout_g = cout_g;
+  for (int i = 0; i < 3; ++i) {
+    a.seg_c[i] = i < d->nseg ? d->seg_c[i] : (1 << 28);
+    a.seg_x[i] = i < d->nseg ? d->seg_x[i] : d->seg_x[0];
+  }
+  a.wp = reinterpret_cast<const uint4*>(d->w_packed);
+  a.bias = d->bias; a.bias_scale = d->bias_scale;
+  a.in_shift = d->in_shift; a.in_scale = d->in_scale; a.in_act = d->in_act;
+  a.shift_stride = d->in_shift_stride > 0 ? d->in_shift_stride : (d->in_shift_stride < 0 ? 0 : d->Cin);
+  a.scale_stride = d->in_scale_stride > 0 ? d->in_scale_stride : (d->in_scale_stride < 0 ? 0 : d->Cin);
+  a.residual = d->residual; a.out_scale = d->out_scale; a.y = d->y;
+  hipStream_t st = as_stream(stream);
+  if (cout_g % 64 == 0) return launch<2, 2, 8, 8>(a, st);
+  return d->W >= 16 ? launch<4, 1, 8, 16>(a, st) : launch<2, 1, 8, 8>(a, st);
+}

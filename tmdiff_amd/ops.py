@@ -34,6 +34,25 @@ def pack_conv_weight(w, groups=1, mode=0):
     return out
 
 
+def bf16_conv_supported(cout, cin, ksize, groups=1, seg_channels=None):
+    """Shapes tmdiff_conv3d_fwd_bf16 accepts (include/tmdiff_hip.h); other layers stay on the fp32 kernel."""
+    if ksize != 3 or cin % groups or cout % groups or (cin // groups) % 8 or (cout // groups) % 32:
+        return False
+    return all(c % 8 == 0 for c in (seg_channels or ()))
+
+
+def pack_conv_weight_bf16(w, groups=1):
+    """[Cout, Cin/g, 3,3,3] fp32 -> bf16 packing [g][Cin_g/8][28 taps][Cout_g][8] (returned as an int16 tensor)."""
+    cout, cin_g = w.shape[0], w.shape[1]
+    nbytes = lib.tmdiff_conv3d_packed_bf16_bytes(cout, cin_g * groups, groups)
+    if nbytes == 0 or tuple(w.shape[2:]) != (3, 3, 3):
+        raise ValueError(f"conv weight {tuple(w.shape)} (groups={groups}) has no bf16 packing")
+    out = torch.empty(nbytes // 2, device=w.device, dtype=torch.int16)
+    check(lib.tmdiff_conv3d_pack_weights_bf16(_chk(w.detach(), "w"), out.data_ptr(), cout, cin_g * groups, groups,
+                                              stream_ptr()), "conv3d_pack_weights_bf16")
+    return out
+
+
 def make_conv_desc(segs, w_packed, cout, ksize, y, groups=1, bias=None, bias_scale=1.0, in_shift=None, in_scale=None,
                    shift_stride=0, scale_stride=0, in_act=False, in_mask=None, residual=None, out_scale=1.0):
     """Fill a tmdiff_conv3d_desc.  `segs` = list of 1..3 tensors [B, c_i, N, H, W] (concat-free input).
@@ -48,7 +67,9 @@ def make_conv_desc(segs, w_packed, cout, ksize, y, groups=1, bias=None, bias_sca
             raise ValueError("conv3d: input segments disagree on [B, N, H, W]")
         d.seg_c[i] = s.shape[1]
         d.seg_x[i] = _chk(s, f"segment {i}")
-    d.w_packed = w_packed if isinstance(w_packed, int) else _chk(w_packed, "w_packed")
+    if not isinstance(w_packed, int) and not (w_packed.is_cuda and w_packed.is_contiguous()):
+        raise ValueError("w_packed: need a contiguous packed-weight tensor on the GPU")
+    d.w_packed = w_packed if isinstance(w_packed, int) else w_packed.data_ptr()
     d.bias = _chk(bias, "bias")
     d.bias_scale = bias_scale
     d.in_shift = in_shift if isinstance(in_shift, int) else _chk(in_shift, "in_shift")
@@ -85,16 +106,28 @@ class ConvTimer:
 TIMER = None      # set to a ConvTimer() to time every conv launch
 
 
-def conv3d(segs, w_packed, cout, ksize, out=None, **kw):
+def conv3d(segs, w_packed, cout, ksize, out=None, math="fp32", **kw):
+    """math="fp32": exact-fp32 MFMA kernel (w_packed from pack_conv_weight); "bf16": bf16 operands / fp32
+    accumulation (w_packed from pack_conv_weight_bf16)."""
     b, _, n, h, w = segs[0].shape
     y = out if out is not None else torch.empty(b, cout, n, h, w, device=segs[0].device, dtype=torch.float32)
     d = make_conv_desc(segs, w_packed, cout, ksize, y, **kw)
+    if math == "bf16":
+        if w_packed.dtype != torch.int16:
+            raise TypeError("conv3d(math='bf16') needs weights from pack_conv_weight_bf16")
+        fwd, what = lib.tmdiff_conv3d_fwd_bf16, "conv3d_fwd_bf16"
+    elif math == "fp32":
+        if not isinstance(w_packed, int) and w_packed.dtype != torch.float32:
+            raise TypeError("conv3d(math='fp32') needs weights from pack_conv_weight")
+        fwd, what = lib.tmdiff_conv3d_fwd, "conv3d_fwd"
+    else:
+        raise ValueError(f"conv3d: unknown math {math!r}")
     if TIMER is None:
-        check(lib.tmdiff_conv3d_fwd(C.byref(d), stream_ptr()), "conv3d_fwd")
+        check(fwd(C.byref(d), stream_ptr()), what)
         return y
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     e0.record()
-    check(lib.tmdiff_conv3d_fwd(C.byref(d), stream_ptr()), "conv3d_fwd")
+    check(fwd(C.byref(d), stream_ptr()), what)
     e1.record()
     TIMER.records.append((e0, e1, 2.0 * b * cout * (d.Cin // d.groups) * ksize ** 3 * n * h * w, ksize))
     return y
