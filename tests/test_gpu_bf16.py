@@ -1,0 +1,95 @@
+"""GPU tests of the bf16-compute mode ("bf16 compute / fp32 accumulate").
+Tolerances are the ones SURVEY 8(d) states for bf16: single forward rel-L2 <= 1e-2, DPM-Solver (steps=20, 21 network
+evaluations) PSNR >= 35 dB against the fp32 result on the [0,1] fused image."""
+import pytest
+import torch
+
+from conftest import rel_err
+from oracle import unet_ref as U
+from oracle.diffusion_ref import GeneralDiffusionRef
+from oracle.make_golden import FULL, case_inputs
+
+pytestmark = pytest.mark.gpu
+MID = [32, 64, 128, 256]
+
+
+def cu(t):
+    return t.cuda().contiguous()
+
+
+@pytest.fixture(scope="module")
+def nets():
+    from tmdiff_amd.Hyper_unet_general import WavBEST
+    ref = U.fill_weights_(U.WavBESTRef(channels=MID)).eval()
+    hip = WavBEST(channels=MID)
+    hip.load_state_dict(ref.state_dict())
+    return ref, hip.cuda().eval()
+
+
+def test_unet_bf16_forward_within_bf16_tolerance(nets):
+    ref, hip = nets
+    d = case_inputs(77, 2, 8, 16)
+    t = torch.tensor([[40], [900]])
+    with torch.no_grad():
+        want = ref(d["x_t"], t, d["PAN"], d["MS"], "WV3")
+    args = (cu(d["x_t"]), t.cuda(), cu(d["PAN"]), cu(d["MS"]), "WV3")
+    hip.set_compute_dtype("fp32")
+    y32 = hip(*args).cpu()
+    hip.set_compute_dtype("bf16")
+    try:
+        P = hip._prepare()
+        n_k3 = sum(1 for _, m in hip.named_modules() if isinstance(m, torch.nn.Conv3d) and m.kernel_size[0] == 3
+                   and m.in_channels > 1)
+        assert len(P["bf16"]) == n_k3, "every 3x3x3 conv of the 32-256 network takes the bf16 kernel"
+        y16 = hip(*args).cpu()
+        # condition cache holds in bf16 mode too
+        hip.begin_condition_cache(args[2], args[3], "WV3")
+        try:
+            assert torch.equal(hip(*args).cpu(), y16)
+        finally:
+            hip.end_condition_cache()
+    finally:
+        hip.set_compute_dtype("fp32")
+    m32, l32 = rel_err(y32, want)
+    m16, l16 = rel_err(y16, want)
+    print(f"fp32: max-rel {m32:.2e} rel-L2 {l32:.2e};  bf16: max-rel {m16:.2e} rel-L2 {l16:.2e}")
+    assert l32 <= 1e-5 and l16 <= 1e-2 and m16 <= 5e-2
+    assert l16 > 1e-5, "bf16 mode must actually change the arithmetic"
+    assert torch.equal(hip(*args).cpu(), y32), "switching back restores the exact-fp32 path"
+    with pytest.raises(ValueError):
+        hip.set_compute_dtype("fp8")
+
+
+def test_dpm_solver_bf16_psnr(nets):
+    from tmdiff_amd.diffusion_general import GeneralDiffusion
+    from tmdiff_amd.util import psnr
+    ref, hip = nets
+    noise = lambda like: torch.randn(like.shape, dtype=torch.float32)
+    diff = GeneralDiffusion(hip, "l1", noise_fn=noise).cuda()
+    diff.set_new_noise_schedule({"schedule": "cosine", "n_timestep": 1000}, "cuda")
+    d = case_inputs(78, 2, 8, 16)
+    dev = {k: cu(v) for k, v in d.items()}
+    torch.manual_seed(5)
+    want = diff.sample_by_dpmsolver(dev, "WV3", steps=20).cpu()
+    hip.set_compute_dtype("bf16")
+    try:
+        torch.manual_seed(5)
+        got = diff.sample_by_dpmsolver(dev, "WV3", steps=20).cpu()
+        assert diff.last_solver.nfe == 21
+    finally:
+        hip.set_compute_dtype("fp32")
+    p = psnr(got, want)
+    print(f"DPM-Solver++ 21 NFE, bf16 vs fp32: PSNR {p:.1f} dB, max|d| {(got - want).abs().max():.2e}")
+    assert p >= 35.0
+
+
+def test_factory_compute_dtype_option():
+    from tmdiff_amd import networks
+    opt = {"phase": "val", "gpu_ids": [0], "distributed": False,
+           "model": {"unet": {"channel_multiplier": [8, 16, 32, 64]}, "diffusion": {"loss_type": "l1"},
+                     "init_type": "orthogonal", "compute_dtype": "bf16"}}
+    net = networks.define_General(opt)
+    assert net.denoise_fn.compute_dtype == "bf16"
+    opt["model"]["compute_dtype"] = "fp16"
+    with pytest.raises(ValueError):
+        networks.define_General(opt)

@@ -180,6 +180,7 @@ class WavBEST(nn.Module):
         # fp32 frequency table of gamma_embedding (ref :89-92), computed on the host exactly like the reference
         half = inter_dim // 2
         self._freqs_cpu = torch.exp(-math.log(10000) * torch.arange(half, dtype=torch.float32) / half)
+        self.compute_dtype = "fp32"   # "bf16": bf16 operands / fp32 accumulation in the 3x3x3 convs (inference only)
         self._prep = None        # packed weights / banks, keyed on parameter versions
         self._cond = None        # pinned step-invariant tensors of the current image set
 
@@ -196,19 +197,40 @@ class WavBEST(nn.Module):
         state_dict = {k: v for k, v in state_dict.items() if not k.startswith("clip_text_model.")}
         return super().load_state_dict(state_dict, strict=strict, **kw)
 
+    def set_compute_dtype(self, dtype):
+        """"fp32" (default, exact-fp32 MFMA) or "bf16": the 3x3x3 convolutions of the no-grad forward round their
+        operands to bf16 and accumulate in fp32 ("bf16 compute / fp32 accumulate").
+        Activations, the embedding MLPs, wavelets, 1x1x1 convs, the sampler and all of training stay fp32."""
+        dtype = {"float32": "fp32", "bfloat16": "bf16", torch.float32: "fp32", torch.bfloat16: "bf16"}.get(dtype, dtype)
+        if dtype not in ("fp32", "bf16"):
+            raise ValueError(f"compute dtype must be 'fp32' or 'bf16', got {dtype!r}")
+        if dtype != self.compute_dtype:
+            self.compute_dtype = dtype
+            self._prep = None
+            self._cond = None
+        return self
+
     # ---- weight-dependent preparation (redone when any parameter changes) --------------------------
     def _prepare(self):
         params = list(self.parameters())
-        key = (tuple(p._version for p in params), tuple(p.data_ptr() for p in params))
+        key = (tuple(p._version for p in params), tuple(p.data_ptr() for p in params), self.compute_dtype)
         if self._prep is not None and self._prep["key"] == key:
             return self._prep
         dev = params[0].device
         if dev.type != "cuda":
             raise RuntimeError("tmdiff_amd.WavBEST runs on the HIP kernels only: move the module to a GPU (.cuda())")
-        prep = {"key": key, "w": {}, "freqs": self._freqs_cpu.to(dev)}
+        prep = {"key": key, "w": {}, "bf16": set(), "freqs": self._freqs_cpu.to(dev)}
         for name, m in self.named_modules():
             if isinstance(m, nn.Conv3d) and m.in_channels > 1 and m.out_channels > 1:
-                prep["w"][name] = ops.pack_conv_weight(m.weight.detach().float().contiguous(), groups=m.groups)
+                w = m.weight.detach().float().contiguous()
+                # every multi-segment input of the network splits into equal segments (3 x c): check their size too
+                seg = [m.in_channels // 3] if m.in_channels % 3 == 0 else None
+                if self.compute_dtype == "bf16" and ops.bf16_conv_supported(m.out_channels, m.in_channels,
+                                                                            m.kernel_size[0], m.groups, seg):
+                    prep["w"][name] = ops.pack_conv_weight_bf16(w, groups=m.groups)
+                    prep["bf16"].add(name)
+                else:
+                    prep["w"][name] = ops.pack_conv_weight(w, groups=m.groups)
         shift, scale = [], []
         for name, m in self.named_modules():
             if isinstance(m, ResBlockModulateBEST):
@@ -231,6 +253,7 @@ class WavBEST(nn.Module):
     def _conv(self, P, name, segs, use_bias=True, bias_scale=1.0, **kw):
         m = self.get_submodule(name)
         return ops.conv3d(segs, P["w"][name], m.out_channels, m.kernel_size[0], groups=m.groups,
+                          math="bf16" if name in P["bf16"] else "fp32",
                           bias=m.bias.detach() if (use_bias and m.bias is not None) else None,
                           bias_scale=bias_scale, **kw)
 

@@ -2,9 +2,10 @@
 
 Reads the same option keys as the reference -- ``opt['model']['unet']['channel_multiplier']``,
 ``opt['model']['diffusion']['loss_type']``, ``opt['model']['init_type']``, ``opt['phase']``,
-``opt['gpu_ids']``, ``opt['distributed']`` -- plus one optional key of ours,
+``opt['gpu_ids']``, ``opt['distributed']`` -- plus two optional keys of ours,
 ``opt['model']['text_embeddings']`` (dict or path; default: fixed synthetic vectors, because the CLIP
-weights are not shipped).  Missing keys behave like the reference's ``NoneDict`` (-> None).
+weights are not shipped) and ``opt['model']['compute_dtype']`` ("fp32" default | "bf16": bf16-operand convs for
+inference).  Missing keys behave like the reference's ``NoneDict`` (-> None).
 
 Multi-GPU: the reference wraps the module in single-process ``nn.DataParallel`` (:88-91).  Here the
 unit of parallelism is one process per GPU (``tmdiff_amd.dist``), so with ``distributed`` set the
@@ -85,6 +86,8 @@ def define_General(opt):
     model_opt = opt["model"]
     model = unet.WavBEST(channels=_get(model_opt, "unet", "channel_multiplier"),
                          text_embeddings=_get(model_opt, "text_embeddings"))
+    if _get(model_opt, "compute_dtype") is not None:      # ours, optional: "fp32" (default) | "bf16" (inference convs)
+        model.set_compute_dtype(_get(model_opt, "compute_dtype"))
     netG = diffusion.GeneralDiffusion(denoise_fn=model, loss_type=_get(model_opt, "diffusion", "loss_type"))
     if _get(opt, "phase") == "train":
         init_weights(netG, init_type=_get(model_opt, "init_type"))

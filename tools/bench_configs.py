@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""Secondary measurements for DESIGN.md (not the headline bench): BASELINE configs 1, 3 (in fp32) and the
+"""Secondary measurements for DESIGN.md (not the headline bench): BASELINE configs 1, 3 (fp32 and bf16 compute) and the
 finetune step of config 4 on ONE GPU.  Prints one line per config."""
 import os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -32,15 +32,21 @@ if "c1" in which:   # single 8-ch 64x64 tile, 50-step DDPM
     net.end_condition_cache()
     print(f"config1: same step as a captured HIP graph: {dt / 50 * 1e3:.2f} ms/step -> {50 / dt:.1f} denoise-steps/s", flush=True)
     del net, diff
-if "c3" in which:   # WorldView-3 config: ch 64-512, 8-ch 256x256, DPM-Solver 20 steps (21 NFE) -- fp32 here
+if "c3" in which:   # WorldView-3 config: ch 64-512, 8-ch 256x256, DPM-Solver 20 steps (21 NFE), fp32 and bf16 compute
     net = fill_weights_(WavBEST(channels=[64, 128, 256, 512])).cuda().eval()
     diff = GeneralDiffusion(net, "l1").cuda(); diff.set_new_noise_schedule({"schedule": "cosine", "n_timestep": 1000}, "cuda")
     d = synthetic_tile_batch(3407, 1, 8, 256, device="cuda")
-    diff.sample_by_dpmsolver(d, "WV3", steps=20)
-    dt, out = sync_time(lambda: diff.sample_by_dpmsolver(d, "WV3", steps=20))
     gf = 172.39 * 4.0 * 16      # ch x2 -> ~4x, 256x256 -> 16x
-    print(f"config3 (fp32): B=1 8x256x256 ch 64-512, DPM-Solver++ 20 steps (21 NFE): {dt:.3f} s -> {21 / dt:.2f} NFE/s, "
-          f"~{(62.82 + 109.57 * 21) / 172.39 * gf / dt / 1e3:.1f} TFLOP/s executed", flush=True)
+    outs = {}
+    for mode in ("fp32", "bf16"):
+        net.set_compute_dtype(mode)
+        torch.manual_seed(1); diff.sample_by_dpmsolver(d, "WV3", steps=20)
+        torch.manual_seed(1)
+        dt, outs[mode] = sync_time(lambda: diff.sample_by_dpmsolver(d, "WV3", steps=20))
+        print(f"config3 ({mode}): B=1 8x256x256 ch 64-512, DPM-Solver++ 20 steps (21 NFE): {dt:.3f} s -> {21 / dt:.2f} NFE/s, "
+              f"~{(62.82 + 109.57 * 21) / 172.39 * gf / dt / 1e3:.1f} TFLOP/s executed", flush=True)
+    from tmdiff_amd.util import psnr
+    print(f"config3: PSNR(bf16, fp32) = {psnr(outs['bf16'], outs['fp32']):.1f} dB", flush=True)
     del net, diff
 if "c4" in which:   # finetune step, local batch 8, ch 32-256, AdamW, dropout on
     net = fill_weights_(WavBEST(channels=[32, 64, 128, 256])).cuda().train()
