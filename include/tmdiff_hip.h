@@ -86,11 +86,16 @@ int tmdiff_conv3d_fwd(const tmdiff_conv3d_desc* d, tmdiff_stream_t stream);
  * (tmdiff_conv3d_packed_bf16_bytes bytes; 0 = shape not supported).
  * Supported: ksize 3, Cin/groups and every segment a multiple of 8 channels, Cout/groups a multiple of 32, no
  * in_mask; anything else returns TMDIFF_E_UNSUPPORTED and the caller keeps using tmdiff_conv3d_fwd (forward only:
- * training runs in fp32). */
+ * training runs in fp32).
+ * workspace NULL: one fused kernel (prologue evaluated while staging, per channel tile).  workspace of
+ * tmdiff_conv3d_bf16_workspace_bytes(d) bytes: two kernels -- the prologue output is packed to bf16 once
+ * ([B][Cin/8][N*H*W] units of 8 channels), then a convolution whose operands go HBM -> LDS directly
+ * (global_load_lds) -- the better choice when several channel tiles share the input.  Same results bit for bit. */
 size_t tmdiff_conv3d_packed_bf16_bytes(int32_t Cout, int32_t Cin, int32_t groups);
 int tmdiff_conv3d_pack_weights_bf16(const float* w, void* packed, int32_t Cout, int32_t Cin, int32_t groups,
                                     tmdiff_stream_t stream);
-int tmdiff_conv3d_fwd_bf16(const tmdiff_conv3d_desc* d, tmdiff_stream_t stream);
+size_t tmdiff_conv3d_bf16_workspace_bytes(const tmdiff_conv3d_desc* d);
+int tmdiff_conv3d_fwd_bf16(const tmdiff_conv3d_desc* d, void* workspace, tmdiff_stream_t stream);
 
 /* ---- backward of the fused convolution (finetune path) ----------------------------------
  * With x' = prologue(x) and y = (conv(x', w) + bias_scale*bias + residual) * out_scale, and g = dL/dy * out_scale:

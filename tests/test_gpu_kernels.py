@@ -389,10 +389,12 @@ def test_conv3d_bf16_operands_fp32_accumulate(ops, case):
         t *= 0.5
     assert ops.bf16_conv_supported(cout, cin, 3, g, case["segs"])
     wp = ops.pack_conv_weight_bf16(cu(w), groups=g)
-    y = ops.conv3d([cu(s) for s in segs], wp, cout, 3, groups=g, math="bf16", bias=cu(bias) if bias is not None else None,
-                   bias_scale=2.0, in_shift=cu(shift) if shift is not None else None,
-                   in_scale=cu(scale) if scale is not None else None, in_act=case["act"],
-                   residual=cu(res) if res is not None else None, out_scale=0.5)
+    kw = dict(groups=g, math="bf16", bias=cu(bias) if bias is not None else None, bias_scale=2.0,
+              in_shift=cu(shift) if shift is not None else None, in_scale=cu(scale) if scale is not None else None,
+              in_act=case["act"], residual=cu(res) if res is not None else None, out_scale=0.5)
+    y = ops.conv3d([cu(s) for s in segs], wp, cout, 3, pack_input=False, **kw)
+    y2 = ops.conv3d([cu(s) for s in segs], wp, cout, 3, pack_input=True, **kw)
+    assert torch.equal(y, y2), "fused and packed-input variants must agree bit for bit"
     # the prologue runs in fp32 on the GPU (fast exp), so a value may round to the neighbouring bf16: allow a few 1e-4
     assert_close(y.cpu(), rounded.float(), 2e-3, 3e-4, "bf16 conv vs bf16-rounded fp64 conv")
     assert_close(y.cpu(), exact.float(), 3e-2, 1e-2, "bf16 conv vs exact conv (bf16 tolerance)")

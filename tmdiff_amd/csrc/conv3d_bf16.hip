@@ -21,8 +21,13 @@
 // registers go through the prologue into LDS (two barriers per chunk).  The other workgroups on the CU cover
 // that hand-off.
 #include <cstdint>
+#include <cstdlib>
 
 #include "common.h"
+
+#ifndef TMDIFF_BF16_DEBUG
+#define TMDIFF_BF16_DEBUG 0  // experiment switches (results wrong): 1 = no prologue math, 2 = no MFMAs, 4 = no in-loop loads
+#endif
 
 namespace {
 
@@ -53,6 +58,10 @@ __device__ __forceinline__ unsigned xcd_remap(unsigned bid, unsigned nwg) {
   return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + k;
 }
 
+// stand-ins for absent shift / scale rows, so that the hand-off has no branches
+__device__ const float kZeros[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+__device__ const float kOnes[8] = {1.f, 1.f, 1.f, 1.f, 1.f, 1.f, 1.f, 1.f};
+
 constexpr int TN = 4;    // bands per workgroup = waves
 constexpr int RS = 24;   // LDS row stride in 16-byte units
 constexpr int TAPS2 = 28;
@@ -68,7 +77,44 @@ struct XLayout {
   }
 };
 
-template <int NS, int MSUB, int TH, int TW>
+// Epilogue shared by both kernels: D layout col = lane&31 (position), row (r&3) + 8*(r>>2) + 4*kg (channel);
+// bias_v[m] holds (in lane l31) the scaled bias of channel co0 + m*32 + l31.
+template <int NS, int MSUB, int TW>
+__device__ __forceinline__ void store_tile(const BfArgs& a, f32x16 (&acc)[NS][MSUB], const float (&bias_v)[MSUB], int b,
+                                           int g, int co0, int n0, int h0, int w0, int wv, int l31, int kg, long plane) {
+#pragma unroll
+  for (int m = 0; m < MSUB; ++m) {
+    float bias_r[16];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int row = (r & 3) + 8 * (r >> 2);
+      const float b0 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(bias_v[m]), row));
+      const float b1 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(bias_v[m]), row + 4));
+      bias_r[r] = kg ? b1 : b0;
+    }
+#pragma unroll
+    for (int s = 0; s < NS; ++s) {
+      constexpr int per_row = TW / 8;
+      const int n = n0 + wv, h = h0 + (s / per_row) * 4 + (l31 >> 3), w = w0 + (s % per_row) * 8 + (l31 & 7);
+      const bool pok = n < a.N && h < a.H && w < a.W;
+      const long sp = pok ? ((long)n * a.H + h) * a.W + w : 0;
+      const long obase = ((long)b * a.Cout + g * a.cout_g + co0 + m * 32 + 4 * kg) * plane + sp;
+      float res[16];
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int row = (r & 3) + 8 * (r >> 2);
+        res[r] = (a.residual && pok) ? a.residual[obase + row * plane] : 0.f;
+      }
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int row = (r & 3) + 8 * (r >> 2);
+        if (pok) a.y[obase + row * plane] = (acc[s][m][r] + bias_r[r] + res[r]) * a.out_scale;
+      }
+    }
+  }
+}
+
+template <int NS, int MSUB, int TH, int TW, bool ACT>
 __global__ void __launch_bounds__(256, 2) conv3d_bf16_kernel(const BfArgs a) {
   using XL = XLayout<TH, TW>;
   constexpr int CO = 32 * MSUB;
@@ -172,19 +218,18 @@ __global__ void __launch_bounds__(256, 2) conv3d_bf16_kernel(const BfArgs a) {
   };
   auto stage_chunk = [&](int c) __attribute__((always_inline)) {
     const int cg = g * a.cin_g + c * 8;
+    const float* shp = a.in_shift ? a.in_shift + (long)b * a.shift_stride + cg : kZeros;
+    const float* scp = a.in_scale ? a.in_scale + (long)b * a.scale_stride + cg : kOnes;
     float sh[8], sc[8];
 #pragma unroll
-    for (int j = 0; j < 8; ++j) {
-      sh[j] = a.in_shift ? a.in_shift[(long)b * a.shift_stride + cg + j] : 0.f;
-      sc[j] = a.in_scale ? a.in_scale[(long)b * a.scale_stride + cg + j] : 1.f;
-    }
+    for (int j = 0; j < 8; ++j) sh[j] = shp[j], sc[j] = scp[j];
 #pragma unroll
     for (int i = 0; i < XI; ++i) {
       union { bf16x8 h; uint4 u; } pk;
 #pragma unroll
       for (int j = 0; j < 8; ++j) {
         float v = xr[i][j] + sh[j];
-        if (a.in_act) v = tmdiff::silu_f(v);
+        if constexpr (ACT && !(TMDIFF_BF16_DEBUG & 1)) v = tmdiff::silu_f(v);
         v *= sc[j];
         pk.h[j] = (__bf16)(inb[i] ? v : 0.f);
       }
@@ -198,7 +243,7 @@ __global__ void __launch_bounds__(256, 2) conv3d_bf16_kernel(const BfArgs a) {
   for (int c = 0; c < nchunks; ++c) {
     stage_chunk(c);
     __syncthreads();
-    if (c + 1 < nchunks) load_chunk(c + 1);
+    if (c + 1 < nchunks && !(TMDIFF_BF16_DEBUG & 4)) load_chunk(c + 1);
 #pragma unroll
     for (int p = 0; p < TAPS2 / 2; ++p) {
       union { bf16x8 h; uint4 u; } av[MSUB], bv[NS];
@@ -213,42 +258,200 @@ __global__ void __launch_bounds__(256, 2) conv3d_bf16_kernel(const BfArgs a) {
       for (int s = 0; s < NS; ++s)
 #pragma unroll
         for (int m = 0; m < MSUB; ++m)
-          acc[s][m] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av[m].h, bv[s].h, acc[s][m], 0, 0, 0);
+          if (!(TMDIFF_BF16_DEBUG & 2) || c == 0)
+            acc[s][m] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av[m].h, bv[s].h, acc[s][m], 0, 0, 0);
     }
     __syncthreads();
   }
 
-  // ---- epilogue: D layout col = lane&31 (position), row (r&3) + 8*(r>>2) + 4*kg (channel) ---------------------
+  store_tile<NS, MSUB, TW>(a, acc, bias_v, b, g, co0, n0, h0, w0, wv, l31, kg, plane);
+}
+
+// ---- two-kernel variant: prologue + bf16 packing once, then a staging-free convolution -----------------------
+// pack_x: xp[b][chunk][pos] (one 16-byte unit = 8 channels, bf16) = bf16(prologue(x[b][chunk*8 .. +7][pos])).
+// The convolution below then moves BOTH operands HBM/L2 -> LDS with global_load_lds_dwordx4 (no registers, no
+// VALU work) into two LDS stages and spends its issue slots on ds_read_b128 + MFMA only.  Worth it when the
+// input is reused by several channel tiles (the fused kernel re-evaluates the prologue per tile and halo).
+__device__ const uint4 kZeroUnit = {0u, 0u, 0u, 0u};  // source of the zero padding
+
+// One wave-wide piece (64 x 16 bytes): global src (per lane) -> LDS dst + lane*16 (dst is wave-uniform, via M0).
+__device__ __forceinline__ void dma_piece(const uint4* src, uint4* dst) {
+#if defined(__HIP_DEVICE_COMPILE__)  // the builtin exists in the device pass only
+  __builtin_amdgcn_global_load_lds(src, dst, 16, 0, 0);
+#endif
+}
+
+template <bool ACT>
+__global__ void __launch_bounds__(256) pack_x_bf16_kernel(const BfArgs a, uint4* __restrict__ xp) {
+  const long plane = (long)a.N * a.H * a.W;
+  const int nch = a.Cin / 8;
+  const int bc = blockIdx.y;  // b * nch + chunk
+  const int b = bc / nch, ch = bc % nch;
+  const int cg = ch * 8;
+  const float* src;
+  int cl, segc;
+  if (cg < a.seg_c[0]) src = a.seg_x[0], cl = cg, segc = a.seg_c[0];
+  else if (cg < a.seg_c[0] + a.seg_c[1]) src = a.seg_x[1], cl = cg - a.seg_c[0], segc = a.seg_c[1];
+  else src = a.seg_x[2], cl = cg - a.seg_c[0] - a.seg_c[1], segc = a.seg_c[2];
+  const float* base = src + ((long)b * segc + cl) * plane;
+  const float* shp = a.in_shift ? a.in_shift + (long)b * a.shift_stride + cg : kZeros;
+  const float* scp = a.in_scale ? a.in_scale + (long)b * a.scale_stride + cg : kOnes;
+  float sh[8], sc[8];
 #pragma unroll
-  for (int m = 0; m < MSUB; ++m) {
-    float bias_r[16];
+  for (int j = 0; j < 8; ++j) sh[j] = shp[j], sc[j] = scp[j];
+  for (long pos = blockIdx.x * 256L + threadIdx.x; pos < plane; pos += 256L * gridDim.x) {
+    float v[8];
 #pragma unroll
-    for (int r = 0; r < 16; ++r) {
-      const int row = (r & 3) + 8 * (r >> 2);
-      const float b0 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(bias_v[m]), row));
-      const float b1 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(bias_v[m]), row + 4));
-      bias_r[r] = kg ? b1 : b0;
+    for (int j = 0; j < 8; ++j) v[j] = base[pos + j * plane];
+    union { bf16x8 h; uint4 u; } pk;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      float t = v[j] + sh[j];
+      if constexpr (ACT) t = tmdiff::silu_f(t);
+      pk.h[j] = (__bf16)(t * sc[j]);
     }
+    xp[(long)bc * plane + pos] = pk.u;
+  }
+}
+
+template <int NS, int MSUB, int TH, int TW>
+__global__ void __launch_bounds__(256, 2) conv3d_bf16_dma_kernel(const BfArgs a, const uint4* __restrict__ xp) {
+  using XL = XLayout<TH, TW>;
+  constexpr int CO = 32 * MSUB;
+  constexpr int HH = XL::HH, HW = XL::HW;
+  constexpr int XINST = (XL::UNITS + 63) / 64;   // wave-wide 1 KiB pieces of the x image
+  constexpr int WINST = TAPS2 * CO / 64;         // ... of the weight slab
+  constexpr int XU = XINST * 64;
+  constexpr int XK = (XINST + 3) / 4, WK = (WINST + 3) / 4;  // pieces per wave
+  constexpr int STAGE = XU + TAPS2 * CO;
+  static_assert(TH * TW == 32 * NS, "a wave covers one band plane = NS tiles of 4x8 positions");
+  __shared__ uint4 st0[STAGE];
+  __shared__ uint4 st1[STAGE];
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63, wv = tid >> 6;
+  const int l31 = lane & 31, kg = lane >> 5;
+
+  unsigned id = xcd_remap(blockIdx.x, a.total_blocks);
+  const int co_tile = __builtin_amdgcn_readfirstlane(id % a.tiles_co); id /= a.tiles_co;
+  const int tw_i = __builtin_amdgcn_readfirstlane(id % a.tiles_w); id /= a.tiles_w;
+  const int th_i = __builtin_amdgcn_readfirstlane(id % a.tiles_h); id /= a.tiles_h;
+  const int tn_i = __builtin_amdgcn_readfirstlane(id % a.tiles_n); id /= a.tiles_n;
+  const int g = __builtin_amdgcn_readfirstlane(id % a.groups);
+  const int b = __builtin_amdgcn_readfirstlane(id / a.groups);
+  const int n0 = tn_i * TN, h0 = th_i * TH, w0 = tw_i * TW;
+  const int co0 = co_tile * CO;
+  const long plane = (long)a.N * a.H * a.W;
+  const int nchunks = a.cin_g / 8;
+
+  // ---- DMA sources of this lane: x piece q = wv + 4k covers LDS units q*64 + lane ------------------------------
+  int xpos[XK];  // position offset inside a chunk plane, or -1 = zero unit (padding / layout filler)
 #pragma unroll
-    for (int s = 0; s < NS; ++s) {
-      constexpr int per_row = TW / 8;
-      const int n = n0 + wv, h = h0 + (s / per_row) * 4 + (l31 >> 3), w = w0 + (s % per_row) * 8 + (l31 & 7);
-      const bool pok = n < a.N && h < a.H && w < a.W;
-      const long sp = pok ? ((long)n * a.H + h) * a.W + w : 0;
-      const long obase = ((long)b * a.Cout + g * a.cout_g + co0 + m * 32 + 4 * kg) * plane + sp;
-      float res[16];
+  for (int k = 0; k < XK; ++k) {
+    const int u = (wv + 4 * k) * 64 + lane;
+    const int row = u / RS, col = u % RS;
+    int zz, yz, xz;
+    if constexpr (XL::ZPAIR) {
+      zz = 2 * (row / HH) + (col >= 12), yz = row % HH, xz = col >= 12 ? col - 12 : col;
+    } else {
+      zz = row / HH, yz = row % HH, xz = col;
+    }
+    const int n = n0 + zz - 1, h = h0 + yz - 1, w = w0 + xz - 1;
+    const bool ok = u < XL::UNITS && xz < HW && n >= 0 && n < a.N && h >= 0 && h < a.H && w >= 0 && w < a.W;
+    xpos[k] = ok ? (n * a.H + h) * a.W + w : -1;
+  }
+  const uint4* xg = xp + ((long)b * (a.Cin / 8) + (long)g * nchunks) * plane;
+  // weight piece q covers slab units q*64 + lane = tap-major [tap][CO]
+  int wsrc[WK];
 #pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const int row = (r & 3) + 8 * (r >> 2);
-        res[r] = (a.residual && pok) ? a.residual[obase + row * plane] : 0.f;
+  for (int k = 0; k < WK; ++k) {
+    const int u = (wv + 4 * k) * 64 + lane;
+    wsrc[k] = (u / CO) * a.cout_g + co0 + u % CO;
+  }
+  const uint4* wg = a.wp + (long)g * nchunks * TAPS2 * a.cout_g;
+
+  auto issue = [&](int c, uint4* st) __attribute__((always_inline)) {
+    const uint4* xc = xg + (long)c * plane;
+#pragma unroll
+    for (int k = 0; k < XK; ++k) {
+      const int q = wv + 4 * k;
+      if (XINST % 4 == 0 || q < XINST) {
+        const uint4* src = xpos[k] >= 0 ? xc + xpos[k] : &kZeroUnit;
+        dma_piece(src, st + q * 64);
+      }
+    }
+    const uint4* wc = wg + (long)c * TAPS2 * a.cout_g;
+#pragma unroll
+    for (int k = 0; k < WK; ++k) {
+      const int q = wv + 4 * k;
+      if (WINST % 4 == 0 || q < WINST) dma_piece(wc + wsrc[k], st + XU + q * 64);
+    }
+  };
+
+  // ---- operand addresses (16-byte units inside a stage) ---------------------------------------------------------
+  const int lane_pos = (l31 >> 3) * RS + (l31 & 7);
+  int baddr[TAPS2 / 2];
+#pragma unroll
+  for (int p = 0; p < TAPS2 / 2; ++p) {
+    const int t0 = 2 * p, t1 = 2 * p + 1 < 27 ? 2 * p + 1 : 26;
+    const int u0 = XL::unit(wv + t0 / 9, (t0 / 3) % 3, t0 % 3);
+    const int u1 = XL::unit(wv + t1 / 9, (t1 / 3) % 3, t1 % 3);
+    baddr[p] = lane_pos + (kg ? u1 : u0);
+  }
+  const int aaddr = XU + kg * CO + l31;
+
+  float bias_v[MSUB];
+#pragma unroll
+  for (int m = 0; m < MSUB; ++m) bias_v[m] = a.bias ? a.bias[g * a.cout_g + co0 + m * 32 + l31] * a.bias_scale : 0.f;
+
+  f32x16 acc[NS][MSUB];
+#pragma unroll
+  for (int s = 0; s < NS; ++s)
+#pragma unroll
+    for (int m = 0; m < MSUB; ++m)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[s][m][r] = 0.f;
+
+  auto mfma_chunk = [&](const uint4* st) __attribute__((always_inline)) {
+    constexpr int per_row = TW / 8;
+    union Frag { bf16x8 h; uint4 u; };
+    Frag av[2][MSUB], bv[2][NS];
+#pragma unroll
+    for (int m = 0; m < MSUB; ++m) av[0][m].u = st[aaddr + m * 32];
+#pragma unroll
+    for (int s = 0; s < NS; ++s) bv[0][s].u = st[baddr[0] + (s / per_row) * 4 * RS + (s % per_row) * 8];
+#pragma unroll
+    for (int p = 0; p < TAPS2 / 2; ++p) {
+      if (p + 1 < TAPS2 / 2) {
+#pragma unroll
+        for (int m = 0; m < MSUB; ++m) av[(p + 1) & 1][m].u = st[aaddr + 2 * (p + 1) * CO + m * 32];
+#pragma unroll
+        for (int s = 0; s < NS; ++s)
+          bv[(p + 1) & 1][s].u = st[baddr[p + 1] + (s / per_row) * 4 * RS + (s % per_row) * 8];
       }
 #pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const int row = (r & 3) + 8 * (r >> 2);
-        if (pok) a.y[obase + row * plane] = (acc[s][m][r] + bias_r[r] + res[r]) * a.out_scale;
-      }
+      for (int s = 0; s < NS; ++s)
+#pragma unroll
+        for (int m = 0; m < MSUB; ++m)
+          acc[s][m] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av[p & 1][m].h, bv[p & 1][s].h, acc[s][m], 0, 0, 0);
+    }
+  };
+
+  // two stages, one barrier per chunk: while chunk c is multiplied out of one stage the pieces of chunk c+1 land in
+  // the other; the barrier at the end of a chunk says "everyone has read this stage and my pieces have landed".
+  issue(0, st0);
+  __syncthreads();
+  for (int c = 0; c < nchunks; c += 2) {
+    if (c + 1 < nchunks) issue(c + 1, st1);
+    mfma_chunk(st0);
+    __syncthreads();
+    if (c + 1 < nchunks) {
+      if (c + 2 < nchunks) issue(c + 2, st0);
+      mfma_chunk(st1);
+      __syncthreads();
     }
   }
+  store_tile<NS, MSUB, TW>(a, acc, bias_v, b, g, co0, n0, h0, w0, wv, l31, kg, plane);
 }
 
 // packed[g][chunk][tap 0..27][co][8 ci] (bf16, RNE) <- w[g*cout_g + co][chunk*8 + ci][tap]; tap 27 = 0
@@ -278,11 +481,39 @@ int launch(BfArgs& a, hipStream_t st) {
   const long blocks = (long)a.B * a.groups * a.tiles_n * a.tiles_h * a.tiles_w * a.tiles_co;
   if (blocks <= 0 || blocks > 0x7fffffffL) return tmdiff::fail(TMDIFF_E_INVALID, "conv3d_bf16: grid of %ld blocks", blocks);
   a.total_blocks = (unsigned)blocks;
-  conv3d_bf16_kernel<NS, MSUB, TH, TW><<<(unsigned)blocks, 256, 0, st>>>(a);
+  if (a.in_act)
+    conv3d_bf16_kernel<NS, MSUB, TH, TW, true><<<(unsigned)blocks, 256, 0, st>>>(a);
+  else
+    conv3d_bf16_kernel<NS, MSUB, TH, TW, false><<<(unsigned)blocks, 256, 0, st>>>(a);
   return tmdiff::check_launch("conv3d_fwd_bf16");
 }
 
+template <int NS, int MSUB, int TH, int TW>
+int launch_dma(BfArgs& a, uint4* xp, hipStream_t st) {
+  constexpr int CO = 32 * MSUB;
+  const long plane = (long)a.N * a.H * a.W;
+  long pb = (plane + 255) / 256;
+  if (pb > 1024) pb = 1024;
+  const dim3 pgrid((unsigned)pb, (unsigned)(a.B * (a.Cin / 8)));
+  if (a.in_act) pack_x_bf16_kernel<true><<<pgrid, 256, 0, st>>>(a, xp);
+  else pack_x_bf16_kernel<false><<<pgrid, 256, 0, st>>>(a, xp);
+  a.tiles_n = (a.N + TN - 1) / TN;
+  a.tiles_h = (a.H + TH - 1) / TH;
+  a.tiles_w = (a.W + TW - 1) / TW;
+  a.tiles_co = a.cout_g / CO;
+  const long blocks = (long)a.B * a.groups * a.tiles_n * a.tiles_h * a.tiles_w * a.tiles_co;
+  if (blocks <= 0 || blocks > 0x7fffffffL) return tmdiff::fail(TMDIFF_E_INVALID, "conv3d_bf16: grid of %ld blocks", blocks);
+  a.total_blocks = (unsigned)blocks;
+  conv3d_bf16_dma_kernel<NS, MSUB, TH, TW><<<(unsigned)blocks, 256, 0, st>>>(a, xp);
+  return tmdiff::check_launch("conv3d_fwd_bf16 (packed input)");
+}
+
 }  // namespace
+
+extern "C" size_t tmdiff_conv3d_bf16_workspace_bytes(const tmdiff_conv3d_desc* d) {
+  if (!d || d->B <= 0 || d->Cin <= 0 || d->Cin % 8) return 0;
+  return (size_t)d->B * d->Cin * d->N * d->H * d->W * 2;
+}
 
 extern "C" size_t tmdiff_conv3d_packed_bf16_bytes(int32_t Cout, int32_t Cin, int32_t groups) {
   if (groups < 1 || Cout <= 0 || Cin <= 0 || Cin % groups || (Cin / groups) % 8) return 0;
@@ -304,7 +535,7 @@ extern "C" int tmdiff_conv3d_pack_weights_bf16(const float* w, void* packed, int
   return check_launch("conv3d_pack_weights_bf16");
 }
 
-extern "C" int tmdiff_conv3d_fwd_bf16(const tmdiff_conv3d_desc* d, tmdiff_stream_t stream) {
+extern "C" int tmdiff_conv3d_fwd_bf16(const tmdiff_conv3d_desc* d, void* workspace, tmdiff_stream_t stream) {
   using namespace tmdiff;
   TMDIFF_REQUIRE(d != nullptr, "conv3d_fwd_bf16: NULL descriptor");
   TMDIFF_REQUIRE(d->B >= 0 && d->N > 0 && d->H > 0 && d->W > 0, "conv3d_fwd_bf16: bad extents B=%d N=%d H=%d W=%d", d->B,
@@ -347,6 +578,17 @@ extern "C" int tmdiff_conv3d_fwd_bf16(const tmdiff_conv3d_desc* d, tmdiff_stream
   a.scale_stride = d->in_scale_stride > 0 ? d->in_scale_stride : (d->in_scale_stride < 0 ? 0 : d->Cin);
   a.residual = d->residual; a.out_scale = d->out_scale; a.y = d->y;
   hipStream_t st = as_stream(stream);
-  if (cout_g % 64 == 0) return launch<2, 2, 8, 8>(a, st);
+  if (workspace) {  // two-kernel variant: pack the prologue output once, then the staging-free kernel
+    TMDIFF_REQUIRE(aligned16(workspace), "conv3d_fwd_bf16: workspace must be 16-byte aligned");
+    TMDIFF_REQUIRE(d->B * (long)(d->Cin / 8) <= 65535, "conv3d_fwd_bf16: B*Cin/8 = %ld exceeds the pack grid", d->B * (long)(d->Cin / 8));
+    uint4* xp = static_cast<uint4*>(workspace);
+    if (cout_g % 64 == 0) return launch_dma<2, 2, 8, 8>(a, xp, st);
+    return d->W >= 16 ? launch_dma<4, 1, 8, 16>(a, xp, st) : launch_dma<2, 1, 8, 8>(a, xp, st);
+  }
+  if (cout_g % 64 == 0) {
+    static const int wide = getenv("TMDIFF_BF16_WIDE") ? atoi(getenv("TMDIFF_BF16_WIDE")) : 0;
+    if (wide && d->W >= 16) return launch<4, 2, 8, 16>(a, st);
+    return launch<2, 2, 8, 8>(a, st);
+  }
   return d->W >= 16 ? launch<4, 1, 8, 16>(a, st) : launch<2, 1, 8, 8>(a, st);
 }

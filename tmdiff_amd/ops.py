@@ -5,6 +5,7 @@ these ops runs in libtmdiff_hip.so.  All wrappers require CUDA(HIP) fp32 contigu
 tensors and raise otherwise -- there is no eager fallback.
 """
 import ctypes as C
+import os
 
 import torch
 
@@ -106,16 +107,31 @@ class ConvTimer:
 TIMER = None      # set to a ConvTimer() to time every conv launch
 
 
-def conv3d(segs, w_packed, cout, ksize, out=None, math="fp32", **kw):
+_WS = {}     # device index -> grow-only scratch tensor (bf16-packed conv inputs); reused launch after launch on a stream
+_BF16_PACK = os.environ.get("TMDIFF_BF16_PACK", "auto")   # experiments: "0" = fused kernel, "1"/"auto" = packed input
+
+
+def _workspace(device, nbytes):
+    ws = _WS.get(device.index)
+    if ws is None or ws.numel() < nbytes:
+        ws = _WS[device.index] = torch.empty(nbytes, device=device, dtype=torch.uint8)
+    return ws
+
+
+def conv3d(segs, w_packed, cout, ksize, out=None, math="fp32", pack_input=None, **kw):
     """math="fp32": exact-fp32 MFMA kernel (w_packed from pack_conv_weight); "bf16": bf16 operands / fp32
-    accumulation (w_packed from pack_conv_weight_bf16)."""
+    accumulation (w_packed from pack_conv_weight_bf16).  pack_input (bf16 only): True = pack the prologue output to
+    bf16 once and run the staging-free kernel (default), False = one fused kernel."""
     b, _, n, h, w = segs[0].shape
     y = out if out is not None else torch.empty(b, cout, n, h, w, device=segs[0].device, dtype=torch.float32)
     d = make_conv_desc(segs, w_packed, cout, ksize, y, **kw)
     if math == "bf16":
         if w_packed.dtype != torch.int16:
             raise TypeError("conv3d(math='bf16') needs weights from pack_conv_weight_bf16")
-        fwd, what = lib.tmdiff_conv3d_fwd_bf16, "conv3d_fwd_bf16"
+        if pack_input is None:
+            pack_input = {"0": False, "1": True}.get(_BF16_PACK, True)   # measured: the two-kernel variant wins on every production layer
+        ws = _workspace(y.device, lib.tmdiff_conv3d_bf16_workspace_bytes(C.byref(d))).data_ptr() if pack_input else None
+        fwd, what = (lambda dd, st: lib.tmdiff_conv3d_fwd_bf16(dd, ws, st)), "conv3d_fwd_bf16"
     elif math == "fp32":
         if not isinstance(w_packed, int) and w_packed.dtype != torch.float32:
             raise TypeError("conv3d(math='fp32') needs weights from pack_conv_weight")

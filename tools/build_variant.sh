@@ -1,0 +1,14 @@
+#!/bin/bash
+# build_variant.sh NAME "-DFLAG=1 ..." : builds tools/lib_NAME.so (experiment library, load with TMDIFF_HIP_LIB)
+set -e
+cd "$(dirname "$0")/.."
+mkdir -p build/var_$1
+for f in tmdiff_amd/csrc/abi.cpp tmdiff_amd/csrc/*.hip; do
+  o=build/var_$1/$(basename $f).o
+  if [[ $f == *conv3d_bf16.hip || ! -f build/$(basename $f).o ]]; then
+    /opt/rocm/bin/hipcc $2 -O3 -std=c++17 -fPIC --offload-arch=gfx950 -Iinclude -Itmdiff_amd/csrc -x hip -c $f -o $o
+  else
+    cp build/$(basename $f).o $o
+  fi
+done
+/opt/rocm/bin/hipcc -shared -fPIC --offload-arch=gfx950 build/var_$1/*.o -o tools/lib_$1.so
