@@ -22,6 +22,7 @@
 // that hand-off.
 #include <cstdint>
 #include <cstdlib>
+#include <type_traits>
 
 #include "common.h"
 
@@ -52,6 +53,14 @@ struct BfArgs {
   int tiles_n, tiles_h, tiles_w, tiles_co;
   unsigned total_blocks;
 };
+
+template <int B, int E, class F>
+__device__ __forceinline__ void static_for(F&& f) {
+  if constexpr (B < E) {
+    f(std::integral_constant<int, B>{});
+    static_for<B + 1, E>(f);
+  }
+}
 
 __device__ __forceinline__ unsigned xcd_remap(unsigned bid, unsigned nwg) {
   const unsigned q = nwg / 8, r = nwg % 8, xcd = bid % 8, k = bid / 8;
@@ -416,25 +425,31 @@ __global__ void __launch_bounds__(256, 2) conv3d_bf16_dma_kernel(const BfArgs a,
     constexpr int per_row = TW / 8;
     union Frag { bf16x8 h; uint4 u; };
     Frag av[2][MSUB], bv[2][NS];
+    auto fetch = [&](auto pc) __attribute__((always_inline)) {
+      constexpr int p = decltype(pc)::value;
 #pragma unroll
-    for (int m = 0; m < MSUB; ++m) av[0][m].u = st[aaddr + m * 32];
+      for (int m = 0; m < MSUB; ++m) av[p & 1][m].u = st[aaddr + 2 * p * CO + m * 32];
 #pragma unroll
-    for (int s = 0; s < NS; ++s) bv[0][s].u = st[baddr[0] + (s / per_row) * 4 * RS + (s % per_row) * 8];
-#pragma unroll
-    for (int p = 0; p < TAPS2 / 2; ++p) {
-      if (p + 1 < TAPS2 / 2) {
-#pragma unroll
-        for (int m = 0; m < MSUB; ++m) av[(p + 1) & 1][m].u = st[aaddr + 2 * (p + 1) * CO + m * 32];
-#pragma unroll
-        for (int s = 0; s < NS; ++s)
-          bv[(p + 1) & 1][s].u = st[baddr[p + 1] + (s / per_row) * 4 * RS + (s % per_row) * 8];
-      }
-#pragma unroll
-      for (int s = 0; s < NS; ++s)
-#pragma unroll
-        for (int m = 0; m < MSUB; ++m)
-          acc[s][m] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av[p & 1][m].h, bv[p & 1][s].h, acc[s][m], 0, 0, 0);
-    }
+      for (int s = 0; s < NS; ++s) bv[p & 1][s].u = st[baddr[p] + (s / per_row) * 4 * RS + (s % per_row) * 8];
+    };
+    fetch(std::integral_constant<int, 0>{});
+    // The operands of tap pair p+1 are requested right after the first MFMA of pair p (pinned with sched_barrier: the
+    // scheduler otherwise sinks the reads behind the MFMAs).  The wait the compiler puts in front of pair p+1 is a
+    // full lgkmcnt(0), so the reads must be old by then: three MFMAs (~100 cycles) cover the LDS latency.
+    static_for<0, TAPS2 / 2>([&](auto pc) __attribute__((always_inline)) {
+      constexpr int p = decltype(pc)::value;
+      static_for<0, NS * MSUB>([&](auto jc) __attribute__((always_inline)) {
+        constexpr int j = decltype(jc)::value;
+        constexpr int sx = j / MSUB, m = j % MSUB;
+        acc[sx][m] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av[p & 1][m].h, bv[p & 1][sx].h, acc[sx][m], 0, 0, 0);
+        if constexpr (j == 0) {
+          __builtin_amdgcn_sched_barrier(0);
+          if constexpr (p + 1 < TAPS2 / 2) fetch(std::integral_constant<int, p + 1>{});
+          __builtin_amdgcn_sched_barrier(0);
+        }
+      });
+      __builtin_amdgcn_sched_barrier(0);
+    });
   };
 
   // two stages, one barrier per chunk: while chunk c is multiplied out of one stage the pieces of chunk c+1 land in
