@@ -84,16 +84,17 @@ int tmdiff_conv3d_fwd(const tmdiff_conv3d_desc* d, tmdiff_stream_t stream);
  * fp32 in memory.  The prologue result x' and the weights are rounded to bf16 (round to nearest even), products
  * are accumulated in fp32 on v_mfma_f32_32x32x16_bf16.  d->w_packed must come from tmdiff_conv3d_pack_weights_bf16
  * (tmdiff_conv3d_packed_bf16_bytes bytes; 0 = shape not supported).
- * Supported: ksize 3, Cin/groups and every segment a multiple of 8 channels, Cout/groups a multiple of 32, no
- * in_mask; anything else returns TMDIFF_E_UNSUPPORTED and the caller keeps using tmdiff_conv3d_fwd (forward only:
+ * Supported: Cin/groups a multiple of 8 (ksize 3) or 16 (ksize 1), every segment a multiple of 8 channels,
+ * Cout/groups a multiple of 32, no in_mask; anything else returns TMDIFF_E_UNSUPPORTED and the caller keeps using tmdiff_conv3d_fwd (forward only:
  * training runs in fp32).
  * workspace NULL: one fused kernel (prologue evaluated while staging, per channel tile).  workspace of
  * tmdiff_conv3d_bf16_workspace_bytes(d) bytes: two kernels -- the prologue output is packed to bf16 once
  * ([B][Cin/8][N*H*W] units of 8 channels), then a convolution whose operands go HBM -> LDS directly
- * (global_load_lds) -- the better choice when several channel tiles share the input.  Same results bit for bit. */
-size_t tmdiff_conv3d_packed_bf16_bytes(int32_t Cout, int32_t Cin, int32_t groups);
-int tmdiff_conv3d_pack_weights_bf16(const float* w, void* packed, int32_t Cout, int32_t Cin, int32_t groups,
-                                    tmdiff_stream_t stream);
+ * (global_load_lds) -- the better choice when several channel tiles share the input.  Same results bit for bit.
+ * ksize 1 is a bandwidth kernel without LDS (operands built in registers); it ignores the workspace. */
+size_t tmdiff_conv3d_packed_bf16_bytes(int32_t Cout, int32_t Cin, int32_t ksize, int32_t groups);
+int tmdiff_conv3d_pack_weights_bf16(const float* w, void* packed, int32_t Cout, int32_t Cin, int32_t ksize,
+                                    int32_t groups, tmdiff_stream_t stream);
 size_t tmdiff_conv3d_bf16_workspace_bytes(const tmdiff_conv3d_desc* d);
 int tmdiff_conv3d_fwd_bf16(const tmdiff_conv3d_desc* d, void* workspace, tmdiff_stream_t stream);
 

@@ -38,9 +38,9 @@ def test_unet_bf16_forward_within_bf16_tolerance(nets):
     hip.set_compute_dtype("bf16")
     try:
         P = hip._prepare()
-        n_k3 = sum(1 for _, m in hip.named_modules() if isinstance(m, torch.nn.Conv3d) and m.kernel_size[0] == 3
-                   and m.in_channels > 1)
-        assert len(P["bf16"]) == n_k3, "every 3x3x3 conv of the 32-256 network takes the bf16 kernel"
+        n_conv = sum(1 for _, m in hip.named_modules() if isinstance(m, torch.nn.Conv3d) and m.in_channels > 1
+                     and m.out_channels > 1)
+        assert len(P["bf16"]) == n_conv, "every MFMA conv (3x3x3 and 1x1x1) of the 32-256 network takes a bf16 kernel"
         y16 = hip(*args).cpu()
         # condition cache holds in bf16 mode too
         hip.begin_condition_cache(args[2], args[3], "WV3")

@@ -359,6 +359,11 @@ def _bf16_round(t):
     dict(B=1, segs=[16, 16, 16], cout=96, g=3, N=8, H=8, W=8, shift=False, scale=False, act=False, bias=True, res=False),
     dict(B=1, segs=[64], cout=128, g=1, N=8, H=20, W=12, shift=True, scale=True, act=True, bias=True, res=False),
     dict(B=3, segs=[32], cout=32, g=1, N=2, H=5, W=7, shift=False, scale=True, act=True, bias=False, res=False),
+    # 1x1x1 (bandwidth kernel): the three channel-tile configurations, ragged position counts, segments
+    dict(k=1, B=2, segs=[32], cout=128, g=1, N=4, H=9, W=7, shift=False, scale=False, act=False, bias=True, res=True),
+    dict(k=1, B=1, segs=[16, 16, 16], cout=64, g=1, N=8, H=16, W=16, shift=True, scale=True, act=True, bias=True, res=False),
+    dict(k=1, B=2, segs=[8, 24], cout=32, g=1, N=4, H=8, W=8, shift=False, scale=True, act=False, bias=False, res=False),
+    dict(k=1, B=1, segs=[48], cout=96, g=3, N=4, H=8, W=8, shift=False, scale=False, act=False, bias=True, res=False),
 ])
 def test_conv3d_bf16_operands_fp32_accumulate(ops, case):
     """bf16-compute conv (config 3 mode): equals an fp64 convolution of the bf16-rounded prologue output with the
@@ -367,7 +372,8 @@ def test_conv3d_bf16_operands_fp32_accumulate(ops, case):
     B, cin, cout, g = case["B"], sum(case["segs"]), case["cout"], case["g"]
     shp = (case["N"], case["H"], case["W"])
     segs = [torch.randn(B, c, *shp) for c in case["segs"]]
-    w = torch.randn(cout, cin // g, 3, 3, 3) / (cin // g * 27) ** 0.5
+    k = case.get("k", 3)
+    w = torch.randn(cout, cin // g, k, k, k) / (cin // g * k ** 3) ** 0.5
     bias = torch.randn(cout) if case["bias"] else None
     shift = torch.randn(B, cin) if case["shift"] else None
     scale = torch.rand(B, cin) + 0.5 if case["scale"] else None
@@ -379,21 +385,21 @@ def test_conv3d_bf16_operands_fp32_accumulate(ops, case):
         x = x * torch.sigmoid(x)
     if scale is not None:
         x = x * scale[:, :, None, None, None].double()
-    exact = F.conv3d(x, w.double(), None, padding=1, groups=g)
-    rounded = F.conv3d(_bf16_round(x.float()), _bf16_round(w), None, padding=1, groups=g)
+    exact = F.conv3d(x, w.double(), None, padding=k // 2, groups=g)
+    rounded = F.conv3d(_bf16_round(x.float()), _bf16_round(w), None, padding=k // 2, groups=g)
     for t in (exact, rounded):
         if bias is not None:
             t += 2.0 * bias.double()[None, :, None, None, None]
         if res is not None:
             t += res.double()
         t *= 0.5
-    assert ops.bf16_conv_supported(cout, cin, 3, g, case["segs"])
+    assert ops.bf16_conv_supported(cout, cin, k, g, case["segs"])
     wp = ops.pack_conv_weight_bf16(cu(w), groups=g)
     kw = dict(groups=g, math="bf16", bias=cu(bias) if bias is not None else None, bias_scale=2.0,
               in_shift=cu(shift) if shift is not None else None, in_scale=cu(scale) if scale is not None else None,
               in_act=case["act"], residual=cu(res) if res is not None else None, out_scale=0.5)
-    y = ops.conv3d([cu(s) for s in segs], wp, cout, 3, pack_input=False, **kw)
-    y2 = ops.conv3d([cu(s) for s in segs], wp, cout, 3, pack_input=True, **kw)
+    y = ops.conv3d([cu(s) for s in segs], wp, cout, k, pack_input=False, **kw)
+    y2 = ops.conv3d([cu(s) for s in segs], wp, cout, k, pack_input=True, **kw)
     assert torch.equal(y, y2), "fused and packed-input variants must agree bit for bit"
     # the prologue runs in fp32 on the GPU (fast exp), so a value may round to the neighbouring bf16: allow a few 1e-4
     assert_close(y.cpu(), rounded.float(), 2e-3, 3e-4, "bf16 conv vs bf16-rounded fp64 conv")
@@ -405,6 +411,7 @@ def test_conv3d_bf16_rejects_unsupported(ops):
     x = cu(torch.randn(1, 8, 4, 8, 8))
     assert not ops.bf16_conv_supported(16, 8, 3) and not ops.bf16_conv_supported(32, 12, 3)
     assert not ops.bf16_conv_supported(32, 8, 1) and not ops.bf16_conv_supported(32, 16, 3, 1, [4, 12])
+    assert ops.bf16_conv_supported(32, 16, 1) and not ops.bf16_conv_supported(32, 24, 1)
     with pytest.raises(ValueError):
         ops.pack_conv_weight_bf16(cu(torch.randn(32, 12, 3, 3, 3)))
     wp = ops.pack_conv_weight_bf16(cu(torch.randn(32, 8, 3, 3, 3)))

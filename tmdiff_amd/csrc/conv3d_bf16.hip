@@ -469,18 +469,147 @@ __global__ void __launch_bounds__(256, 2) conv3d_bf16_dma_kernel(const BfArgs a,
   store_tile<NS, MSUB, TW>(a, acc, bias_v, b, g, co0, n0, h0, w0, wv, l31, kg, plane);
 }
 
-// packed[g][chunk][tap 0..27][co][8 ci] (bf16, RNE) <- w[g*cout_g + co][chunk*8 + ci][tap]; tap 27 = 0
+// ---- 1x1x1 convolution, bf16 operands -------------------------------------------------------------------------
+// A bandwidth kernel (2*Cin*Cout/(4*(Cin+Cout)) FLOP per byte): no LDS at all.  MFMA columns = 32 consecutive
+// positions, K = 16 input channels: lane (col, kg) loads its 8 channels of position col straight from the fp32
+// activations (each load coalesced over the positions), applies the prologue and converts -- that IS the B
+// operand.  The A operand (weights [chunk][co][8 ci]) comes from L2 as one 16-byte load per lane.
+// A workgroup = 4 waves x (NS x 32 positions) x (MSUB x 32 channels).
+template <int NS, int MSUB, bool ACT>
+__global__ void __launch_bounds__(256, 2) conv1_bf16_kernel(const BfArgs a) {
+  constexpr int CO = 32 * MSUB;
+  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+  const int l31 = lane & 31, kg = lane >> 5;
+  const long plane = (long)a.N * a.H * a.W;
+  unsigned id = blockIdx.x;
+  const int co_tile = __builtin_amdgcn_readfirstlane(id % a.tiles_co); id /= a.tiles_co;
+  const int ptile = __builtin_amdgcn_readfirstlane(id % a.tiles_w); id /= a.tiles_w;   // tiles_w = position tiles here
+  const int g = __builtin_amdgcn_readfirstlane(id % a.groups);
+  const int b = __builtin_amdgcn_readfirstlane(id / a.groups);
+  const int co0 = co_tile * CO;
+  const int nsteps = a.cin_g / 16;
+  const long pos0 = (long)ptile * (4 * NS * 32) + wv * (NS * 32) + l31;
+  long pos[NS];
+  bool pok[NS];
+#pragma unroll
+  for (int s = 0; s < NS; ++s) {
+    pos[s] = pos0 + s * 32;
+    pok[s] = pos[s] < plane;
+    if (!pok[s]) pos[s] = plane - 1;  // clamped loads, no store
+  }
+  const uint4* wg = a.wp + (long)g * (a.cin_g / 8) * a.cout_g + co0 + l31;
+
+  f32x16 acc[NS][MSUB];
+#pragma unroll
+  for (int s = 0; s < NS; ++s)
+#pragma unroll
+    for (int m = 0; m < MSUB; ++m)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[s][m][r] = 0.f;
+
+  float xr[2][NS][8];
+  unsigned wr[2][MSUB][4];
+  float shs[2][8], scs[2][8];
+  auto load_step = [&](int q, int buf) __attribute__((always_inline)) {
+    const int cg = g * a.cin_g + q * 16 + kg * 8;  // this lane's octet (global channel index)
+    const float* src;
+    int cl, segc;
+    if (cg < a.seg_c[0]) src = a.seg_x[0], cl = cg, segc = a.seg_c[0];
+    else if (cg < a.seg_c[0] + a.seg_c[1]) src = a.seg_x[1], cl = cg - a.seg_c[0], segc = a.seg_c[1];
+    else src = a.seg_x[2], cl = cg - a.seg_c[0] - a.seg_c[1], segc = a.seg_c[2];
+    const float* base = src + ((long)b * segc + cl) * plane;
+#pragma unroll
+    for (int s = 0; s < NS; ++s)
+#pragma unroll
+      for (int j = 0; j < 8; ++j) xr[buf][s][j] = base[pos[s] + j * plane];
+    const float* shp = a.in_shift ? a.in_shift + (long)b * a.shift_stride + cg : kZeros;
+    const float* scp = a.in_scale ? a.in_scale + (long)b * a.scale_stride + cg : kOnes;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) shs[buf][j] = shp[j], scs[buf][j] = scp[j];
+#pragma unroll
+    for (int m = 0; m < MSUB; ++m) {
+      const uint4 t = wg[(long)(2 * q + kg) * a.cout_g + m * 32];
+      wr[buf][m][0] = t.x, wr[buf][m][1] = t.y, wr[buf][m][2] = t.z, wr[buf][m][3] = t.w;
+    }
+  };
+  auto mfma_step = [&](int buf) __attribute__((always_inline)) {
+    union Frag { bf16x8 h; uint4 u; };
+    Frag bv[NS], av[MSUB];
+#pragma unroll
+    for (int s = 0; s < NS; ++s)
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        float v = xr[buf][s][j] + shs[buf][j];
+        if constexpr (ACT) v = tmdiff::silu_f(v);
+        bv[s].h[j] = (__bf16)(v * scs[buf][j]);
+      }
+#pragma unroll
+    for (int m = 0; m < MSUB; ++m) av[m].u = make_uint4(wr[buf][m][0], wr[buf][m][1], wr[buf][m][2], wr[buf][m][3]);
+#pragma unroll
+    for (int s = 0; s < NS; ++s)
+#pragma unroll
+      for (int m = 0; m < MSUB; ++m)
+        acc[s][m] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av[m].h, bv[s].h, acc[s][m], 0, 0, 0);
+  };
+  load_step(0, 0);
+  for (int q = 0; q < nsteps; q += 2) {
+    if (q + 1 < nsteps) load_step(q + 1, 1);
+    mfma_step(0);
+    if (q + 1 < nsteps) {
+      if (q + 2 < nsteps) load_step(q + 2, 0);
+      mfma_step(1);
+    }
+  }
+
+  // epilogue: col = position, row (r&3) + 8*(r>>2) + 4*kg = channel
+#pragma unroll
+  for (int m = 0; m < MSUB; ++m) {
+    const int cbase = g * a.cout_g + co0 + m * 32 + 4 * kg;
+#pragma unroll
+    for (int s = 0; s < NS; ++s) {
+      const long obase = ((long)b * a.Cout + cbase) * plane + pos[s];
+      float res[16], bs[16];
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int row = (r & 3) + 8 * (r >> 2);
+        res[r] = a.residual ? a.residual[obase + row * plane] : 0.f;
+        bs[r] = a.bias ? a.bias[cbase + row] * a.bias_scale : 0.f;
+      }
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int row = (r & 3) + 8 * (r >> 2);
+        if (pok[s]) a.y[obase + row * plane] = (acc[s][m][r] + bs[r] + res[r]) * a.out_scale;
+      }
+    }
+  }
+}
+
+template <int NS, int MSUB>
+int launch_k1(BfArgs& a, hipStream_t st) {
+  const long plane = (long)a.N * a.H * a.W;
+  a.tiles_w = (int)((plane + 4 * NS * 32 - 1) / (4 * NS * 32));
+  a.tiles_co = a.cout_g / (32 * MSUB);
+  const long blocks = (long)a.B * a.groups * a.tiles_w * a.tiles_co;
+  if (blocks <= 0 || blocks > 0x7fffffffL) return tmdiff::fail(TMDIFF_E_INVALID, "conv1_bf16: grid of %ld blocks", blocks);
+  if (a.in_act) conv1_bf16_kernel<NS, MSUB, true><<<(unsigned)blocks, 256, 0, st>>>(a);
+  else conv1_bf16_kernel<NS, MSUB, false><<<(unsigned)blocks, 256, 0, st>>>(a);
+  return tmdiff::check_launch("conv3d_fwd_bf16 (1x1x1)");
+}
+
+// packed[g][chunk][tap][co][8 ci] (bf16, RNE) <- w[g*cout_g + co][chunk*8 + ci][tap]
+// 3x3x3: 28 tap slots, slot 27 = 0 (taps are consumed in pairs); 1x1x1: one slot.
 __global__ void __launch_bounds__(256) pack_weights_bf16_kernel(const float* __restrict__ w, uint16_t* __restrict__ packed,
-                                                                int cout_g, int cin_g, int groups, long total) {
+                                                                int cout_g, int cin_g, int groups, int taps, int slots,
+                                                                long total) {
   for (long i = blockIdx.x * 256L + threadIdx.x; i < total; i += 256L * gridDim.x) {
     const int ci8 = (int)(i % 8);
     long r = i / 8;
     const int co = (int)(r % cout_g); r /= cout_g;
-    const int tap = (int)(r % TAPS2); r /= TAPS2;
+    const int tap = (int)(r % slots); r /= slots;
     const int chunk = (int)(r % (cin_g / 8));
     const int g = (int)(r / (cin_g / 8));
     float v = 0.f;
-    if (tap < 27) v = w[(((long)g * cout_g + co) * cin_g + chunk * 8 + ci8) * 27 + tap];
+    if (tap < taps) v = w[(((long)g * cout_g + co) * cin_g + chunk * 8 + ci8) * taps + tap];
     const __bf16 h = (__bf16)v;
     packed[i] = *reinterpret_cast<const uint16_t*>(&h);
   }
@@ -530,23 +659,26 @@ extern "C" size_t tmdiff_conv3d_bf16_workspace_bytes(const tmdiff_conv3d_desc* d
   return (size_t)d->B * d->Cin * d->N * d->H * d->W * 2;
 }
 
-extern "C" size_t tmdiff_conv3d_packed_bf16_bytes(int32_t Cout, int32_t Cin, int32_t groups) {
-  if (groups < 1 || Cout <= 0 || Cin <= 0 || Cin % groups || (Cin / groups) % 8) return 0;
-  return (size_t)Cin / 8 * TAPS2 * (Cout / groups) * 16;
+extern "C" size_t tmdiff_conv3d_packed_bf16_bytes(int32_t Cout, int32_t Cin, int32_t ksize, int32_t groups) {
+  if (groups < 1 || Cout <= 0 || Cin <= 0 || Cin % groups || Cout % groups || (ksize != 1 && ksize != 3)) return 0;
+  if ((Cin / groups) % (ksize == 3 ? 8 : 16)) return 0;
+  return (size_t)Cin / 8 * (ksize == 3 ? TAPS2 : 1) * (Cout / groups) * 16;
 }
 
-extern "C" int tmdiff_conv3d_pack_weights_bf16(const float* w, void* packed, int32_t Cout, int32_t Cin, int32_t groups,
-                                               tmdiff_stream_t stream) {
+extern "C" int tmdiff_conv3d_pack_weights_bf16(const float* w, void* packed, int32_t Cout, int32_t Cin, int32_t ksize,
+                                               int32_t groups, tmdiff_stream_t stream) {
   using namespace tmdiff;
   TMDIFF_REQUIRE(w && packed, "pack_weights_bf16: NULL pointer");
+  TMDIFF_REQUIRE(ksize == 1 || ksize == 3, "pack_weights_bf16: ksize=%d (1 or 3)", ksize);
   TMDIFF_REQUIRE(groups >= 1 && Cout > 0 && Cin > 0 && Cout % groups == 0 && Cin % groups == 0,
                  "pack_weights_bf16: Cout=%d Cin=%d groups=%d", Cout, Cin, groups);
   TMDIFF_REQUIRE((Cin / groups) % 8 == 0, "pack_weights_bf16: Cin/groups=%d is not a multiple of 8", Cin / groups);
-  const long total = (long)(Cin / 8) * TAPS2 * (Cout / groups) * 8;
+  const int taps = ksize == 3 ? 27 : 1, slots = ksize == 3 ? TAPS2 : 1;
+  const long total = (long)(Cin / 8) * slots * (Cout / groups) * 8;
   long blocks = (total + 255) / 256;
   if (blocks > 4096) blocks = 4096;
   pack_weights_bf16_kernel<<<(int)blocks, 256, 0, as_stream(stream)>>>(w, static_cast<uint16_t*>(packed), Cout / groups,
-                                                                      Cin / groups, groups, total);
+                                                                      Cin / groups, groups, taps, slots, total);
   return check_launch("conv3d_pack_weights_bf16");
 }
 
@@ -559,11 +691,12 @@ extern "C" int tmdiff_conv3d_fwd_bf16(const tmdiff_conv3d_desc* d, void* workspa
   TMDIFF_REQUIRE(d->Cin > 0 && d->Cout > 0 && d->Cin % d->groups == 0 && d->Cout % d->groups == 0,
                  "conv3d_fwd_bf16: Cin=%d Cout=%d groups=%d", d->Cin, d->Cout, d->groups);
   TMDIFF_REQUIRE(d->nseg >= 1 && d->nseg <= 3, "conv3d_fwd_bf16: nseg=%d", d->nseg);
-  if (d->ksize != 3) return fail(TMDIFF_E_UNSUPPORTED, "conv3d_fwd_bf16: ksize=%d (3x3x3 only)", d->ksize);
+  TMDIFF_REQUIRE(d->ksize == 1 || d->ksize == 3, "conv3d_fwd_bf16: ksize=%d (1 or 3)", d->ksize);
   if (d->in_mask) return fail(TMDIFF_E_UNSUPPORTED, "conv3d_fwd_bf16: input masks (training) are fp32 only");
   const int cin_g = d->Cin / d->groups, cout_g = d->Cout / d->groups;
-  if (cin_g % 8 || cout_g % 32)
-    return fail(TMDIFF_E_UNSUPPORTED, "conv3d_fwd_bf16: Cin/g=%d (multiple of 8) Cout/g=%d (multiple of 32)", cin_g, cout_g);
+  if (cin_g % (d->ksize == 3 ? 8 : 16) || cout_g % 32)
+    return fail(TMDIFF_E_UNSUPPORTED, "conv3d_fwd_bf16: Cin/g=%d (multiple of %d) Cout/g=%d (multiple of 32)", cin_g,
+                d->ksize == 3 ? 8 : 16, cout_g);
   if (d->B == 0) return TMDIFF_OK;
   int csum = 0;
   for (int i = 0; i < d->nseg; ++i) {
@@ -593,6 +726,10 @@ extern "C" int tmdiff_conv3d_fwd_bf16(const tmdiff_conv3d_desc* d, void* workspa
   a.scale_stride = d->in_scale_stride > 0 ? d->in_scale_stride : (d->in_scale_stride < 0 ? 0 : d->Cin);
   a.residual = d->residual; a.out_scale = d->out_scale; a.y = d->y;
   hipStream_t st = as_stream(stream);
+  if (d->ksize == 1) {  // bandwidth kernel, no workspace
+    if (cout_g % 128 == 0) return launch_k1<1, 4>(a, st);
+    return cout_g % 64 == 0 ? launch_k1<2, 2>(a, st) : launch_k1<4, 1>(a, st);
+  }
   if (workspace) {  // two-kernel variant: pack the prologue output once, then the staging-free kernel
     TMDIFF_REQUIRE(aligned16(workspace), "conv3d_fwd_bf16: workspace must be 16-byte aligned");
     TMDIFF_REQUIRE(d->B * (long)(d->Cin / 8) <= 65535, "conv3d_fwd_bf16: B*Cin/8 = %ld exceeds the pack grid", d->B * (long)(d->Cin / 8));

@@ -37,19 +37,22 @@ def pack_conv_weight(w, groups=1, mode=0):
 
 def bf16_conv_supported(cout, cin, ksize, groups=1, seg_channels=None):
     """Shapes tmdiff_conv3d_fwd_bf16 accepts (include/tmdiff_hip.h); other layers stay on the fp32 kernel."""
-    if ksize != 3 or cin % groups or cout % groups or (cin // groups) % 8 or (cout // groups) % 32:
+    if ksize not in (1, 3) or cin % groups or cout % groups or (cout // groups) % 32:
+        return False
+    if (cin // groups) % (8 if ksize == 3 else 16):
         return False
     return all(c % 8 == 0 for c in (seg_channels or ()))
 
 
 def pack_conv_weight_bf16(w, groups=1):
-    """[Cout, Cin/g, 3,3,3] fp32 -> bf16 packing [g][Cin_g/8][28 taps][Cout_g][8] (returned as an int16 tensor)."""
-    cout, cin_g = w.shape[0], w.shape[1]
-    nbytes = lib.tmdiff_conv3d_packed_bf16_bytes(cout, cin_g * groups, groups)
-    if nbytes == 0 or tuple(w.shape[2:]) != (3, 3, 3):
+    """[Cout, Cin/g, k,k,k] fp32 -> bf16 packing [g][Cin_g/8][tap slots][Cout_g][8] (returned as an int16 tensor);
+    28 tap slots for 3x3x3, one for 1x1x1."""
+    cout, cin_g, k = w.shape[0], w.shape[1], w.shape[2]
+    nbytes = lib.tmdiff_conv3d_packed_bf16_bytes(cout, cin_g * groups, k, groups) if tuple(w.shape[2:]) == (k, k, k) else 0
+    if nbytes == 0:
         raise ValueError(f"conv weight {tuple(w.shape)} (groups={groups}) has no bf16 packing")
     out = torch.empty(nbytes // 2, device=w.device, dtype=torch.int16)
-    check(lib.tmdiff_conv3d_pack_weights_bf16(_chk(w.detach(), "w"), out.data_ptr(), cout, cin_g * groups, groups,
+    check(lib.tmdiff_conv3d_pack_weights_bf16(_chk(w.detach(), "w"), out.data_ptr(), cout, cin_g * groups, k, groups,
                                               stream_ptr()), "conv3d_pack_weights_bf16")
     return out
 
@@ -130,7 +133,8 @@ def conv3d(segs, w_packed, cout, ksize, out=None, math="fp32", pack_input=None, 
             raise TypeError("conv3d(math='bf16') needs weights from pack_conv_weight_bf16")
         if pack_input is None:
             pack_input = {"0": False, "1": True}.get(_BF16_PACK, True)   # measured: the two-kernel variant wins on every production layer
-        ws = _workspace(y.device, lib.tmdiff_conv3d_bf16_workspace_bytes(C.byref(d))).data_ptr() if pack_input else None
+        ws = (_workspace(y.device, lib.tmdiff_conv3d_bf16_workspace_bytes(C.byref(d))).data_ptr()
+              if pack_input and ksize == 3 else None)
         fwd, what = (lambda dd, st: lib.tmdiff_conv3d_fwd_bf16(dd, ws, st)), "conv3d_fwd_bf16"
     elif math == "fp32":
         if not isinstance(w_packed, int) and w_packed.dtype != torch.float32:
