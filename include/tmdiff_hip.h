@@ -199,7 +199,8 @@ int tmdiff_linear_bwd(const float* x, const float* w, const float* bias, const f
  *    x0 = (x - sigma*eps)/alpha.
  *  abs_quantile_clamp: dynamic thresholding (:430-439): per sample s = max(quantile(|x0|, q), max_val)
  *    (linear interpolation between order statistics, as torch.quantile), x0 = clamp(x0,-s,s)/s.
- *    workspace: tmdiff_abs_quantile_workspace_bytes(B, n) bytes.
+ *    workspace: tmdiff_abs_quantile_workspace_bytes(B, n) bytes (select state; on return its first B floats hold
+ *    the per-sample thresholds s).  Runs as a few launches (histogram passes spread over many workgroups).
  * ------------------------------------------------------------------------------------ */
 int tmdiff_ddpm_step(const float* x, const float* eps, const float* noise, const float* ms, float* out,
                      float* img_out, int64_t n, float c_recip, float c_recipm1, float coef1, float coef2,
