@@ -18,6 +18,8 @@ Extra objects on the JSON line (tier contract):
                 cores on a bounded sample, rank 0, N == 1 only.
   cond_cached   the same loop with the step-invariant condition branch hoisted out (evaluated once per
                 sampling run): the rate a real 1000-step run sees.  Reported beside, never as, `value`.
+  bf16_compute  the same full-forward loop with bf16 conv operands / fp32 accumulation (the config-3 mode);
+                reduced precision, so also only beside `value`.
 """
 import argparse
 import json
@@ -157,10 +159,22 @@ def main():
     dt_cached = time.perf_counter() - t1
     log(f"cond-cached loop: {args.steps} steps in {dt_cached:.3f} s")
 
+    # ---- the full-forward loop again with bf16-operand convolutions (SURVEY 8d config-3 mode), outside `value` ----
+    net.set_compute_dtype("bf16")
+    x3 = run(2, T - 1, torch.randn_like(d["Res"]))          # packs the bf16 weights
+    barrier()
+    t2 = time.perf_counter()
+    x3 = run(args.steps, T - 1, x3)
+    barrier()
+    dt_bf16 = time.perf_counter() - t2
+    net.set_compute_dtype("fp32")
+    assert torch.isfinite(x3).all()
+    log(f"bf16-compute loop: {args.steps} steps in {dt_bf16:.3f} s")
+
     if dist is not None:
-        tt = torch.tensor([dt, dt_cached], device=dev, dtype=torch.float64)
+        tt = torch.tensor([dt, dt_cached, dt_bf16], device=dev, dtype=torch.float64)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-        dt, dt_cached = float(tt[0]), float(tt[1])
+        dt, dt_cached, dt_bf16 = float(tt[0]), float(tt[1]), float(tt[2])
 
     if rank == 0:
         n3, ms3, fl3 = conv.get(3, (0, 0.0, 0.0))
@@ -192,6 +206,11 @@ def main():
                             "note": "condition branch (62.82 of 172.39 GFLOP/sample, independent of x_t and t) "
                                     "evaluated once inside the timed run instead of every step; outputs are "
                                     "bit-identical (tests/test_gpu_sampling.py)"},
+            "bf16_compute": {"value": round(world * args.steps / dt_bf16, 4), "unit": "batch32-steps/s",
+                             "unet_tflops": round(BATCH * GFLOP_PER_SAMPLE * 1e-3 * args.steps / dt_bf16, 2),
+                             "note": "same full-forward steps with bf16 conv operands / fp32 accumulation "
+                                     "(set_compute_dtype('bf16'), the config-3 mode; forward rel-L2 7e-3 vs fp32, "
+                                     "tests/test_gpu_bf16.py) -- reduced precision, never `value`"},
         }
         if world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline()
