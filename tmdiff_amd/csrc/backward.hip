@@ -6,9 +6,20 @@
 //   dL/dw   : conv3d_wgrad_kernel below (fp32 MFMA; K = batch x positions, split over workgroups, then reduced)
 //   dL/dx, dL/dshift, dL/dscale : prologue_bwd_kernel (HBM-bound, one workgroup per (b, c) plane)
 //   bias grads, stem / head / linear backward: small HBM-bound reductions.
+#include <type_traits>
+
 #include "common.h"
 
 namespace {
+
+template <int B, int E, class F>
+__device__ __forceinline__ void static_for(F&& f) {
+  if constexpr (B < E) {
+    f(std::integral_constant<int, B>{});
+    static_for<B + 1, E>(f);
+  }
+}
+
 
 using f32x16 = __attribute__((ext_vector_type(16))) float;
 
@@ -32,21 +43,18 @@ __device__ __forceinline__ float block_sum_256(float v, float* red) {
 //   MFMA rows (A) = 32 output channels : lane l holds g[co = l&31][k = l>>5]
 //   MFMA cols (B) = 32 input channels  : lane l holds x'[ci = l&31] at position k = l>>5, shifted by the tap
 //   K step = 2 positions.
-// A workgroup owns a 32x32 (co, ci) tile and walks a list of 2x8x8 position boxes; per box it stages the g box
-// [32][128] and the haloed, prologue-applied x' box [32][4*10*10] in LDS (odd row strides: conflict-free
-// column reads).  KS=3: wave w accumulates taps w, w+4, ... (7 accumulators, the g operand is shared by all of
-// them); KS=1: the four waves split the positions of the box and their partials are separate splits.
+// x' (the prologue output) is formed once per convolution by prologue_apply_kernel (it used to be re-evaluated by
+// every channel tile); the wgrad kernel then only copies.  A workgroup owns a 32x32 (co, ci) tile and walks a list
+// of 2x8x8 position boxes; per box it stages the g box [32][128] and the haloed x' box [32][4*10*10] in LDS (odd
+// row strides: conflict-free column reads).  The next box is fetched into registers while the MFMAs of this one
+// run (a box is 64 K-steps x 7 taps = 448 MFMAs per wave); all LDS operand reads have compile-time offsets.
+// KS=3: wave w accumulates taps w, w+4, ... (7 accumulators, the g operand is shared by all of them); KS=1: the
+// four waves split the positions of the box and their partials are separate splits.
 // Partials go to workspace[split][g][tap][co][ci]; wgrad_reduce_kernel sums the splits into PyTorch layout.
 // ---------------------------------------------------------------------------------------------------
 struct WgradArgs {
-  int B, N, H, W, Cin, Cout, cin_g, cout_g, groups, nseg;
-  int seg_c[3];
-  const float* seg_x[3];
-  const float* in_shift;
-  const float* in_scale;
-  int shift_stride, scale_stride;
-  const float* in_mask;
-  int in_act;
+  int B, N, H, W, Cin, Cout, cin_g, cout_g, groups;
+  const float* xp;  // x' [B, Cin, N, H, W]
   const float* g;
   float* ws;
   int nbn, nbh, nbw;       // boxes per sample along n, h, w
@@ -54,6 +62,40 @@ struct WgradArgs {
   int splits, boxes_per_split;
   long total_boxes;
 };
+
+struct ApplyArgs {
+  int B, Cin, nseg;
+  int seg_c[3];
+  const float* seg_x[3];
+  const float* in_shift;
+  const float* in_scale;
+  int shift_stride, scale_stride;
+  const float* in_mask;
+  int in_act;
+  float* xp;
+  long plane;
+};
+
+// x'[b, c, :] = act(x[b, c, :] + shift[b,c]) * scale[b,c] * mask[b,c,:]  -- one (b, c) plane per blockIdx.y
+__global__ void __launch_bounds__(256) prologue_apply_kernel(const ApplyArgs a) {
+  const int bc = blockIdx.y, b = bc / a.Cin, c = bc % a.Cin;
+  int cs = c, seg = 0;
+  if (a.nseg > 1 && cs >= a.seg_c[0]) { cs -= a.seg_c[0]; seg = 1; }
+  if (seg == 1 && a.nseg > 2 && cs >= a.seg_c[1]) { cs -= a.seg_c[1]; seg = 2; }
+  const int segc = seg == 0 ? a.seg_c[0] : (seg == 1 ? a.seg_c[1] : a.seg_c[2]);
+  const float* xs = (seg == 0 ? a.seg_x[0] : (seg == 1 ? a.seg_x[1] : a.seg_x[2])) + ((long)b * segc + cs) * a.plane;
+  const float* msk = a.in_mask ? a.in_mask + (long)bc * a.plane : nullptr;
+  const float sh = a.in_shift ? a.in_shift[(long)b * a.shift_stride + c] : 0.f;
+  const float sc = a.in_scale ? a.in_scale[(long)b * a.scale_stride + c] : 1.f;
+  float* dst = a.xp + (long)bc * a.plane;
+  for (long i = blockIdx.x * 256L + threadIdx.x; i < a.plane; i += 256L * gridDim.x) {
+    float v = xs[i] + sh;
+    if (a.in_act) v = tmdiff::silu_f(v);
+    v *= sc;
+    if (msk) v *= msk[i];
+    dst[i] = v;
+  }
+}
 
 template <int KS>
 __global__ void __launch_bounds__(256, 2) conv3d_wgrad_kernel(const WgradArgs a) {
@@ -63,6 +105,8 @@ __global__ void __launch_bounds__(256, 2) conv3d_wgrad_kernel(const WgradArgs a)
   constexpr int XE = HN * HH * HW;                                      // haloed box elements
   constexpr int GS = POSB + 1, XS = XE | 1;                             // odd LDS row strides
   constexpr int NT = KS == 3 ? 7 : 1;                                   // accumulators per wave
+  constexpr int GI = 32 * POSB / 256, XI = 32 * XE / 256;               // staged elements per thread
+  static_assert(32 * XE % 256 == 0 && XI <= 64, "the x' box must split evenly over the workgroup");
   __shared__ float gt[32 * GS];
   __shared__ float xt[32 * XS];
 
@@ -75,79 +119,111 @@ __global__ void __launch_bounds__(256, 2) conv3d_wgrad_kernel(const WgradArgs a)
   const int co0 = co_t * 32, ci0 = ci_t * 32;
   const long plane = (long)a.N * a.H * a.W;
 
+  // ---- staging pattern (the same for every box): x' item i covers element q = i*256 + tid of [32 ci][XE].  Its
+  //      (ci, nz, hz, wz) are re-derived from q per box (constant divisions): keeping them costs 25+ registers.
+  const int gp = tid & (POSB - 1), gco = tid >> 7;  // g item i: channel 2*i + gco, position gp of the box
+  const int gpn = gp / (BH * BW), gph = (gp / BW) % BH, gpw = gp % BW;
+
   f32x16 acc[NT];
 #pragma unroll
   for (int j = 0; j < NT; ++j)
 #pragma unroll
     for (int r = 0; r < 16; ++r) acc[j][r] = 0.f;
 
+  float gr[GI], xr[XI];
+  unsigned gmask = 0;
+  unsigned long long xmask = 0;
+  auto prefetch = [&](long bx) __attribute__((always_inline)) {
+    unsigned t = (unsigned)bx;
+    const int bw_i = (int)(t % (unsigned)a.nbw); t /= (unsigned)a.nbw;
+    const int bh_i = (int)(t % (unsigned)a.nbh); t /= (unsigned)a.nbh;
+    const int bn_i = (int)(t % (unsigned)a.nbn);
+    const int b = (int)(t / (unsigned)a.nbn);
+    const int n0 = bn_i * BN, h0 = bh_i * BH, w0 = bw_i * BW;
+    // branch-free, 32-bit offsets from wave-uniform bases (bitwise & on purpose: && would branch around the loads)
+    const unsigned plane32 = (unsigned)plane;
+    {
+      const int n = n0 + gpn, h = h0 + gph, w = w0 + gpw;
+      const bool pok = (n < a.N) & (h < a.H) & (w < a.W);
+      const unsigned off = pok ? (unsigned)((n * a.H + h) * a.W + w) : 0u;
+      const float* gb = a.g + ((long)b * a.Cout + g * a.cout_g + co0) * plane;
+      const int co_left = a.cout_g - co0;
+      gmask = 0;
+#pragma unroll
+      for (int i = 0; i < GI; ++i) {
+        const int co = 2 * i + gco;
+        const bool ok = pok & (co < co_left);
+        gr[i] = gb[ok ? (unsigned)co * plane32 + off : 0u];
+        gmask |= (unsigned)ok << i;
+      }
+    }
+    const float* xb = a.xp + ((long)b * a.Cin + g * a.cin_g + ci0) * plane;
+    const int ci_left = a.cin_g - ci0;
+    int tid_o = tid;
+    asm volatile("" : "+v"(tid_o));
+    unsigned xm_lo = 0, xm_hi = 0;
+#pragma unroll
+    for (int i = 0; i < XI; ++i) {
+      unsigned q = (unsigned)(i * 256) + (unsigned)tid_o;  // tid_o: tid made opaque per box so that this is not hoisted
+      const unsigned ci = q / XE, e = q % XE;
+      const int nz = e / (HH * HW), hz = (e / HW) % HH, wz = e % HW;
+      const int n = n0 + nz - HALO, h = h0 + hz - HALO, w = w0 + wz - HALO;
+      const bool ok = ((int)ci < ci_left) & ((unsigned)n < (unsigned)a.N) & ((unsigned)h < (unsigned)a.H) &
+                      ((unsigned)w < (unsigned)a.W);
+      xr[i] = xb[ok ? ci * plane32 + (unsigned)((n * a.H + h) * a.W + w) : 0u];
+      if (i < 32) xm_lo |= (unsigned)ok << (i & 31); else xm_hi |= (unsigned)ok << (i & 31);
+    }
+    xmask = (unsigned long long)xm_hi << 32 | xm_lo;
+  };
+  auto stage = [&]() __attribute__((always_inline)) {
+    int tid_s = tid;
+    asm volatile("" : "+v"(tid_s));
+#pragma unroll
+    for (int i = 0; i < GI; ++i) gt[(2 * i + gco) * GS + gp] = (gmask >> i) & 1 ? gr[i] : 0.f;
+#pragma unroll
+    for (int i = 0; i < XI; ++i) {
+      const unsigned q = (unsigned)(i * 256) + (unsigned)tid_s;
+      xt[(q / XE) * XS + q % XE] = (xmask >> i) & 1 ? xr[i] : 0.f;
+    }
+  };
+  const float* ga = gt + l31 * GS + khalf;   // A operand of K-step ks: ga[2*ks]
+  const float* xa = xt + l31 * XS + khalf;   // B operand: xa[box offset of position 2*ks + tap offset]
+  const float* xj[NT];                       // ... with the (wave-uniform) tap offset of accumulator j folded in
+#pragma unroll
+  for (int j = 0; j < NT; ++j) {
+    const int tap = KS == 3 ? min(wv + 4 * j, TAPS - 1) : 0;
+    xj[j] = xa + ((tap / (KS * KS)) * HH + (tap / KS) % KS) * HW + tap % KS;
+  }
+  auto mfma_box = [&]() __attribute__((always_inline)) {
+    constexpr int KSTEPS = POSB / 2, PER_WAVE = KS == 3 ? KSTEPS : KSTEPS / 4;
+    static_for<0, PER_WAVE>([&](auto kc) __attribute__((always_inline)) {
+      constexpr int k0 = decltype(kc)::value;
+      if constexpr (KS == 3) {
+        constexpr int p = 2 * k0;
+        constexpr int pn = p / (BH * BW), ph = (p / BW) % BH, pw = p % BW;
+        const float av = ga[p];
+#pragma unroll
+        for (int j = 0; j < NT; ++j) {
+          // (wave 3 has no 7th tap: it repeats tap 26 into an accumulator that is never stored)
+          acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, xj[j][(pn * HH + ph) * HW + pw], acc[j], 0, 0, 0);
+        }
+      } else {
+        const int p = 2 * (wv * PER_WAVE + k0);
+        acc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(ga[p], xa[p], acc[0], 0, 0, 0);
+      }
+      if constexpr (k0 % 2 == 1) __builtin_amdgcn_sched_barrier(0);  // keep the operand reads of later K-steps out of flight
+    });
+  };
+
   const long box_lo = (long)split * a.boxes_per_split;
   const long box_hi = min(box_lo + a.boxes_per_split, a.total_boxes);
+  if (box_lo < box_hi) prefetch(box_lo);
   for (long bx = box_lo; bx < box_hi; ++bx) {
-    long t = bx;
-    const int bw_i = (int)(t % a.nbw); t /= a.nbw;
-    const int bh_i = (int)(t % a.nbh); t /= a.nbh;
-    const int bn_i = (int)(t % a.nbn);
-    const int b = (int)(t / a.nbn);
-    const int n0 = bn_i * BN, h0 = bh_i * BH, w0 = bw_i * BW;
     __syncthreads();  // previous box fully consumed
-    // ---- stage g box: [32 co][128 pos] ---------------------------------------------------------------------
-    for (int e = tid; e < 32 * POSB; e += 256) {
-      const int co = e / POSB, p = e % POSB;
-      const int n = n0 + p / (BH * BW), h = h0 + (p / BW) % BH, w = w0 + p % BW;
-      float v = 0.f;
-      if (co0 + co < a.cout_g && n < a.N && h < a.H && w < a.W)
-        v = a.g[((long)b * a.Cout + g * a.cout_g + co0 + co) * plane + ((long)n * a.H + h) * a.W + w];
-      gt[co * GS + p] = v;
-    }
-    // ---- stage x' box: [32 ci][haloed], prologue applied once per element, padding exactly zero ------------
-    for (int ci = 0; ci < 32; ++ci) {
-      const int cl = ci0 + ci;
-      const bool cvalid = cl < a.cin_g;
-      const int cg = g * a.cin_g + (cvalid ? cl : 0);
-      float sh = 0.f, sc = 1.f;
-      if (a.in_shift) sh = a.in_shift[(long)b * a.shift_stride + cg];
-      if (a.in_scale) sc = a.in_scale[(long)b * a.scale_stride + cg];
-      int cs = cg, segc = a.seg_c[0];
-      const float* base = a.seg_x[0];
-      if (a.nseg > 1 && cs >= segc) {
-        cs -= segc; base = a.seg_x[1]; segc = a.seg_c[1];
-        if (a.nseg > 2 && cs >= segc) { cs -= segc; base = a.seg_x[2]; segc = a.seg_c[2]; }
-      }
-      const float* src = base + ((long)b * segc + cs) * plane;
-      const float* msk = a.in_mask ? a.in_mask + ((long)b * a.Cin + cg) * plane : nullptr;
-      for (int e = tid; e < XE; e += 256) {
-        const int wz = e % HW, hz = (e / HW) % HH, nz = e / (HW * HH);
-        const int n = n0 + nz - HALO, h = h0 + hz - HALO, w = w0 + wz - HALO;
-        float v = 0.f;
-        if (cvalid && n >= 0 && n < a.N && h >= 0 && h < a.H && w >= 0 && w < a.W) {
-          const long o = ((long)n * a.H + h) * a.W + w;
-          v = src[o] + sh;
-          if (a.in_act) v = tmdiff::silu_f(v);
-          v *= sc;
-          if (msk) v *= msk[o];
-        }
-        xt[ci * XS + e] = v;
-      }
-    }
+    stage();
     __syncthreads();
-    // ---- K loop over the positions of the box ------------------------------------------------------------------
-    const int ks_lo = KS == 3 ? 0 : wv * (POSB / 8), ks_hi = KS == 3 ? POSB / 2 : (wv + 1) * (POSB / 8);
-    for (int ks = ks_lo; ks < ks_hi; ++ks) {
-      const int p = 2 * ks + khalf;
-      const int pn = p / (BH * BW), ph = (p / BW) % BH, pw = p % BW;
-      const float av = gt[l31 * GS + p];
-      const int xb = l31 * XS + (pn * HH + ph) * HW + pw;
-#pragma unroll
-      for (int j = 0; j < NT; ++j) {
-        const int tap = KS == 3 ? wv + 4 * j : 0;
-        if (tap < TAPS) {  // wave-uniform
-          const int dn = tap / (KS * KS), dh = (tap / KS) % KS, dw = tap % KS;
-          const float bv = xt[xb + (dn * HH + dh) * HW + dw];
-          acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bv, acc[j], 0, 0, 0);
-        }
-      }
-    }
+    if (bx + 1 < box_hi) prefetch(bx + 1);
+    mfma_box();
   }
   // ---- partial sums -> workspace[slot][g][tap][co][ci]; D layout: col = l31 (ci), row = co ----------------------
   const int slot = KS == 3 ? split : split * 4 + wv;
@@ -346,6 +422,8 @@ __global__ void __launch_bounds__(256) linear_dx_kernel(const float* __restrict_
 struct WgradPlan {
   int taps, nbn, nbh, nbw, tiles_co, tiles_ci, splits, boxes_per_split, slots;
   long total_boxes;
+  bool needs_xp;        // the prologue output (or the concatenation of the segments) is materialised in the workspace
+  size_t partial_floats;
 };
 
 inline WgradPlan plan_wgrad(const tmdiff_conv3d_desc* d) {
@@ -356,12 +434,14 @@ inline WgradPlan plan_wgrad(const tmdiff_conv3d_desc* d) {
   const int cout_g = d->Cout / d->groups, cin_g = d->Cin / d->groups;
   p.tiles_co = (cout_g + 31) / 32; p.tiles_ci = (cin_g + 31) / 32;
   const long tiles = (long)d->groups * p.tiles_co * p.tiles_ci;
-  long splits = (1024 + tiles - 1) / tiles;  // ~4 workgroups per CU
+  long splits = (512 + tiles - 1) / tiles;  // two resident workgroups per CU
   if (splits > p.total_boxes) splits = p.total_boxes;
   if (splits < 1) splits = 1;
   p.boxes_per_split = (int)((p.total_boxes + splits - 1) / splits);
   p.splits = (int)((p.total_boxes + p.boxes_per_split - 1) / p.boxes_per_split);
   p.slots = d->ksize == 3 ? p.splits : p.splits * 4;
+  p.needs_xp = d->nseg > 1 || d->in_shift || d->in_scale || d->in_mask || d->in_act;
+  p.partial_floats = ((size_t)p.slots * d->Cout * cin_g * p.taps + 3) / 4 * 4;
   return p;
 }
 
@@ -370,7 +450,8 @@ inline WgradPlan plan_wgrad(const tmdiff_conv3d_desc* d) {
 extern "C" size_t tmdiff_conv3d_wgrad_workspace_bytes(const tmdiff_conv3d_desc* d) {
   if (!d || d->B <= 0 || d->groups <= 0 || (d->ksize != 1 && d->ksize != 3)) return 0;
   const WgradPlan p = plan_wgrad(d);
-  return (size_t)p.slots * d->Cout * (d->Cin / d->groups) * p.taps * sizeof(float);
+  const size_t xp = p.needs_xp ? (size_t)d->B * d->Cin * d->N * d->H * d->W : 0;
+  return (p.partial_floats + xp) * sizeof(float);
 }
 
 extern "C" int tmdiff_conv3d_wgrad(const tmdiff_conv3d_desc* d, const float* g, float* dw, void* workspace,
@@ -390,18 +471,33 @@ extern "C" int tmdiff_conv3d_wgrad(const tmdiff_conv3d_desc* d, const float* g, 
   TMDIFF_REQUIRE(csum == d->Cin, "conv3d_wgrad: segments hold %d channels, Cin=%d", csum, d->Cin);
   TMDIFF_REQUIRE(workspace != nullptr, "conv3d_wgrad: NULL workspace");
   const WgradPlan p = plan_wgrad(d);
+  TMDIFF_REQUIRE(p.total_boxes < (1L << 31) && (long)d->N * d->H * d->W * 32 < (1L << 31),
+                 "conv3d_wgrad: tensor too large for 32-bit box / offset arithmetic");
+  hipStream_t st = as_stream(stream);
+  const long plane = (long)d->N * d->H * d->W;
   WgradArgs a;
   a.B = d->B; a.N = d->N; a.H = d->H; a.W = d->W; a.Cin = d->Cin; a.Cout = d->Cout;
-  a.groups = d->groups; a.cin_g = d->Cin / d->groups; a.cout_g = d->Cout / d->groups; a.nseg = d->nseg;
-  for (int i = 0; i < 3; ++i) { a.seg_c[i] = i < d->nseg ? d->seg_c[i] : 0; a.seg_x[i] = i < d->nseg ? d->seg_x[i] : nullptr; }
-  a.in_shift = d->in_shift; a.in_scale = d->in_scale; a.in_mask = d->in_mask; a.in_act = d->in_act;
-  a.shift_stride = d->in_shift_stride > 0 ? d->in_shift_stride : (d->in_shift_stride < 0 ? 0 : d->Cin);
-  a.scale_stride = d->in_scale_stride > 0 ? d->in_scale_stride : (d->in_scale_stride < 0 ? 0 : d->Cin);
+  a.groups = d->groups; a.cin_g = d->Cin / d->groups; a.cout_g = d->Cout / d->groups;
   a.g = g; a.ws = reinterpret_cast<float*>(workspace);
+  a.xp = d->seg_x[0];
+  if (p.needs_xp) {
+    TMDIFF_REQUIRE((long)d->B * d->Cin <= 65535, "conv3d_wgrad: B*Cin = %ld exceeds the grid", (long)d->B * d->Cin);
+    ApplyArgs q;
+    q.B = d->B; q.Cin = d->Cin; q.nseg = d->nseg;
+    for (int i = 0; i < 3; ++i) { q.seg_c[i] = i < d->nseg ? d->seg_c[i] : 0; q.seg_x[i] = i < d->nseg ? d->seg_x[i] : nullptr; }
+    q.in_shift = d->in_shift; q.in_scale = d->in_scale; q.in_mask = d->in_mask; q.in_act = d->in_act;
+    q.shift_stride = d->in_shift_stride > 0 ? d->in_shift_stride : (d->in_shift_stride < 0 ? 0 : d->Cin);
+    q.scale_stride = d->in_scale_stride > 0 ? d->in_scale_stride : (d->in_scale_stride < 0 ? 0 : d->Cin);
+    q.xp = a.ws + p.partial_floats;
+    q.plane = plane;
+    long pb = (plane + 1023) / 1024;
+    if (pb > 64) pb = 64;
+    prologue_apply_kernel<<<dim3((unsigned)pb, (unsigned)(d->B * d->Cin)), 256, 0, st>>>(q);
+    a.xp = q.xp;
+  }
   a.nbn = p.nbn; a.nbh = p.nbh; a.nbw = p.nbw; a.tiles_co = p.tiles_co; a.tiles_ci = p.tiles_ci;
   a.splits = p.splits; a.boxes_per_split = p.boxes_per_split; a.total_boxes = p.total_boxes;
   const long blocks = (long)d->groups * p.tiles_co * p.tiles_ci * p.splits;
-  hipStream_t st = as_stream(stream);
   if (d->ksize == 3)
     conv3d_wgrad_kernel<3><<<(unsigned)blocks, 256, 0, st>>>(a);
   else
