@@ -241,35 +241,68 @@ __global__ void __launch_bounds__(256, 2) conv3d_wgrad_kernel(const WgradArgs a)
 }
 
 // dw[g*cout_g + co][ci][tap] = sum_slot ws[slot][g][tap][co][ci]
+// A workgroup sums 64 consecutive workspace elements: 4 thread rows take every 4th slot (8 loads in flight each),
+// then the rows are combined through LDS in a fixed order (deterministic).
 __global__ void __launch_bounds__(256) wgrad_reduce_kernel(const float* __restrict__ ws, float* __restrict__ dw,
                                                            int slots, int groups, int taps, int cout_g, int cin_g,
                                                            long total) {
+  __shared__ float part[4][64];
   const long per_slot = (long)groups * taps * cout_g * cin_g;
-  for (long i = blockIdx.x * 256L + threadIdx.x; i < total; i += 256L * gridDim.x) {
-    // i enumerates the workspace order [g][tap][co][ci] (coalesced reads)
-    const int ci = (int)(i % cin_g);
-    long r = i / cin_g;
-    const int co = (int)(r % cout_g); r /= cout_g;
-    const int tap = (int)(r % taps);
-    const int g = (int)(r / taps);
+  const int col = threadIdx.x & 63, row = threadIdx.x >> 6;
+  for (long base = blockIdx.x * 64L; base < total; base += 64L * gridDim.x) {
+    const long i = base + col;  // workspace order [g][tap][co][ci] (coalesced reads)
     float s = 0.f;
-    for (int k = 0; k < slots; ++k) s += ws[k * per_slot + i];
-    dw[(((long)g * cout_g + co) * cin_g + ci) * taps + tap] = s;
+    if (i < total) {
+      int k = row;
+      for (; k + 28 < slots; k += 32) {
+        float v[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) v[u] = ws[(long)(k + 4 * u) * per_slot + i];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) s += v[u];
+      }
+      for (; k < slots; k += 4) s += ws[(long)k * per_slot + i];
+    }
+    part[row][col] = s;
+    __syncthreads();
+    if (row == 0 && i < total) {
+      const float t = (part[0][col] + part[1][col]) + (part[2][col] + part[3][col]);
+      const int ci = (int)(i % cin_g);
+      long r = i / cin_g;
+      const int co = (int)(r % cout_g); r /= cout_g;
+      const int tap = (int)(r % taps);
+      const int g = (int)(r / taps);
+      dw[(((long)g * cout_g + co) * cin_g + ci) * taps + tap] = t;
+    }
+    __syncthreads();
   }
 }
 
-// out[c] = scale * sum_{b,p} x[b,c,p]; one workgroup per channel
+// out[c] = scale * sum_{b,p} x[b,c,p].  A channel is spread over gridDim.y slices (one workgroup per channel left
+// most of the chip idle: 130 us for 33 MB); every slice adds its partial with one atomic (out is zeroed first).
+__global__ void __launch_bounds__(256) zero_kernel(float* __restrict__ p, int n) {
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i < n) p[i] = 0.f;
+}
+
 __global__ void __launch_bounds__(256) channel_sum_kernel(const float* __restrict__ x, float* __restrict__ out, int B,
                                                           int C, long P, float scale) {
   __shared__ float red[4];
   const int c = blockIdx.x;
+  const long per = (P + gridDim.y - 1) / gridDim.y;
+  const long lo = blockIdx.y * per, hi = min(lo + per, P);
   float s = 0.f;
   for (int b = 0; b < B; ++b) {
     const float* p = x + ((long)b * C + c) * P;
-    for (long i = threadIdx.x; i < P; i += 256) s += p[i];
+    long i = lo + threadIdx.x;
+    for (; i + 768 < hi; i += 1024) {
+      const float v0 = p[i], v1 = p[i + 256], v2 = p[i + 512], v3 = p[i + 768];
+      s += (v0 + v1) + (v2 + v3);
+    }
+    for (; i < hi; i += 256) s += p[i];
   }
   s = block_sum_256(s, red);
-  if (threadIdx.x == 0) out[c] = scale * s;
+  if (threadIdx.x == 0) atomicAdd(&out[c], scale * s);
 }
 
 struct PrologueBwdArgs {
@@ -409,14 +442,30 @@ __global__ void __launch_bounds__(256) linear_dw_kernel(const float* __restrict_
   }
 }
 
+// dx[b,k] = sum_o gu[b,o] w[o,k].  Workgroup = (b, 64 consecutive k); its 4 waves take every 4th row o (coalesced
+// 256-byte reads of w), partials combined through LDS in a fixed order.
 __global__ void __launch_bounds__(256) linear_dx_kernel(const float* __restrict__ w, const float* __restrict__ gu,
                                                         float* __restrict__ dx, int B, int I, int O) {
-  const long i = blockIdx.x * 256L + threadIdx.x;  // over B*I
-  if (i >= (long)B * I) return;
-  const int b = (int)(i / I), k = (int)(i % I);
+  __shared__ float part[4][64];
+  const int col = threadIdx.x & 63, row = threadIdx.x >> 6;
+  const int ktiles = (I + 63) / 64;
+  const int b = blockIdx.x / ktiles, k = (blockIdx.x % ktiles) * 64 + col;
   float s = 0.f;
-  for (int o = 0; o < O; ++o) s = fmaf(gu[(long)b * O + o], w[(long)o * I + k], s);
-  dx[i] = s;
+  if (k < I) {
+    int o = row;
+    for (; o + 12 < O; o += 16) {
+      const float w0 = w[(long)o * I + k], w1 = w[(long)(o + 4) * I + k], w2 = w[(long)(o + 8) * I + k],
+                  w3 = w[(long)(o + 12) * I + k];
+      s = fmaf(gu[(long)b * O + o], w0, s);
+      s = fmaf(gu[(long)b * O + o + 4], w1, s);
+      s = fmaf(gu[(long)b * O + o + 8], w2, s);
+      s = fmaf(gu[(long)b * O + o + 12], w3, s);
+    }
+    for (; o < O; o += 4) s = fmaf(gu[(long)b * O + o], w[(long)o * I + k], s);
+  }
+  part[row][col] = s;
+  __syncthreads();
+  if (row == 0 && k < I) dx[(long)b * I + k] = (part[0][col] + part[1][col]) + (part[2][col] + part[3][col]);
 }
 
 struct WgradPlan {
@@ -505,8 +554,8 @@ extern "C" int tmdiff_conv3d_wgrad(const tmdiff_conv3d_desc* d, const float* g, 
   int rc = check_launch("conv3d_wgrad");
   if (rc) return rc;
   const long total = (long)d->Cout * a.cin_g * p.taps;
-  long rb = (total + 255) / 256;
-  if (rb > 4096) rb = 4096;
+  long rb = (total + 63) / 64;
+  if (rb > 8192) rb = 8192;
   wgrad_reduce_kernel<<<(unsigned)rb, 256, 0, st>>>(a.ws, dw, p.slots, d->groups, p.taps, a.cout_g, a.cin_g, total);
   return check_launch("conv3d_wgrad(reduce)");
 }
@@ -515,7 +564,12 @@ extern "C" int tmdiff_channel_sum(const float* x, float* out, int32_t B, int32_t
                                   tmdiff_stream_t stream) {
   using namespace tmdiff;
   TMDIFF_REQUIRE(x && out && B >= 0 && C > 0 && P > 0, "channel_sum: bad arguments");
-  channel_sum_kernel<<<C, 256, 0, as_stream(stream)>>>(x, out, B, C, P, scale);
+  // ~2048 workgroups in total, at least 2048 elements per slice and sample
+  long slices = (2048 + C - 1) / C;
+  if (slices > (P + 2047) / 2048) slices = (P + 2047) / 2048;
+  if (slices < 1) slices = 1;
+  zero_kernel<<<(C + 255) / 256, 256, 0, as_stream(stream)>>>(out, C);
+  channel_sum_kernel<<<dim3(C, (unsigned)slices), 256, 0, as_stream(stream)>>>(x, out, B, C, P, scale);
   return check_launch("channel_sum");
 }
 
@@ -591,8 +645,7 @@ extern "C" int tmdiff_linear_bwd(const float* x, const float* w, const float* bi
     if (rc) return rc;
   }
   if (dx) {
-    const long n = (long)B * I;
-    linear_dx_kernel<<<(unsigned)((n + 255) / 256), 256, 0, st>>>(w, gu, dx, B, I, O);
+    linear_dx_kernel<<<(unsigned)(B * ((I + 63) / 64)), 256, 0, st>>>(w, gu, dx, B, I, O);
     return check_launch("linear_bwd(dx)");
   }
   return TMDIFF_OK;
