@@ -105,10 +105,10 @@ __global__ void __launch_bounds__(256, 2) conv3d_wgrad_kernel(const WgradArgs a)
   constexpr int XE = HN * HH * HW;                                      // haloed box elements
   constexpr int GS = POSB + 1, XS = XE | 1;                             // odd LDS row strides
   constexpr int NT = KS == 3 ? 7 : 1;                                   // accumulators per wave
-  constexpr int GI = 32 * POSB / 256, XI = 32 * XE / 256;               // staged elements per thread
-  static_assert(32 * XE % 256 == 0 && XI <= 64, "the x' box must split evenly over the workgroup");
+  constexpr int XJ = (XE + 63) / 64, GJ = POSB / 64;  // wave-wide pieces per channel row (x': the last one is partial)
+  constexpr int DUMMY = 32 * XS;                     // LDS word that absorbs the lanes of a partial piece
   __shared__ float gt[32 * GS];
-  __shared__ float xt[32 * XS];
+  __shared__ float xt[32 * XS + 1];
 
   const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, l31 = lane & 31, khalf = lane >> 5;
   int id = blockIdx.x;
@@ -119,20 +119,17 @@ __global__ void __launch_bounds__(256, 2) conv3d_wgrad_kernel(const WgradArgs a)
   const int co0 = co_t * 32, ci0 = ci_t * 32;
   const long plane = (long)a.N * a.H * a.W;
 
-  // ---- staging pattern (the same for every box): x' item i covers element q = i*256 + tid of [32 ci][XE].  Its
-  //      (ci, nz, hz, wz) are re-derived from q per box (constant divisions): keeping them costs 25+ registers.
-  const int gp = tid & (POSB - 1), gco = tid >> 7;  // g item i: channel 2*i + gco, position gp of the box
-  const int gpn = gp / (BH * BW), gph = (gp / BW) % BH, gpw = gp % BW;
-
   f32x16 acc[NT];
 #pragma unroll
   for (int j = 0; j < NT; ++j)
 #pragma unroll
     for (int r = 0; r < 16; ++r) acc[j][r] = 0.f;
 
-  float gr[GI], xr[XI];
-  unsigned gmask = 0;
-  unsigned long long xmask = 0;
+  // ---- staging: wave w copies channels 8w .. 8w+7 of both boxes; a load instruction covers 64 consecutive box
+  //      elements of ONE channel, so the channel base is wave-uniform (scalar) and the per-lane position offset is
+  //      shared by all 8 channels: per box XJ + GJ offset computations per lane instead of one per element.
+  float gr[8][GJ], xr[8][XJ];
+  unsigned gok = 0, xok = 0;  // bit j: piece j of this lane lies inside the image
   auto prefetch = [&](long bx) __attribute__((always_inline)) {
     unsigned t = (unsigned)bx;
     const int bw_i = (int)(t % (unsigned)a.nbw); t /= (unsigned)a.nbw;
@@ -140,50 +137,48 @@ __global__ void __launch_bounds__(256, 2) conv3d_wgrad_kernel(const WgradArgs a)
     const int bn_i = (int)(t % (unsigned)a.nbn);
     const int b = (int)(t / (unsigned)a.nbn);
     const int n0 = bn_i * BN, h0 = bh_i * BH, w0 = bw_i * BW;
-    // branch-free, 32-bit offsets from wave-uniform bases (bitwise & on purpose: && would branch around the loads)
-    const unsigned plane32 = (unsigned)plane;
-    {
-      const int n = n0 + gpn, h = h0 + gph, w = w0 + gpw;
-      const bool pok = (n < a.N) & (h < a.H) & (w < a.W);
-      const unsigned off = pok ? (unsigned)((n * a.H + h) * a.W + w) : 0u;
-      const float* gb = a.g + ((long)b * a.Cout + g * a.cout_g + co0) * plane;
-      const int co_left = a.cout_g - co0;
-      gmask = 0;
+    // (bitwise & on purpose: && would branch around the loads)
+    unsigned goff[GJ], xoff[XJ];
+    gok = 0; xok = 0;
 #pragma unroll
-      for (int i = 0; i < GI; ++i) {
-        const int co = 2 * i + gco;
-        const bool ok = pok & (co < co_left);
-        gr[i] = gb[ok ? (unsigned)co * plane32 + off : 0u];
-        gmask |= (unsigned)ok << i;
-      }
+    for (int j = 0; j < GJ; ++j) {
+      const int p = j * 64 + lane;
+      const int n = n0 + p / (BH * BW), h = h0 + (p / BW) % BH, w = w0 + p % BW;
+      const bool ok = (n < a.N) & (h < a.H) & (w < a.W);
+      goff[j] = ok ? (unsigned)((n * a.H + h) * a.W + w) : 0u;
+      gok |= (unsigned)ok << j;
     }
-    const float* xb = a.xp + ((long)b * a.Cin + g * a.cin_g + ci0) * plane;
-    const int ci_left = a.cin_g - ci0;
-    int tid_o = tid;
-    asm volatile("" : "+v"(tid_o));
-    unsigned xm_lo = 0, xm_hi = 0;
 #pragma unroll
-    for (int i = 0; i < XI; ++i) {
-      unsigned q = (unsigned)(i * 256) + (unsigned)tid_o;  // tid_o: tid made opaque per box so that this is not hoisted
-      const unsigned ci = q / XE, e = q % XE;
-      const int nz = e / (HH * HW), hz = (e / HW) % HH, wz = e % HW;
-      const int n = n0 + nz - HALO, h = h0 + hz - HALO, w = w0 + wz - HALO;
-      const bool ok = ((int)ci < ci_left) & ((unsigned)n < (unsigned)a.N) & ((unsigned)h < (unsigned)a.H) &
-                      ((unsigned)w < (unsigned)a.W);
-      xr[i] = xb[ok ? ci * plane32 + (unsigned)((n * a.H + h) * a.W + w) : 0u];
-      if (i < 32) xm_lo |= (unsigned)ok << (i & 31); else xm_hi |= (unsigned)ok << (i & 31);
+    for (int j = 0; j < XJ; ++j) {
+      const int e = j * 64 + lane;
+      const int n = n0 + e / (HH * HW) - HALO, h = h0 + (e / HW) % HH - HALO, w = w0 + e % HW - HALO;
+      const bool ok = (e < XE) & ((unsigned)n < (unsigned)a.N) & ((unsigned)h < (unsigned)a.H) & ((unsigned)w < (unsigned)a.W);
+      xoff[j] = ok ? (unsigned)((n * a.H + h) * a.W + w) : 0u;
+      xok |= (unsigned)ok << j;
     }
-    xmask = (unsigned long long)xm_hi << 32 | xm_lo;
+#pragma unroll
+    for (int c = 0; c < 8; ++c) {
+      const int ch = wv * 8 + c;  // wave-uniform
+      const float* gb = a.g + ((long)b * a.Cout + g * a.cout_g + (co0 + ch < a.cout_g ? co0 + ch : 0)) * plane;
+      const float* xb = a.xp + ((long)b * a.Cin + g * a.cin_g + (ci0 + ch < a.cin_g ? ci0 + ch : 0)) * plane;
+#pragma unroll
+      for (int j = 0; j < GJ; ++j) gr[c][j] = gb[goff[j]];
+#pragma unroll
+      for (int j = 0; j < XJ; ++j) xr[c][j] = xb[xoff[j]];
+    }
   };
   auto stage = [&]() __attribute__((always_inline)) {
-    int tid_s = tid;
-    asm volatile("" : "+v"(tid_s));
 #pragma unroll
-    for (int i = 0; i < GI; ++i) gt[(2 * i + gco) * GS + gp] = (gmask >> i) & 1 ? gr[i] : 0.f;
+    for (int c = 0; c < 8; ++c) {
+      const int ch = wv * 8 + c;
+      const bool gch = co0 + ch < a.cout_g, xch = ci0 + ch < a.cin_g;
 #pragma unroll
-    for (int i = 0; i < XI; ++i) {
-      const unsigned q = (unsigned)(i * 256) + (unsigned)tid_s;
-      xt[(q / XE) * XS + q % XE] = (xmask >> i) & 1 ? xr[i] : 0.f;
+      for (int j = 0; j < GJ; ++j) gt[ch * GS + j * 64 + lane] = (gch & ((gok >> j) & 1)) ? gr[c][j] : 0.f;
+#pragma unroll
+      for (int j = 0; j < XJ; ++j) {
+        const int e = j * 64 + lane;
+        xt[(XE % 64 == 0 || j + 1 < XJ || e < XE) ? ch * XS + e : DUMMY] = (xch & ((xok >> j) & 1)) ? xr[c][j] : 0.f;
+      }
     }
   };
   const float* ga = gt + l31 * GS + khalf;   // A operand of K-step ks: ga[2*ks]
