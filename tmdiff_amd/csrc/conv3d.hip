@@ -418,7 +418,9 @@ int launch(ConvArgs& a, hipStream_t st) {
   if (blocks <= 0 || blocks > 0x7fffffffL) return tmdiff::fail(TMDIFF_E_INVALID, "conv3d: grid of %ld blocks", blocks);
   a.total_blocks = (unsigned)blocks;
   const bool fast = a.cin_g % KC == 0 && a.cout_g % CO == 0 && a.w_vec4;
-  if (a.in_mask)  // training (dropout) path
+  if (a.in_mask && fast)  // training (dropout) path
+    conv3d_mfma_kernel<KS, NS, MSUB, KC, TN, TH, TW, true, true><<<(unsigned)blocks, 256, 0, st>>>(a);
+  else if (a.in_mask)
     conv3d_mfma_kernel<KS, NS, MSUB, KC, TN, TH, TW, false, true><<<(unsigned)blocks, 256, 0, st>>>(a);
   else if (fast)
     conv3d_mfma_kernel<KS, NS, MSUB, KC, TN, TH, TW, true, false><<<(unsigned)blocks, 256, 0, st>>>(a);
