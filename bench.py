@@ -197,7 +197,8 @@ def main():
             "unet_tflops": round(BATCH * GFLOP_PER_SAMPLE * 1e-3 * args.steps / dt, 2),
             "roofline": {"bound": "mfma", "achieved": round(achieved, 2), "peak": PEAK_FP32_MFMA, "unit": "TFLOP/s",
                          "frac": round(achieved / PEAK_FP32_MFMA, 4), "traffic": None,
-                         "kernel": "conv3d_mfma_kernel<KS=3> (fp32 v_mfma_f32_32x32x2_f32)",
+                         "kernel": "3x3x3 conv launches, fp32 v_mfma_f32_32x32x2_f32: conv3d_mfma_kernel<3,..> (fused prologue) "
+                                   "or prologue_apply_kernel + conv3d_dma_kernel<3,..> (staged), chosen per layer",
                          "launches": n3, "avg_launch_us": round(ms3 / max(n3, 1) * 1e3, 2),
                          "algorithmic_gflop_per_launch": round(fl3 / max(n3, 1) / 1e9, 2),
                          "k1_conv": {"launches": n1, "avg_launch_us": round(ms1 / max(n1, 1) * 1e3, 2),

@@ -79,6 +79,17 @@ int tmdiff_conv3d_pack_weights(const float* w, float* packed, int32_t Cout, int3
                                int32_t groups, int32_t mode, tmdiff_stream_t stream);
 int tmdiff_conv3d_fwd(const tmdiff_conv3d_desc* d, tmdiff_stream_t stream);
 
+/* ---- staged variant of tmdiff_conv3d_fwd (same arithmetic, exact fp32, bit-identical results) ----------------
+ * Two launches instead of one: the prologue output x' (and the concatenation of the segments) is written once into
+ * `workspace` ([B, Cin, N, H, W] fp32, tmdiff_conv3d_fwd_staged_workspace_bytes(d) bytes; 0 and NULL allowed when
+ * the input is a single tensor without shift / scale / act / mask), then a convolution whose operands go
+ * L2/HBM -> LDS directly (global_load_lds) so that its instruction stream is MFMAs and operand reads only.
+ * Faster than the fused kernel on every production layer; shapes it does not take (Cin/groups not a multiple of
+ * 4 (k=3) / 8 (k=1), Cout/groups not a multiple of 32) return TMDIFF_E_UNSUPPORTED -- use tmdiff_conv3d_fwd. */
+int tmdiff_conv3d_fwd_staged_supported(const tmdiff_conv3d_desc* d);
+size_t tmdiff_conv3d_fwd_staged_workspace_bytes(const tmdiff_conv3d_desc* d);
+int tmdiff_conv3d_fwd_staged(const tmdiff_conv3d_desc* d, void* workspace, tmdiff_stream_t stream);
+
 /* ---- bf16 compute / fp32 accumulate (WorldView-3 inference) --------------------------
  * Same descriptor and fused prologue / epilogue as tmdiff_conv3d_fwd; activations, bias, residual and output stay
  * fp32 in memory.  The prologue result x' and the weights are rounded to bf16 (round to nearest even), products

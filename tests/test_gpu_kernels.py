@@ -421,3 +421,53 @@ def test_conv3d_bf16_rejects_unsupported(ops):
         ops.conv3d([x], wp, 32, 3, math="bf16", in_mask=torch.ones_like(x))
     with pytest.raises(TmdiffError):
         ops.conv3d([x], wp, 16, 3, math="bf16")                        # Cout not a multiple of 32
+
+
+@pytest.mark.parametrize("case", [
+    dict(B=2, segs=[8, 16, 8], cout=64, k=3, g=1, N=8, H=16, W=24, prologue=True),
+    dict(B=1, segs=[32], cout=32, k=3, g=1, N=4, H=20, W=12, prologue=False),
+    dict(B=3, segs=[16], cout=96, k=3, g=1, N=4, H=8, W=8, prologue=True),
+    dict(B=2, segs=[16, 16, 16], cout=96, k=3, g=3, N=8, H=8, W=8, prologue=False),
+    dict(B=2, segs=[16], cout=64, k=1, g=1, N=4, H=9, W=7, prologue=True),
+    dict(B=1, segs=[64], cout=256, k=3, g=1, N=8, H=8, W=8, prologue=True),       # small-grid tile config
+])
+def test_conv3d_staged_equals_fused(ops, case):
+    """The staged fp32 convolution (prologue pass + global_load_lds kernel) and the fused kernel run the same
+    arithmetic in the same order: bit-identical outputs; and both match the fp64 reference."""
+    torch.manual_seed(23)
+    B, cin, cout, k, g = case["B"], sum(case["segs"]), case["cout"], case["k"], case["g"]
+    shp = (case["N"], case["H"], case["W"])
+    segs = [cu(torch.randn(B, c, *shp)) for c in case["segs"]]
+    w = torch.randn(cout, cin // g, k, k, k) / (cin // g * k ** 3) ** 0.5
+    wp = ops.pack_conv_weight(cu(w), groups=g)
+    kw = dict(groups=g, bias=cu(torch.randn(cout)), residual=cu(torch.randn(B, cout, *shp)), out_scale=0.7)
+    if case["prologue"]:
+        kw.update(in_shift=cu(torch.randn(B, cin)), in_scale=cu(torch.rand(B, cin) + 0.5), in_act=True)
+    d = ops.make_conv_desc(segs, wp, cout, k, torch.empty(B, cout, *shp, device="cuda"), **kw)
+    from tmdiff_amd._lib import lib
+    import ctypes as C
+    assert lib.tmdiff_conv3d_fwd_staged_supported(C.byref(d)) == 1
+    need = lib.tmdiff_conv3d_fwd_staged_workspace_bytes(C.byref(d))
+    assert (need > 0) == (case["prologue"] or len(segs) > 1)
+    y_f = ops.conv3d(segs, wp, cout, k, staged=False, **kw)
+    y_s = ops.conv3d(segs, wp, cout, k, staged=True, **kw)
+    assert torch.equal(y_f, y_s)
+    x = torch.cat([s.cpu() for s in segs], 1).double()
+    if case["prologue"]:
+        x = x + kw["in_shift"].cpu().double()[:, :, None, None, None]
+        x = x * torch.sigmoid(x) * kw["in_scale"].cpu().double()[:, :, None, None, None]
+    ref = (F.conv3d(x, w.double(), kw["bias"].cpu().double(), padding=k // 2, groups=g) + kw["residual"].cpu().double()) * 0.7
+    assert_close(y_s, ref.float(), 2e-5, 2e-6, "staged conv vs fp64")
+
+
+def test_conv3d_staged_rejects_unsupported(ops):
+    from tmdiff_amd._lib import lib, TmdiffError
+    import ctypes as C
+    x = cu(torch.randn(1, 6, 4, 8, 8))
+    w = cu(torch.randn(16, 6, 3, 3, 3))
+    wp = ops.pack_conv_weight(w)
+    d = ops.make_conv_desc([x], wp, 16, 3, torch.empty(1, 16, 4, 8, 8, device="cuda"))
+    assert lib.tmdiff_conv3d_fwd_staged_supported(C.byref(d)) == 0
+    assert lib.tmdiff_conv3d_fwd_staged(C.byref(d), None, None) == -2
+    y = ops.conv3d([x], wp, 16, 3)                 # falls back to the fused kernel by itself
+    assert_close(y, F.conv3d(x.cpu(), w.cpu(), padding=1), 1e-5, 1e-5, "fallback")

@@ -491,6 +491,23 @@ inline WgradPlan plan_wgrad(const tmdiff_conv3d_desc* d) {
 
 }  // namespace
 
+int tmdiff::launch_prologue_apply(const tmdiff_conv3d_desc* d, float* xp, hipStream_t st) {
+  TMDIFF_REQUIRE((long)d->B * d->Cin <= 65535, "prologue_apply: B*Cin = %ld exceeds the grid", (long)d->B * d->Cin);
+  const long plane = (long)d->N * d->H * d->W;
+  ApplyArgs q;
+  q.B = d->B; q.Cin = d->Cin; q.nseg = d->nseg;
+  for (int i = 0; i < 3; ++i) { q.seg_c[i] = i < d->nseg ? d->seg_c[i] : 0; q.seg_x[i] = i < d->nseg ? d->seg_x[i] : nullptr; }
+  q.in_shift = d->in_shift; q.in_scale = d->in_scale; q.in_mask = d->in_mask; q.in_act = d->in_act;
+  q.shift_stride = d->in_shift_stride > 0 ? d->in_shift_stride : (d->in_shift_stride < 0 ? 0 : d->Cin);
+  q.scale_stride = d->in_scale_stride > 0 ? d->in_scale_stride : (d->in_scale_stride < 0 ? 0 : d->Cin);
+  q.xp = xp;
+  q.plane = plane;
+  long pb = (plane + 1023) / 1024;
+  if (pb > 64) pb = 64;
+  prologue_apply_kernel<<<dim3((unsigned)pb, (unsigned)(d->B * d->Cin)), 256, 0, st>>>(q);
+  return check_launch("prologue_apply");
+}
+
 extern "C" size_t tmdiff_conv3d_wgrad_workspace_bytes(const tmdiff_conv3d_desc* d) {
   if (!d || d->B <= 0 || d->groups <= 0 || (d->ksize != 1 && d->ksize != 3)) return 0;
   const WgradPlan p = plan_wgrad(d);
@@ -525,19 +542,10 @@ extern "C" int tmdiff_conv3d_wgrad(const tmdiff_conv3d_desc* d, const float* g, 
   a.g = g; a.ws = reinterpret_cast<float*>(workspace);
   a.xp = d->seg_x[0];
   if (p.needs_xp) {
-    TMDIFF_REQUIRE((long)d->B * d->Cin <= 65535, "conv3d_wgrad: B*Cin = %ld exceeds the grid", (long)d->B * d->Cin);
-    ApplyArgs q;
-    q.B = d->B; q.Cin = d->Cin; q.nseg = d->nseg;
-    for (int i = 0; i < 3; ++i) { q.seg_c[i] = i < d->nseg ? d->seg_c[i] : 0; q.seg_x[i] = i < d->nseg ? d->seg_x[i] : nullptr; }
-    q.in_shift = d->in_shift; q.in_scale = d->in_scale; q.in_mask = d->in_mask; q.in_act = d->in_act;
-    q.shift_stride = d->in_shift_stride > 0 ? d->in_shift_stride : (d->in_shift_stride < 0 ? 0 : d->Cin);
-    q.scale_stride = d->in_scale_stride > 0 ? d->in_scale_stride : (d->in_scale_stride < 0 ? 0 : d->Cin);
-    q.xp = a.ws + p.partial_floats;
-    q.plane = plane;
-    long pb = (plane + 1023) / 1024;
-    if (pb > 64) pb = 64;
-    prologue_apply_kernel<<<dim3((unsigned)pb, (unsigned)(d->B * d->Cin)), 256, 0, st>>>(q);
-    a.xp = q.xp;
+    float* xp = a.ws + p.partial_floats;
+    const int rc = launch_prologue_apply(d, xp, st);
+    if (rc) return rc;
+    a.xp = xp;
   }
   a.nbn = p.nbn; a.nbh = p.nbh; a.nbw = p.nbw; a.tiles_co = p.tiles_co; a.tiles_ci = p.tiles_ci;
   a.splits = p.splits; a.boxes_per_split = p.boxes_per_split; a.total_boxes = p.total_boxes;

@@ -36,6 +36,10 @@ __device__ __forceinline__ float silu_f(float v) {
   return v / (1.0f + __expf(-v));
 }
 
+// x' = act(x + shift[b,c]) * scale[b,c] * mask of the descriptor's (possibly segmented) input, written densely as
+// [B, Cin, N, H, W] (backward.hip).  Used by the weight-gradient kernel and the staged forward convolution.
+int launch_prologue_apply(const tmdiff_conv3d_desc* d, float* xp, hipStream_t st);
+
 }  // namespace tmdiff
 
 #define TMDIFF_REQUIRE(cond, ...) \

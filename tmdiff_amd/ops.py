@@ -111,6 +111,7 @@ TIMER = None      # set to a ConvTimer() to time every conv launch
 
 
 _WS = {}     # device index -> grow-only scratch tensor (bf16-packed conv inputs); reused launch after launch on a stream
+_FP32_STAGED = os.environ.get("TMDIFF_FP32_STAGED", "auto")   # experiments: "0" = fused kernel only, "1"/"auto" = staged where supported
 _BF16_PACK = os.environ.get("TMDIFF_BF16_PACK", "auto")   # experiments: "0" = fused kernel, "1"/"auto" = packed input
 
 
@@ -121,10 +122,11 @@ def _workspace(device, nbytes):
     return ws
 
 
-def conv3d(segs, w_packed, cout, ksize, out=None, math="fp32", pack_input=None, **kw):
+def conv3d(segs, w_packed, cout, ksize, out=None, math="fp32", pack_input=None, staged=None, **kw):
     """math="fp32": exact-fp32 MFMA kernel (w_packed from pack_conv_weight); "bf16": bf16 operands / fp32
     accumulation (w_packed from pack_conv_weight_bf16).  pack_input (bf16 only): True = pack the prologue output to
-    bf16 once and run the staging-free kernel (default), False = one fused kernel."""
+    bf16 once and run the staging-free kernel (default), False = one fused kernel.  staged (fp32 only): True = prologue
+    pass + global_load_lds staged kernel (default where the shape allows), False = the fused kernel."""
     b, _, n, h, w = segs[0].shape
     y = out if out is not None else torch.empty(b, cout, n, h, w, device=segs[0].device, dtype=torch.float32)
     d = make_conv_desc(segs, w_packed, cout, ksize, y, **kw)
@@ -139,7 +141,20 @@ def conv3d(segs, w_packed, cout, ksize, out=None, math="fp32", pack_input=None, 
     elif math == "fp32":
         if not isinstance(w_packed, int) and w_packed.dtype != torch.float32:
             raise TypeError("conv3d(math='fp32') needs weights from pack_conv_weight")
-        fwd, what = lib.tmdiff_conv3d_fwd, "conv3d_fwd"
+        if staged is None:
+            # measured (tools/bench_conv.py, B=32): the staged kernel itself is 3-6 % faster than the fused one, but its
+            # prologue pass costs 8 B per input element -- a net win when the input needs no pass (one plain tensor:
+            # every data-gradient convolution) or is shared by >= 2 channel tiles of a 3x3x3 convolution / is wide.
+            plain = len(segs) == 1 and not (kw.get("in_act") or kw.get("in_shift") is not None or
+                                            kw.get("in_scale") is not None or kw.get("in_mask") is not None)
+            staged = {"0": False, "1": True}.get(_FP32_STAGED, plain or (ksize == 3 and cout // d.groups >= 128)
+                                                 or d.Cin // d.groups >= 384)
+        if staged and lib.tmdiff_conv3d_fwd_staged_supported(C.byref(d)):
+            nb = lib.tmdiff_conv3d_fwd_staged_workspace_bytes(C.byref(d))
+            ws32 = _workspace(y.device, nb).data_ptr() if nb else None
+            fwd, what = (lambda dd, st: lib.tmdiff_conv3d_fwd_staged(dd, ws32, st)), "conv3d_fwd_staged"
+        else:
+            fwd, what = lib.tmdiff_conv3d_fwd, "conv3d_fwd"
     else:
         raise ValueError(f"conv3d: unknown math {math!r}")
     if TIMER is None:
