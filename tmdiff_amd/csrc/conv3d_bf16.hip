@@ -21,14 +21,9 @@
 // registers go through the prologue into LDS (two barriers per chunk).  The other workgroups on the CU cover
 // that hand-off.
 #include <cstdint>
-#include <cstdlib>
 #include <type_traits>
 
 #include "common.h"
-
-#ifndef TMDIFF_BF16_DEBUG
-#define TMDIFF_BF16_DEBUG 0  // experiment switches (results wrong): 1 = no prologue math, 2 = no MFMAs, 4 = no in-loop loads
-#endif
 
 namespace {
 
@@ -238,7 +233,7 @@ __global__ void __launch_bounds__(256, 2) conv3d_bf16_kernel(const BfArgs a) {
 #pragma unroll
       for (int j = 0; j < 8; ++j) {
         float v = xr[i][j] + sh[j];
-        if constexpr (ACT && !(TMDIFF_BF16_DEBUG & 1)) v = tmdiff::silu_f(v);
+        if constexpr (ACT) v = tmdiff::silu_f(v);
         v *= sc[j];
         pk.h[j] = (__bf16)(inb[i] ? v : 0.f);
       }
@@ -252,7 +247,7 @@ __global__ void __launch_bounds__(256, 2) conv3d_bf16_kernel(const BfArgs a) {
   for (int c = 0; c < nchunks; ++c) {
     stage_chunk(c);
     __syncthreads();
-    if (c + 1 < nchunks && !(TMDIFF_BF16_DEBUG & 4)) load_chunk(c + 1);
+    if (c + 1 < nchunks) load_chunk(c + 1);
 #pragma unroll
     for (int p = 0; p < TAPS2 / 2; ++p) {
       union { bf16x8 h; uint4 u; } av[MSUB], bv[NS];
@@ -267,8 +262,7 @@ __global__ void __launch_bounds__(256, 2) conv3d_bf16_kernel(const BfArgs a) {
       for (int s = 0; s < NS; ++s)
 #pragma unroll
         for (int m = 0; m < MSUB; ++m)
-          if (!(TMDIFF_BF16_DEBUG & 2) || c == 0)
-            acc[s][m] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av[m].h, bv[s].h, acc[s][m], 0, 0, 0);
+          acc[s][m] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av[m].h, bv[s].h, acc[s][m], 0, 0, 0);
     }
     __syncthreads();
   }
@@ -737,10 +731,6 @@ extern "C" int tmdiff_conv3d_fwd_bf16(const tmdiff_conv3d_desc* d, void* workspa
     if (cout_g % 64 == 0) return launch_dma<2, 2, 8, 8>(a, xp, st);
     return d->W >= 16 ? launch_dma<4, 1, 8, 16>(a, xp, st) : launch_dma<2, 1, 8, 8>(a, xp, st);
   }
-  if (cout_g % 64 == 0) {
-    static const int wide = getenv("TMDIFF_BF16_WIDE") ? atoi(getenv("TMDIFF_BF16_WIDE")) : 0;
-    if (wide && d->W >= 16) return launch<4, 2, 8, 16>(a, st);
-    return launch<2, 2, 8, 8>(a, st);
-  }
+  if (cout_g % 64 == 0) return launch<2, 2, 8, 8>(a, st);
   return d->W >= 16 ? launch<4, 1, 8, 16>(a, st) : launch<2, 1, 8, 8>(a, st);
 }

@@ -21,15 +21,18 @@ def load(d):
 main = load(sys.argv[1])
 fetch = load(sys.argv[2]) if len(sys.argv) > 2 else {}
 write = load(sys.argv[3]) if len(sys.argv) > 3 else {}
-fl = [e for e in fetch.values() if "conv3d_mfma" in e["name"]]
-wl = [e for e in write.values() if "conv3d_mfma" in e["name"]]
+import re
+KEY = re.compile(r"(conv3d_\w+_kernel|conv1_bf16_kernel|pack_x_bf16_kernel|prologue_apply_kernel)")
+fl = [e for e in fetch.values() if KEY.search(e["name"])]
+wl = [e for e in write.values() if KEY.search(e["name"])]
 i = 0
 for k, e in main.items():
-    if "conv3d_mfma" not in e["name"]:
+    if not KEY.search(e["name"]):
         continue
-    name = e["name"][e["name"].index("kernel<") + 6: e["name"].index(">(") + 1]
+    m = re.search(r"(\w+_kernel)(<[^>]*>)?", e["name"])
+    name = (m.group(1).replace("conv3d_", "").replace("_kernel", "") + (m.group(2) or ""))[:44]
     gui = e.get("GRBM_GUI_ACTIVE", 0); wc = max(e.get("SQ_WAVE_CYCLES", 1), 1)
-    s = f"{name:32s} blocks={e['grid'] // e['wg']:5d} v{e['vgpr']}+a{e['agpr']} lds={e['lds']:>6} dur={e['dur'] / 1e3:8.1f}us clk={gui / 8 / e['dur']:4.2f}GHz " \
+    s = f"{name:44s} blocks={e['grid'] // e['wg']:5d} v{e['vgpr']}+a{e['agpr']} lds={e['lds']:>6} dur={e['dur'] / 1e3:8.1f}us clk={gui / 8 / e['dur']:4.2f}GHz " \
         f"mfma={e.get('SQ_VALU_MFMA_BUSY_CYCLES', 0) / (128 * gui) if gui else 0:5.3f} wait_any={e.get('SQ_WAIT_ANY', 0) / wc:4.2f} " \
         f"wait_inst={e.get('SQ_WAIT_INST_ANY', 0) / wc:4.2f} active={e.get('SQ_ACTIVE_INST_ANY', 0) / wc:4.2f} ldsconf={e.get('SQ_LDS_BANK_CONFLICT', 0) / wc:5.3f}"
     if i < len(fl) and i < len(wl):
