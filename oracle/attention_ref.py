@@ -132,3 +132,40 @@ class SpatialTransformer(nn.Module):
         if not self.use_linear:
             y = self.proj_out(y)
         return y + x
+
+
+# ---- DDPM++ attention block of GeneralModel/Hyper_unet_general.py:471-515 (never instantiated by WavBEST) ----------
+class NIN(nn.Module):
+    """1x1 "network in network": y[b, :, h, w] = x[b, :, h, w] @ W + b (ref :471-480)."""
+
+    def __init__(self, in_dim, num_units):
+        super().__init__()
+        self.W = nn.Parameter(torch.zeros(in_dim, num_units))
+        self.b = nn.Parameter(torch.zeros(num_units))
+
+    def forward(self, x):
+        return torch.einsum("bchw,cu->buhw", x, self.W) + self.b[None, :, None, None]
+
+
+class AttnBlockpp(nn.Module):
+    """ref :483-515.  `channels` is the folded count C*N: the block folds [B,C,N,H,W] -> [B,C*N,H,W], normalises with
+    min(channels/4, 32) groups (eps 1e-6), attends over the H*W positions with scale C^-1/2 (the UNFOLDED C), and
+    returns (x + h)/sqrt(2) when skip_rescale."""
+
+    def __init__(self, channels, skip_rescale=True):
+        super().__init__()
+        self.GroupNorm_0 = nn.GroupNorm(min(channels // 4, 32), channels, eps=1e-6)
+        self.NIN_0, self.NIN_1, self.NIN_2, self.NIN_3 = (NIN(channels, channels) for _ in range(4))
+        self.skip_rescale = skip_rescale
+
+    def forward(self, x):
+        b, c, n, h, w = x.shape
+        xf = x.reshape(b, c * n, h, w)
+        t = self.GroupNorm_0(xf)
+        q, k, v = self.NIN_0(t), self.NIN_1(t), self.NIN_2(t)
+        att = torch.einsum("bcp,bcq->bpq", q.flatten(2), k.flatten(2)) * (int(c) ** -0.5)
+        att = att.softmax(-1)
+        o = torch.einsum("bpq,bcq->bcp", att, v.flatten(2)).reshape(b, c * n, h, w)
+        o = self.NIN_3(o)
+        y = (xf + o).reshape(b, c, n, h, w)
+        return y / (2.0 ** 0.5) if self.skip_rescale else y

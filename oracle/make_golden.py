@@ -49,7 +49,12 @@ def randn(seed, *shape):
     return torch.randn(*shape, generator=torch.Generator(device="cpu").manual_seed(seed))
 
 
+ONLY = set(a for a in sys.argv[1:] if not a.startswith("-"))   # e.g. `make_golden.py attnpp`: rewrite just that file
+
+
 def save(name, **arrays):
+    if ONLY and name not in ONLY:
+        return
     os.makedirs(OUT, exist_ok=True)
     arrays = {k: (v.detach().cpu().numpy() if torch.is_tensor(v) else np.asarray(v)) for k, v in arrays.items()}
     arrays["torch_version"] = np.asarray(torch.__version__)
@@ -284,6 +289,14 @@ def main():
     ff = fill_weights_(RA.FeedForward(64, glu=True), seed=3).eval()
     arrs["geglu_ff"] = ff(randn(170, 3, 10, 64))
     save("attention", **arrs)
+
+    # ---- (12) AttnBlockpp / NIN (Hyper_unet_general.py:471-515; never instantiated by WavBEST) ------
+    # `channels` must be the FOLDED channel count C*N (the block folds 'b c n h w -> b (c n) h w' before its GroupNorm).
+    arrs = {}
+    for tag, (b, c, n, hw, rescale) in {"a": (2, 16, 4, 8, True), "b": (1, 8, 8, 16, False)}.items():
+        m = fill_weights_(RU.AttnBlockpp(c * n, skip_rescale=rescale), seed=5).eval()
+        arrs[f"{tag}_y"] = m(randn(180, b, c, n, hw, hw))
+    save("attnpp", **arrs)
 
 
 if __name__ == "__main__":

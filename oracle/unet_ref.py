@@ -273,6 +273,8 @@ def fill_weights_(module: nn.Module, seed: int = 0):
             elif key.endswith("bias"):
                 mean = 1.0 if key.endswith(".dense.bias") else 0.0
                 ten.copy_(mean + torch.randn(ten.shape, generator=g) * 0.05)
+            elif key.endswith(".b"):                     # NIN bias of AttnBlockpp
+                ten.copy_(torch.randn(ten.shape, generator=g) * 0.05)
             elif key.endswith("weight"):                 # 1-D norm scales (attention ops only)
                 ten.copy_(1.0 + torch.randn(ten.shape, generator=g) * 0.1)
     return module

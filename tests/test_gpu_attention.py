@@ -15,8 +15,8 @@ def cu(t):
     return t.cuda().contiguous()
 
 
-def pair(ref_cls, hip_cls, *args, **kw):
-    ref = U.fill_weights_(ref_cls(*args, **kw), seed=3).eval()
+def pair(ref_cls, hip_cls, *args, seed=3, **kw):
+    ref = U.fill_weights_(ref_cls(*args, **kw), seed=seed).eval()
     hip = hip_cls(*args, **kw)
     hip.load_state_dict(ref.state_dict())
     return ref, hip.cuda().eval()
@@ -78,3 +78,17 @@ def test_modules_vs_reference_fixture(golden):
     x, c1 = randn(171, 1, 64, 8, 8), randn(172, 1, 10, 32)
     with torch.no_grad():
         assert_close(hip(cu(x), context=[cu(c1), cu(c1)]).cpu(), ref(x, context=[c1, c1]), 3e-5, 3e-5, "depth-2 transformer")
+
+
+def test_attnblockpp_vs_reference_fixture(golden):
+    """AttnBlockpp / NIN (ref Hyper_unet_general.py:471-515) on the HIP kernels vs the reference fixture and the oracle."""
+    from tmdiff_amd import Attention as A
+    g = golden("attnpp")
+    for tag, (b, c, n, hw, rescale) in {"a": (2, 16, 4, 8, True), "b": (1, 8, 8, 16, False)}.items():
+        ref, hip = pair(R.AttnBlockpp, A.AttnBlockpp, c * n, skip_rescale=rescale, seed=5)
+        assert set(hip.state_dict()) == set(ref.state_dict())
+        x = randn(180, b, c, n, hw, hw)
+        y = hip(cu(x)).cpu()
+        assert_close(y, g[f"{tag}_y"], 2e-5, 2e-5, f"AttnBlockpp {tag} vs reference")
+        with torch.no_grad():
+            assert_close(y, ref(x), 2e-5, 2e-5, f"AttnBlockpp {tag} vs oracle")

@@ -280,3 +280,12 @@ def test_attention_ops(golden):
         assert_close(m(randn(168, 2, 128, 16, 16), context=randn(169, 2, 77, 768)), g["spatial_transformer"], 1e-5, 1e-5)
         ff = U.fill_weights_(A.FeedForward(64, glu=True), seed=3).eval()
         assert_close(ff(randn(170, 3, 10, 64)), g["geglu_ff"], 1e-5, 1e-5, "geglu ff")
+
+
+def test_attnblockpp(golden):
+    """DDPM++ attention block (ref Hyper_unet_general.py:471-515, never instantiated there): oracle vs the reference."""
+    g = golden("attnpp")
+    for tag, (b, c, n, hw, rescale) in {"a": (2, 16, 4, 8, True), "b": (1, 8, 8, 16, False)}.items():
+        m = U.fill_weights_(A.AttnBlockpp(c * n, skip_rescale=rescale), seed=5).eval()
+        with torch.no_grad():
+            assert_close(m(randn(180, b, c, n, hw, hw)), g[f"{tag}_y"], 1e-5, 1e-5, f"AttnBlockpp {tag}")

@@ -3,7 +3,8 @@
 ``core/Attention.py`` is imported by nothing in TMDiff (SURVEY 0, 2.3) and WavBEST contains no attention layer;
 these classes exist because BASELINE's north star names them.  Module tree and parameter names follow the
 reference (GEGLU :69-76, FeedForward :79-96, SpatialSelfAttention :112-162, CrossAttention :165-214,
-BasicTransformerBlock :266-296, SpatialTransformer :299-362), so its state_dicts load.  Only the vanilla softmax
+BasicTransformerBlock :266-296, SpatialTransformer :299-362), so its state_dicts load; ``NIN`` / ``AttnBlockpp`` are
+the DDPM++ attention block that GeneralModel/Hyper_unet_general.py defines (:471-515) and never instantiates.  Only the vanilla softmax
 path exists (the reference falls back to it when xformers is absent, :31-35, :267-274).  nn.Linear / nn.Conv2d /
 norm modules are parameter containers: the arithmetic is tmdiff_gemm_nt, tmdiff_conv3d_fwd (1x1), tmdiff_attn_fwd,
 tmdiff_group_norm, tmdiff_layer_norm, tmdiff_geglu.
@@ -156,3 +157,46 @@ class SpatialTransformer(nn.Module):
         if not self.use_linear:
             return _conv1x1(self.proj_out, y, residual=x)
         return ops.add(y, x)
+
+
+class NIN(nn.Module):
+    """y[b, :, h, w] = x[b, :, h, w] @ W + b (Hyper_unet_general.py:471-480); W is [in, out]."""
+
+    def __init__(self, in_dim, num_units, init_scale=0.1):
+        super().__init__()
+        w = torch.empty(in_dim, num_units)
+        # DDPM default_init (ref :417-454): fan-avg uniform variance scaling
+        bound = (3.0 * max(init_scale, 1e-10) / ((in_dim + num_units) / 2.0)) ** 0.5
+        self.W = nn.Parameter(w.uniform_(-bound, bound))
+        self.b = nn.Parameter(torch.zeros(num_units))
+
+
+class AttnBlockpp(nn.Module):
+    """Hyper_unet_general.py:483-515 on the HIP kernels.  ``channels`` is the FOLDED channel count C*N (the block
+    folds 'b c n h w -> b (c n) h w' before its GroupNorm); the softmax scale uses the unfolded C, as there."""
+
+    def __init__(self, channels, skip_rescale=True, init_scale=0.0):
+        super().__init__()
+        self.GroupNorm_0 = nn.GroupNorm(num_groups=min(channels // 4, 32), num_channels=channels, eps=1e-6)
+        self.NIN_0 = NIN(channels, channels)
+        self.NIN_1 = NIN(channels, channels)
+        self.NIN_2 = NIN(channels, channels)
+        self.NIN_3 = NIN(channels, channels, init_scale=init_scale)
+        self.skip_rescale = skip_rescale
+
+    @torch.no_grad()
+    def forward(self, x):
+        b, c, n, h, w = x.shape
+        cf = c * n
+        xf = x.contiguous().reshape(b, cf, h, w)
+        gn = self.GroupNorm_0
+        t = ops.group_norm(xf, gn.weight.detach(), gn.bias.detach(), gn.num_groups, gn.eps)
+        tok = t.reshape(b, cf, h * w).transpose(1, 2).contiguous()                        # [B, HW, CF] token-major
+        nin = lambda m, a, res=None: ops.gemm_nt(a, m.W.detach().t().contiguous(), m.b.detach(), res)
+        q, k, v = nin(self.NIN_0, tok), nin(self.NIN_1, tok), nin(self.NIN_2, tok)
+        o = ops.attention(q, k, v, float(int(c) ** -0.5), heads=1)                        # [B, HW, CF]
+        x_tok = xf.reshape(b, cf, h * w).transpose(1, 2).contiguous()
+        y = nin(self.NIN_3, o, x_tok)                                                     # x + NIN_3(h), token-major
+        if self.skip_rescale:
+            y = ops.axpby([y], [2.0 ** -0.5])
+        return y.transpose(1, 2).reshape(b, c, n, h, w).contiguous()
