@@ -110,15 +110,17 @@ class ConvTimer:
 TIMER = None      # set to a ConvTimer() to time every conv launch
 
 
-_WS = {}     # device index -> grow-only scratch tensor (bf16-packed conv inputs); reused launch after launch on a stream
-_FP32_STAGED = os.environ.get("TMDIFF_FP32_STAGED", "auto")   # experiments: "0" = fused kernel only, "1"/"auto" = staged where supported
-_BF16_PACK = os.environ.get("TMDIFF_BF16_PACK", "auto")   # experiments: "0" = fused kernel, "1"/"auto" = packed input
+_WS = {}     # (device index, stream) -> grow-only scratch tensor (prologue outputs / bf16-packed conv inputs); launches
+             # on one stream are ordered, so consecutive convolutions can reuse it; other streams get their own
+_FP32_STAGED = os.environ.get("TMDIFF_FP32_STAGED", "auto")   # experiments: "0" = fused kernel only, "1" = staged wherever supported
+_BF16_PACK = os.environ.get("TMDIFF_BF16_PACK", "auto")       # experiments: "0" = fused kernel, "1"/"auto" = packed input
 
 
 def _workspace(device, nbytes):
-    ws = _WS.get(device.index)
+    key = (device.index, stream_ptr())
+    ws = _WS.get(key)
     if ws is None or ws.numel() < nbytes:
-        ws = _WS[device.index] = torch.empty(nbytes, device=device, dtype=torch.uint8)
+        ws = _WS[key] = torch.empty(nbytes, device=device, dtype=torch.uint8)
     return ws
 
 
