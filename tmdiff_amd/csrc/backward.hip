@@ -535,7 +535,6 @@ extern "C" int tmdiff_conv3d_wgrad(const tmdiff_conv3d_desc* d, const float* g, 
   TMDIFF_REQUIRE(p.total_boxes < (1L << 31) && (long)d->N * d->H * d->W * 32 < (1L << 31),
                  "conv3d_wgrad: tensor too large for 32-bit box / offset arithmetic");
   hipStream_t st = as_stream(stream);
-  const long plane = (long)d->N * d->H * d->W;
   WgradArgs a;
   a.B = d->B; a.N = d->N; a.H = d->H; a.W = d->W; a.Cin = d->Cin; a.Cout = d->Cout;
   a.groups = d->groups; a.cin_g = d->Cin / d->groups; a.cout_g = d->Cout / d->groups;

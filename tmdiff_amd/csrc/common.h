@@ -40,6 +40,9 @@ __device__ __forceinline__ float silu_f(float v) {
 // [B, Cin, N, H, W] (backward.hip).  Used by the weight-gradient kernel and the staged forward convolution.
 int launch_prologue_apply(const tmdiff_conv3d_desc* d, float* xp, hipStream_t st);
 
+// 1x1x1 forward through the LDS-free bandwidth kernel (conv1.hip); TMDIFF_E_UNSUPPORTED = shape not taken.
+int conv1_fp32_try(const tmdiff_conv3d_desc* d, hipStream_t st);
+
 }  // namespace tmdiff
 
 #define TMDIFF_REQUIRE(cond, ...) \

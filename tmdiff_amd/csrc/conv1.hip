@@ -1,0 +1,188 @@
+// 1x1x1 convolution on the exact-fp32 matrix cores, as a bandwidth kernel.
+//
+// res_conv (ResBlockModulateBEST, Hyper_unet_general.py:231, :248) and Conv_2 (WaveletUPorDown :361, :389) are
+// 1x1x1: 2*Cin*Cout/(4*(Cin+Cout)) FLOP per byte, i.e. HBM-bound for the 32..256-channel layers.  The generic
+// implicit-GEMM kernel stages them through LDS like a 3x3x3 convolution and reaches ~3 TB/s; this kernel has no LDS:
+//   MFMA columns = 32 consecutive positions, K step = 2 input channels (v_mfma_f32_32x32x2_f32):
+//   lane (col, khalf) loads x[channel 2q+khalf][position col] straight from the activations -- one dword, coalesced
+//   over the positions -- applies the prologue, and that IS the B operand; the A operand (packed weights
+//   [ci][co], tmdiff_conv3d_pack_weights) is one 4/8-byte load per lane from L2.
+// A workgroup = 4 waves x (NS x 32 positions) x (MSUB x 32 channels); 16 input channels (8 K-steps) are in flight
+// in registers while the previous 16 are multiplied.  Same accumulation order as the generic kernel.
+#include "common.h"
+
+namespace {
+
+using f32x16 = __attribute__((ext_vector_type(16))) float;
+
+constexpr int G = 8;  // K-steps per register group (16 input channels)
+
+__device__ const float kZeros16[16] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+__device__ const float kOnes16[16] = {1.f, 1.f, 1.f, 1.f, 1.f, 1.f, 1.f, 1.f, 1.f, 1.f, 1.f, 1.f, 1.f, 1.f, 1.f, 1.f};
+
+struct K1Args {
+  int B, Cin, Cout, cin_g, cout_g, groups;
+  int seg_c[3];
+  const float* seg_x[3];
+  const float* wp;
+  const float* bias;
+  float bias_scale;
+  const float* in_shift;
+  const float* in_scale;
+  int shift_stride, scale_stride;
+  const float* residual;
+  float out_scale;
+  float* y;
+  long plane;
+  int ptiles, tiles_co;
+};
+
+template <int NS, int MSUB, bool ACT>
+__global__ void __launch_bounds__(256, 2) conv1_fp32_kernel(const K1Args a) {
+  constexpr int CO = 32 * MSUB;
+  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+  const int l31 = lane & 31, khalf = lane >> 5;
+  unsigned id = blockIdx.x;
+  const int co_tile = __builtin_amdgcn_readfirstlane(id % a.tiles_co); id /= a.tiles_co;
+  const int ptile = __builtin_amdgcn_readfirstlane(id % a.ptiles); id /= a.ptiles;
+  const int g = __builtin_amdgcn_readfirstlane(id % a.groups);
+  const int b = __builtin_amdgcn_readfirstlane(id / a.groups);
+  const int co0 = co_tile * CO;
+  const long plane = a.plane;
+  const int ngroups = a.cin_g / (2 * G);
+
+  unsigned pos[NS];
+  bool pok[NS];
+#pragma unroll
+  for (int s = 0; s < NS; ++s) {
+    const long p = (long)ptile * (4 * NS * 32) + (wv * NS + s) * 32 + l31;
+    pok[s] = p < plane;
+    pos[s] = (unsigned)(pok[s] ? p : plane - 1);  // clamped loads, no store
+  }
+  // lane part of every x offset inside a 16-channel group: channel 2j + khalf, position pos[s]
+  const unsigned chan_off = (unsigned)khalf * (unsigned)plane;
+  const float* wg = a.wp + (long)g * a.cin_g * a.cout_g + (long)khalf * a.cout_g + co0 + l31 * MSUB;
+
+  f32x16 acc[NS][MSUB];
+#pragma unroll
+  for (int s = 0; s < NS; ++s)
+#pragma unroll
+    for (int m = 0; m < MSUB; ++m)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[s][m][r] = 0.f;
+
+  float xr[2][G][NS], wr[2][G][MSUB], shr[2][G], scr[2][G];
+  auto load_group = [&](int q, int buf) __attribute__((always_inline)) {
+    const int cg = g * a.cin_g + q * 2 * G;  // first of 16 channels; they lie in one input segment
+    const float* src;
+    int cl, segc;
+    if (cg < a.seg_c[0]) src = a.seg_x[0], cl = cg, segc = a.seg_c[0];
+    else if (cg < a.seg_c[0] + a.seg_c[1]) src = a.seg_x[1], cl = cg - a.seg_c[0], segc = a.seg_c[1];
+    else src = a.seg_x[2], cl = cg - a.seg_c[0] - a.seg_c[1], segc = a.seg_c[2];
+    const float* base = src + ((long)b * segc + cl) * plane;
+    const float* shp = a.in_shift ? a.in_shift + (long)b * a.shift_stride + cg : kZeros16;
+    const float* scp = a.in_scale ? a.in_scale + (long)b * a.scale_stride + cg : kOnes16;
+    const float* wq = wg + (long)q * 2 * G * a.cout_g;
+#pragma unroll
+    for (int j = 0; j < G; ++j) {
+#pragma unroll
+      for (int s = 0; s < NS; ++s) xr[buf][j][s] = base[(unsigned)(2 * j) * (unsigned)plane + chan_off + pos[s]];
+      shr[buf][j] = shp[2 * j + khalf];
+      scr[buf][j] = scp[2 * j + khalf];
+      if constexpr (MSUB == 2) {
+        const float2 t = *reinterpret_cast<const float2*>(wq + (long)(2 * j) * a.cout_g);
+        wr[buf][j][0] = t.x, wr[buf][j][1] = t.y;
+      } else {
+        wr[buf][j][0] = wq[(long)(2 * j) * a.cout_g];
+      }
+    }
+  };
+  auto mfma_group = [&](int buf) __attribute__((always_inline)) {
+#pragma unroll
+    for (int j = 0; j < G; ++j) {
+      float bv[NS];
+#pragma unroll
+      for (int s = 0; s < NS; ++s) {
+        float v = xr[buf][j][s] + shr[buf][j];
+        if constexpr (ACT) v = tmdiff::silu_f(v);
+        bv[s] = v * scr[buf][j];
+      }
+#pragma unroll
+      for (int s = 0; s < NS; ++s)
+#pragma unroll
+        for (int m = 0; m < MSUB; ++m)
+          acc[s][m] = __builtin_amdgcn_mfma_f32_32x32x2f32(wr[buf][j][m], bv[s], acc[s][m], 0, 0, 0);
+    }
+  };
+  load_group(0, 0);
+  for (int q = 0; q < ngroups; q += 2) {
+    if (q + 1 < ngroups) load_group(q + 1, 1);
+    mfma_group(0);
+    if (q + 1 < ngroups) {
+      if (q + 2 < ngroups) load_group(q + 2, 0);
+      mfma_group(1);
+    }
+  }
+
+  // epilogue: col = position, row (r&3) + 8*(r>>2) + 4*khalf = channel
+#pragma unroll
+  for (int m = 0; m < MSUB; ++m) {
+    const int cbase = g * a.cout_g + co0 + m * 32 + 4 * khalf;
+#pragma unroll
+    for (int s = 0; s < NS; ++s) {
+      const long obase = ((long)b * a.Cout + cbase) * plane + pos[s];
+      float res[16], bs[16];
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int row = (r & 3) + 8 * (r >> 2);
+        res[r] = a.residual ? a.residual[obase + row * plane] : 0.f;
+        bs[r] = a.bias ? a.bias[cbase + row] * a.bias_scale : 0.f;
+      }
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int row = (r & 3) + 8 * (r >> 2);
+        if (pok[s]) a.y[obase + row * plane] = (acc[s][m][r] + bs[r] + res[r]) * a.out_scale;
+      }
+    }
+  }
+}
+
+template <int NS, int MSUB>
+int launch(K1Args& a, int in_act, hipStream_t st) {
+  a.ptiles = (int)((a.plane + 4 * NS * 32 - 1) / (4 * NS * 32));
+  a.tiles_co = a.cout_g / (32 * MSUB);
+  const long blocks = (long)a.B * a.groups * a.ptiles * a.tiles_co;
+  if (blocks <= 0 || blocks > 0x7fffffffL) return tmdiff::fail(TMDIFF_E_INVALID, "conv1: grid of %ld blocks", blocks);
+  if (in_act) conv1_fp32_kernel<NS, MSUB, true><<<(unsigned)blocks, 256, 0, st>>>(a);
+  else conv1_fp32_kernel<NS, MSUB, false><<<(unsigned)blocks, 256, 0, st>>>(a);
+  return tmdiff::check_launch("conv3d_fwd (1x1x1 bandwidth kernel)");
+}
+
+}  // namespace
+
+// 1x1x1 forward through the bandwidth kernel.  Returns TMDIFF_E_UNSUPPORTED (without touching the error string)
+// for shapes it does not take; tmdiff_conv3d_fwd then uses the generic kernel.  `d` has been validated by the caller.
+int tmdiff::conv1_fp32_try(const tmdiff_conv3d_desc* d, hipStream_t st) {
+  if (d->ksize != 1 || d->in_mask) return TMDIFF_E_UNSUPPORTED;
+  const int cin_g = d->Cin / d->groups, cout_g = d->Cout / d->groups;
+  if (cin_g % (2 * G) || cout_g % 32) return TMDIFF_E_UNSUPPORTED;
+  for (int i = 0; i < d->nseg; ++i)
+    if (d->seg_c[i] % (2 * G)) return TMDIFF_E_UNSUPPORTED;
+  const long plane = (long)d->N * d->H * d->W;
+  if (plane * 2 * G >= (1L << 31)) return TMDIFF_E_UNSUPPORTED;
+  K1Args a;
+  a.B = d->B; a.Cin = d->Cin; a.Cout = d->Cout; a.cin_g = cin_g; a.cout_g = cout_g; a.groups = d->groups;
+  for (int i = 0; i < 3; ++i) {
+    a.seg_c[i] = i < d->nseg ? d->seg_c[i] : (1 << 28);
+    a.seg_x[i] = i < d->nseg ? d->seg_x[i] : d->seg_x[0];
+  }
+  a.wp = d->w_packed; a.bias = d->bias; a.bias_scale = d->bias_scale;
+  a.in_shift = d->in_shift; a.in_scale = d->in_scale;
+  a.shift_stride = d->in_shift_stride > 0 ? d->in_shift_stride : (d->in_shift_stride < 0 ? 0 : d->Cin);
+  a.scale_stride = d->in_scale_stride > 0 ? d->in_scale_stride : (d->in_scale_stride < 0 ? 0 : d->Cin);
+  a.residual = d->residual; a.out_scale = d->out_scale; a.y = d->y;
+  a.plane = plane;
+  // channel tiles follow the weight packing: 64-channel interleaved rows when cout_g % 64 == 0
+  if (cout_g % 64 == 0) return launch<2, 2>(a, d->in_act, st);
+  return launch<2, 1>(a, d->in_act, st);
+}

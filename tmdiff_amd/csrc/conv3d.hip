@@ -471,6 +471,11 @@ extern "C" int tmdiff_conv3d_fwd(const tmdiff_conv3d_desc* d, tmdiff_stream_t st
   TMDIFF_REQUIRE(d->w_packed && d->y, "conv3d_fwd: NULL weights/output");
   TMDIFF_REQUIRE((long)d->N * d->H * d->W < (1L << 31), "conv3d_fwd: plane too large for 32-bit offsets");
 
+  if (d->ksize == 1) {  // bandwidth kernel for the shapes it takes (every production 1x1x1 layer)
+    const int rc = conv1_fp32_try(d, as_stream(stream));
+    if (rc != TMDIFF_E_UNSUPPORTED) return rc;
+  }
+
   ConvArgs a;
   a.B = d->B; a.N = d->N; a.H = d->H; a.W = d->W;
   a.Cin = d->Cin; a.Cout = d->Cout; a.groups = d->groups;

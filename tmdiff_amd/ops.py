@@ -147,11 +147,12 @@ def conv3d(segs, w_packed, cout, ksize, out=None, math="fp32", pack_input=None, 
             # measured (tools/bench_conv.py, B=32): the staged kernel itself is 3-6 % faster than the fused one, but its
             # prologue pass costs 8 B per input element -- a net win when the input needs no pass (one plain tensor:
             # every data-gradient convolution), is shared by >= 2 channel tiles of a 3x3x3 convolution, is wide, or carries a
-            # dropout mask (the fused kernel reads the mask inside its MFMA stream).
+            # dropout mask (the fused kernel reads the mask inside its MFMA stream).  1x1x1 layers have their own
+            # bandwidth kernel behind tmdiff_conv3d_fwd.
             plain = len(segs) == 1 and not (kw.get("in_act") or kw.get("in_shift") is not None or
                                             kw.get("in_scale") is not None or kw.get("in_mask") is not None)
-            staged = {"0": False, "1": True}.get(_FP32_STAGED, plain or (ksize == 3 and cout // d.groups >= 128)
-                                                 or d.Cin // d.groups >= 384 or kw.get("in_mask") is not None)
+            staged = {"0": False, "1": True}.get(_FP32_STAGED, ksize == 3 and (
+                plain or cout // d.groups >= 128 or d.Cin // d.groups >= 384 or kw.get("in_mask") is not None))
         if staged and lib.tmdiff_conv3d_fwd_staged_supported(C.byref(d)):
             nb = lib.tmdiff_conv3d_fwd_staged_workspace_bytes(C.byref(d))
             ws32 = _workspace(y.device, nb).data_ptr() if nb else None
