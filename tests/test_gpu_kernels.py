@@ -471,3 +471,14 @@ def test_conv3d_staged_rejects_unsupported(ops):
     assert lib.tmdiff_conv3d_fwd_staged(C.byref(d), None, None) == -2
     y = ops.conv3d([x], wp, 16, 3)                 # falls back to the fused kernel by itself
     assert_close(y, F.conv3d(x.cpu(), w.cpu(), padding=1), 1e-5, 1e-5, "fallback")
+
+
+def test_empty_batch_all_forward_variants(ops):
+    """B == 0 is a no-op for the fused, staged, bf16 and 1x1x1 forward entry points (nothing read or written)."""
+    w3, w1 = cu(torch.randn(32, 16, 3, 3, 3)), cu(torch.randn(32, 16, 1, 1, 1))
+    x = torch.empty(0, 16, 4, 8, 8, device="cuda")
+    for w, k in ((w3, 3), (w1, 1)):
+        for kw in (dict(staged=False), dict(staged=True), dict(math="bf16", pack_input=True), dict(math="bf16", pack_input=False)):
+            wp = ops.pack_conv_weight_bf16(w) if kw.get("math") == "bf16" else ops.pack_conv_weight(w)
+            y = ops.conv3d([x], wp, 32, k, in_act=True, **kw)
+            assert y.shape == (0, 32, 4, 8, 8)
