@@ -373,21 +373,22 @@ __global__ void __launch_bounds__(256, 2) conv3d_bf16_dma_kernel(const BfArgs a,
   }
   const uint4* wg = a.wp + (long)g * nchunks * TAPS2 * a.cout_g;
 
-  auto issue = [&](int c, uint4* st) __attribute__((always_inline)) {
-    const uint4* xc = xg + (long)c * plane;
-#pragma unroll
-    for (int k = 0; k < XK; ++k) {
+  // piece i of this wave for chunk c: i < XK = input pieces, then the weight pieces
+  constexpr int NPIECE = XK + WK;
+  static_assert(NPIECE <= TAPS2 / 2, "one piece is issued per tap pair");
+  auto issue_piece = [&](auto ic, int c, uint4* st) __attribute__((always_inline)) {
+    constexpr int i = decltype(ic)::value;
+    if constexpr (i < XK) {
+      constexpr int k = i;
       const int q = wv + 4 * k;
       if (XINST % 4 == 0 || q < XINST) {
-        const uint4* src = xpos[k] >= 0 ? xc + xpos[k] : &kZeroUnit;
+        const uint4* src = xpos[k] >= 0 ? xg + (long)c * plane + xpos[k] : &kZeroUnit;
         dma_piece(src, st + q * 64);
       }
-    }
-    const uint4* wc = wg + (long)c * TAPS2 * a.cout_g;
-#pragma unroll
-    for (int k = 0; k < WK; ++k) {
+    } else if constexpr (i < NPIECE) {
+      constexpr int k = i - XK;
       const int q = wv + 4 * k;
-      if (WINST % 4 == 0 || q < WINST) dma_piece(wc + wsrc[k], st + XU + q * 64);
+      if (WINST % 4 == 0 || q < WINST) dma_piece(wg + (long)c * TAPS2 * a.cout_g + wsrc[k], st + XU + q * 64);
     }
   };
 
@@ -415,7 +416,10 @@ __global__ void __launch_bounds__(256, 2) conv3d_bf16_dma_kernel(const BfArgs a,
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[s][m][r] = 0.f;
 
-  auto mfma_chunk = [&](const uint4* st) __attribute__((always_inline)) {
+  // While chunk c is multiplied, one piece of chunk c_next is issued behind the last MFMA of each of the first NPIECE
+  // tap pairs: issued in a burst at the start of a chunk, the pieces cost the wave ~0.6 us in which it feeds no
+  // MFMA (measured: MFMA-only 1.5 us + DMA-only 1.15 us per chunk added up to 2.6 us).
+  auto mfma_chunk = [&](const uint4* st, int c_next, uint4* st_next) __attribute__((always_inline)) {
     constexpr int per_row = TW / 8;
     union Frag { bf16x8 h; uint4 u; };
     Frag av[2][MSUB], bv[2][NS];
@@ -441,6 +445,11 @@ __global__ void __launch_bounds__(256, 2) conv3d_bf16_dma_kernel(const BfArgs a,
           if constexpr (p + 1 < TAPS2 / 2) fetch(std::integral_constant<int, p + 1>{});
           __builtin_amdgcn_sched_barrier(0);
         }
+        if constexpr (j == NS * MSUB - 1 && p < NPIECE) {
+          __builtin_amdgcn_sched_barrier(0);
+          issue_piece(std::integral_constant<int, p>{}, c_next, st_next);
+          __builtin_amdgcn_sched_barrier(0);
+        }
       });
       __builtin_amdgcn_sched_barrier(0);
     });
@@ -448,15 +457,15 @@ __global__ void __launch_bounds__(256, 2) conv3d_bf16_dma_kernel(const BfArgs a,
 
   // two stages, one barrier per chunk: while chunk c is multiplied out of one stage the pieces of chunk c+1 land in
   // the other; the barrier at the end of a chunk says "everyone has read this stage and my pieces have landed".
-  issue(0, st0);
+  static_for<0, NPIECE>([&](auto ic) __attribute__((always_inline)) { issue_piece(ic, 0, st0); });
   __syncthreads();
   for (int c = 0; c < nchunks; c += 2) {
-    if (c + 1 < nchunks) issue(c + 1, st1);
-    mfma_chunk(st0);
+    // (past the last chunk the pieces of chunk 0 are fetched again into the idle stage: valid addresses, nobody
+    //  reads them, and the MFMA stream stays free of branches)
+    mfma_chunk(st0, c + 1 < nchunks ? c + 1 : 0, st1);
     __syncthreads();
     if (c + 1 < nchunks) {
-      if (c + 2 < nchunks) issue(c + 2, st0);
-      mfma_chunk(st1);
+      mfma_chunk(st1, c + 2 < nchunks ? c + 2 : 0, st0);
       __syncthreads();
     }
   }
