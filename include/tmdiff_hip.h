@@ -84,8 +84,10 @@ int tmdiff_conv3d_fwd(const tmdiff_conv3d_desc* d, tmdiff_stream_t stream);
  * `workspace` ([B, Cin, N, H, W] fp32, tmdiff_conv3d_fwd_staged_workspace_bytes(d) bytes; 0 and NULL allowed when
  * the input is a single tensor without shift / scale / act / mask), then a convolution whose operands go
  * L2/HBM -> LDS directly (global_load_lds) so that its instruction stream is MFMAs and operand reads only.
- * Faster than the fused kernel on every production layer; shapes it does not take (Cin/groups not a multiple of
- * 4 (k=3) / 8 (k=1), Cout/groups not a multiple of 32) return TMDIFF_E_UNSUPPORTED -- use tmdiff_conv3d_fwd. */
+ * The kernel itself is 3-6 % faster than the fused one; with the prologue pass it wins where that pass is absent or
+ * amortised (plain inputs such as every data-gradient convolution, >= 128 output channels).  3x3x3 only; shapes it does
+ * not take (Cin/groups not a multiple of 4, Cout/groups not a multiple of 32, ksize 1) return TMDIFF_E_UNSUPPORTED --
+ * use tmdiff_conv3d_fwd. */
 int tmdiff_conv3d_fwd_staged_supported(const tmdiff_conv3d_desc* d);
 size_t tmdiff_conv3d_fwd_staged_workspace_bytes(const tmdiff_conv3d_desc* d);
 int tmdiff_conv3d_fwd_staged(const tmdiff_conv3d_desc* d, void* workspace, tmdiff_stream_t stream);

@@ -1,4 +1,4 @@
-// conv3d 3x3x3 / 1x1x1 on the exact-fp32 matrix cores (v_mfma_f32_32x32x2_f32), "staged" variant.
+// conv3d 3x3x3 on the exact-fp32 matrix cores (v_mfma_f32_32x32x2_f32), "staged" variant.
 //
 // Same arithmetic, tiling and LDS operand layout as conv3d_mfma_kernel (conv3d.hip); what differs is how a chunk
 // of input channels reaches LDS.  There, a workgroup loads it into registers, applies the prologue and writes it
@@ -123,18 +123,19 @@ __global__ void __launch_bounds__(256, 2) conv3d_dma_kernel(const DmaArgs a) {
   const float* wg = a.wp + (long)g * a.cin_g * G::TAPS * a.cout_g + co0;
   const float* zero = reinterpret_cast<const float*>(&kZero4);
 
-  auto issue = [&](int c, float* st) __attribute__((always_inline)) {
-    const float* xc = xg + (long)c * KC * plane;
-#pragma unroll
-    for (int k = 0; k < XK; ++k) {
+  // piece i of this wave for chunk c: i < XK = input pieces (dwords), then the weight pieces (16 bytes)
+  constexpr int NPIECE = XK + WK;
+  auto issue_piece = [&](auto ic, int c, float* st) __attribute__((always_inline)) {
+    constexpr int i = decltype(ic)::value;
+    if constexpr (i < XK) {
+      constexpr int k = i;
       const int q = wv + 4 * k;
-      if (G::XP % 4 == 0 || q < G::XP) dma_b32(xsrc[k] >= 0 ? xc + xsrc[k] : zero, st + q * 64);
-    }
-    const float* wc = wg + (long)c * KC * G::TAPS * a.cout_g;
-#pragma unroll
-    for (int k = 0; k < WK; ++k) {
+      if (G::XP % 4 == 0 || q < G::XP) dma_b32(xsrc[k] >= 0 ? xg + (long)c * KC * plane + xsrc[k] : zero, st + q * 64);
+    } else if constexpr (i < NPIECE) {
+      constexpr int k = i - XK;
       const int q = wv + 4 * k;
-      if (G::WP % 4 == 0 || q < G::WP) dma_b128(wsrc[k] >= 0 ? wc + wsrc[k] : zero, st + G::X_FLOATS + q * 256);
+      if (G::WP % 4 == 0 || q < G::WP)
+        dma_b128(wsrc[k] >= 0 ? wg + (long)c * KC * G::TAPS * a.cout_g + wsrc[k] : zero, st + G::X_FLOATS + q * 256);
     }
   };
 
@@ -162,7 +163,11 @@ __global__ void __launch_bounds__(256, 2) conv3d_dma_kernel(const DmaArgs a) {
 
   constexpr int MF = NS * MSUB;
   constexpr int KSTEPS = (KC / 2) * G::TAPS;
-  auto mfma_chunk = [&](const float* st) __attribute__((always_inline)) {
+  // While chunk c is multiplied, the pieces of chunk c_next are issued one at a time behind MFMAs, spread evenly over
+  // the K-steps (a burst at the start of the chunk keeps the wave away from the matrix pipe for its whole issue time).
+  constexpr int PSTRIDE = KSTEPS / NPIECE > 0 ? KSTEPS / NPIECE : 1;
+  static_assert(NPIECE <= KSTEPS, "at most one piece per K-step");
+  auto mfma_chunk = [&](const float* st, int c_next, float* st_next) __attribute__((always_inline)) {
     float av[2][MSUB], bv[2][NS];
     auto fetch = [&](auto ksc) __attribute__((always_inline)) {
       constexpr int ks = decltype(ksc)::value;
@@ -192,20 +197,25 @@ __global__ void __launch_bounds__(256, 2) conv3d_dma_kernel(const DmaArgs a) {
           if constexpr (ks + 1 < KSTEPS) fetch(std::integral_constant<int, ks + 1>{});
           __builtin_amdgcn_sched_barrier(0);
         }
+        if constexpr (j == MF - 1 && ks % PSTRIDE == 0 && ks / PSTRIDE < NPIECE) {
+          __builtin_amdgcn_sched_barrier(0);
+          issue_piece(std::integral_constant<int, ks / PSTRIDE>{}, c_next, st_next);
+          __builtin_amdgcn_sched_barrier(0);
+        }
       });
       __builtin_amdgcn_sched_barrier(0);
     });
   };
 
-  issue(0, st0);
+  static_for<0, NPIECE>([&](auto ic) __attribute__((always_inline)) { issue_piece(ic, 0, st0); });
   __syncthreads();
   for (int c = 0; c < nchunks; c += 2) {
-    if (c + 1 < nchunks) issue(c + 1, st1);
-    mfma_chunk(st0);
+    // (past the last chunk the pieces of chunk 0 are fetched again into the idle stage: valid addresses, nobody
+    //  reads them, and the MFMA stream stays free of branches)
+    mfma_chunk(st0, c + 1 < nchunks ? c + 1 : 0, st1);
     __syncthreads();
     if (c + 1 < nchunks) {
-      if (c + 2 < nchunks) issue(c + 2, st0);
-      mfma_chunk(st1);
+      mfma_chunk(st1, c + 2 < nchunks ? c + 2 : 0, st0);
       __syncthreads();
     }
   }
@@ -263,10 +273,10 @@ bool needs_apply(const tmdiff_conv3d_desc* d) {
 
 // shapes the staged kernel takes (every production layer); others stay on the fused kernel
 bool staged_ok(const tmdiff_conv3d_desc* d) {
-  if (!d || (d->ksize != 1 && d->ksize != 3) || (d->groups != 1 && d->groups != 3)) return false;
+  if (!d || d->ksize != 3 || (d->groups != 1 && d->groups != 3)) return false;  // 1x1x1 has its own kernel (conv1.hip)
   if (d->Cin <= 0 || d->Cout <= 0 || d->Cin % d->groups || d->Cout % d->groups) return false;
   const int cin_g = d->Cin / d->groups, cout_g = d->Cout / d->groups;
-  return cin_g % (d->ksize == 3 ? 4 : 8) == 0 && cout_g % 32 == 0;
+  return cin_g % 4 == 0 && cout_g % 32 == 0;
 }
 
 }  // namespace
@@ -314,11 +324,7 @@ extern "C" int tmdiff_conv3d_fwd_staged(const tmdiff_conv3d_desc* d, void* works
   const bool c64 = a.cout_g % 64 == 0;
   const long wg256 = (long)d->B * d->groups * ((d->N + 3) / 4) * ((d->H + 7) / 8) * ((d->W + 7) / 8) * ((a.cout_g + 63) / 64);
   const bool small_grid = c64 && wg256 < 2 * 256 && d->N > 2;
-  if (d->ksize == 3) {
-    if (small_grid) return launch<3, 1, 2, 4, 2, 8, 8>(a, st);
-    if (c64) return launch<3, 2, 2, 4, 4, 8, 8>(a, st);
-    return d->W >= 16 ? launch<3, 4, 1, 4, 4, 8, 16>(a, st) : launch<3, 2, 1, 4, 4, 8, 8>(a, st);
-  }
-  if (c64) return launch<1, 2, 2, 8, 4, 8, 8>(a, st);
-  return d->W >= 16 ? launch<1, 4, 1, 8, 4, 8, 16>(a, st) : launch<1, 2, 1, 8, 4, 8, 8>(a, st);
+  if (small_grid) return launch<3, 1, 2, 4, 2, 8, 8>(a, st);
+  if (c64) return launch<3, 2, 2, 4, 4, 8, 8>(a, st);
+  return d->W >= 16 ? launch<3, 4, 1, 4, 4, 8, 16>(a, st) : launch<3, 2, 1, 4, 4, 8, 8>(a, st);
 }
