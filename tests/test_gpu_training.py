@@ -1,5 +1,7 @@
 """GPU parity of the finetune path: backward kernels against PyTorch CPU autograd, the whole training loss and
 its parameter gradients against the reference fixture (tests/golden/train.npz) and the oracle."""
+import os
+
 import numpy as np
 import pytest
 import torch
@@ -213,3 +215,48 @@ def test_trainer_wrapper_roundtrip(tmp_path):
     m2.test(continous=False, prompt="WV3")
     vis = m2.get_current_visuals()
     assert vis["SR"].shape[1:] == (8, 16, 16) and torch.isfinite(vis["SR"]).all()
+
+
+def test_finetune_driver_end_to_end(tmp_path):
+    """python -m tmdiff_amd.train on tiny npz datasets: random dataset choice, optimizer steps, validation with .mat
+    output, checkpoint; then a val-phase run that resumes from that checkpoint (ref driver :56-180)."""
+    import json
+    import scipy.io as scio
+    from tmdiff_amd import train
+
+    def dataset(name, n, c, scale):
+        g = np.random.default_rng(len(name))
+        np.savez(str(tmp_path / name), gt=g.integers(0, scale, (n, c, 16, 16)), lms=g.integers(0, scale, (n, c, 16, 16)),
+                 ms=g.integers(0, scale, (n, c, 4, 4)), pan=g.integers(0, scale, (n, 1, 16, 16)))
+        return str(tmp_path / name)
+
+    tr = dict(batch_size=2, num_workers=0, use_shuffle=True, data_len=-1)
+    opt = {"name": "t", "phase": "train", "gpu_ids": [0],
+           "path": {"log": "logs", "results": "results", "checkpoint": "checkpoint", "resume": None},
+           "datasets": {"train_qb": dict(tr, dataroot=dataset("train_qb.npz", 4, 4, 2047)),
+                        "train_gf2": dict(tr, dataroot=dataset("train_gf2.npz", 4, 4, 1023)),
+                        "train_wv3": dict(tr, dataroot=dataset("train_wv3.npz", 6, 8, 2047)),
+                        "val_GF2": dict(dataroot=dataset("test_gf2.npz", 1, 4, 1023), data_len=-1),
+                        "val_WV3": dict(dataroot=dataset("test_wv3.npz", 2, 8, 2047), data_len=-1)},
+           "model": {"beta_schedule": {"train": {"schedule": "cosine", "n_timestep": 20},
+                                       "val": {"schedule": "cosine", "n_timestep": 4}},
+                     "unet": {"channel_multiplier": [8, 16, 32, 64]}, "diffusion": {"loss_type": "l1"}, "init_type": "orthogonal"},
+           "train": {"val_freq": 4, "save_checkpoint_freq": 4, "print_freq": 2, "max_iter": 4, "optimizer": {"lr": 1e-4}}}
+    cfg = tmp_path / "opt.json"
+    cfg.write_text(json.dumps(opt))
+    root = str(tmp_path / "exp")
+    assert train.main(["-c", str(cfg), "-p", "train", "--root", root]) == 4
+    run = os.path.join(root, sorted(os.listdir(root))[-1])
+    mats = sorted(os.listdir(os.path.join(run, "results", "WV3")))
+    assert mats == ["output_mulExm_0.mat", "output_mulExm_1.mat"]
+    sr = scio.loadmat(os.path.join(run, "results", "WV3", mats[0]))["sr"]
+    assert sr.shape == (16, 16, 8) and np.isfinite(sr).all() and sr.min() >= 0 and sr.max() <= 2047.0
+    assert scio.loadmat(os.path.join(run, "results", "GF2", "output_mulExm_0.mat"))["sr"].shape == (16, 16, 4)
+    ckpt = os.path.join(run, "checkpoint", "I4")
+    assert os.path.exists(ckpt + "_gen.pth") and os.path.exists(ckpt + "_opt.pth")
+    # validation-only run from that checkpoint
+    opt["path"]["resume"] = ckpt
+    opt["model"]["beta_schedule"]["val"]["n_timestep"] = 3
+    cfg.write_text(json.dumps(opt))
+    scores = train.main(["-c", str(cfg), "-p", "val", "--root", root])
+    assert set(scores) >= {"ssim_WV3", "sam_WV3", "ssim_GF2", "sam_GF2"} and all(np.isfinite(v) for v in scores.values())

@@ -258,3 +258,66 @@ def test_val_dataset_writes_mat_and_scores(tmp_path):
     assert abs(score["sam_GF2"] - (metrics.sam(hr0, sr0) + metrics.sam(hr1, want)) / 2) < 1e-12
     evaluate.val_dataset(t, "WV3", loader[:1], str(tmp_path), log=lambda *a: None)
     assert np.allclose(scio.loadmat(os.path.join(str(tmp_path), "WV3", "output_mulExm_0.mat"))["sr"], sr0 * 2047.0, rtol=1e-6)
+
+
+def _write_dataset(path, n, c, h, scale, with_gt=True, seed=0):
+    g = np.random.default_rng(seed)
+    arrays = {"ms": g.integers(0, scale, (n, c, h // 4, h // 4)).astype(np.float64),
+              "lms": g.integers(0, scale, (n, c, h, h)).astype(np.float64),
+              "pan": g.integers(0, scale, (n, 1, h, h)).astype(np.float64)}
+    if with_gt:
+        arrays["gt"] = g.integers(0, scale, (n, c, h, h)).astype(np.float64)
+    np.savez(path, **arrays)
+    return arrays
+
+
+def test_config_parse_and_datasets(tmp_path):
+    """Option file (ref core/logger.py:20-125) and PanCollection reader (ref data/LRHR_dataset.py:87-133)."""
+    from tmdiff_amd import config as Config, data as Data
+    cfg = tmp_path / "opt.json"
+    cfg.write_text('''{
+  "name": "best", // run name
+  "phase": "val", "gpu_ids": [0],
+  "path": {"log": "logs", "results": "results", "checkpoint": "checkpoint", "resume": "/nowhere/I100000"},
+  "datasets": {"train_wv3": {"dataroot": "x.npz", "batch_size": 4, "num_workers": 0, "use_shuffle": true, "data_len": -1},
+               "val_WV3": {"dataroot": "y.npz", "data_len": -1}},
+  "model": {"beta_schedule": {"train": {"schedule": "cosine", "n_timestep": 1000}, "val": {"schedule": "cosine", "n_timestep": 1000}},
+            "unet": {"channel_multiplier": [32, 64, 128, 256]}, "diffusion": {"loss_type": "l1"}, "init_type": "kaiming"},
+  "train": {"val_freq": 2000, "save_checkpoint_freq": 2000, "print_freq": 50, "max_iter": 150000, "optimizer": {"lr": 1e-4}}
+}''')
+    opt = Config.parse(str(cfg), "train", root=str(tmp_path / "exp"))
+    assert opt["phase"] == "train" and opt["distributed"] is False and opt["nothing"] is None
+    assert opt["path"]["resume"] == "/nowhere/I100000"                       # resume paths are left alone
+    assert opt["path"]["results"].startswith(str(tmp_path / "exp" / "best_")) and os.path.isdir(opt["path"]["results"])
+    assert opt["model"]["unet"]["missing"] is None and "channel_multiplier" in Config.dict2str(opt)
+    dbg = Config.parse(str(cfg), "train", gpu_ids="0,1", debug=True, root=str(tmp_path / "exp"), make_dirs=False)
+    assert dbg["name"] == "debug_best" and dbg["distributed"] is True and dbg["gpu_ids"] == [0, 1]
+    assert dbg["train"]["val_freq"] == 2 and dbg["model"]["beta_schedule"]["val"]["n_timestep"] == 10
+    assert dbg["datasets"]["train_wv3"]["batch_size"] == 2 and dbg["datasets"]["val_WV3"]["data_len"] == 3
+
+    raw = _write_dataset(str(tmp_path / "train_wv3.npz"), 5, 8, 16, 2047)
+    ds = Data.LRHRDataset(str(tmp_path / "train_wv3.npz"), data_len=3)
+    assert len(ds) == 3 and ds.img_scale == 2047.0
+    item = ds[2]
+    assert set(item) == {"LR", "PAN", "MS", "HR", "Res"} and item["LR"].shape == (8, 4, 4) and item["PAN"].shape == (1, 16, 16)
+    np.testing.assert_allclose(item["HR"].numpy(), raw["gt"][2] / 2047.0, rtol=1e-6)
+    np.testing.assert_allclose(item["Res"].numpy(), (raw["gt"][2] - raw["lms"][2]) / 2047.0, rtol=1e-5, atol=1e-7)
+    raw2 = _write_dataset(str(tmp_path / "test_gf2_full.npz"), 2, 4, 16, 1023, with_gt=False)
+    ds2 = Data.LRHRDataset(str(tmp_path / "test_gf2_full.npz"))
+    assert ds2.img_scale == 1023.0 and len(ds2) == 2
+    np.testing.assert_allclose(ds2[0]["HR"].numpy(), raw2["lms"][0] / 1023.0, rtol=1e-6)   # no gt: lms stands in
+    assert float(ds2[0]["Res"].abs().max()) == 0.0
+    loader = Data.create_dataloader(ds, {"batch_size": 2, "use_shuffle": False, "num_workers": 0}, "train_wv3")
+    batch = next(Data.get_data_generator(loader))
+    assert batch["MS"].shape == (2, 8, 16, 16)
+    assert len(Data.create_dataloader(ds, {}, "val_WV3")) == 3
+
+
+def test_driver_dataset_sampling():
+    """Per-iteration choice of the training set (ref driver :45-53, :158-160): weights 4 / 4 / 8 per batch."""
+    from tmdiff_amd import train
+    p = train.dataset_probabilities({"train_qb": 100, "train_gf2": 50, "train_wv3": 25})
+    assert abs(p["train_qb"] - 400 / 800) < 1e-12 and abs(p["train_gf2"] - 200 / 800) < 1e-12
+    assert train.sample_dataset(p, 0.49) == "train_qb" and train.sample_dataset(p, 0.5) == "train_gf2"
+    assert train.sample_dataset(p, 0.7499) == "train_gf2" and train.sample_dataset(p, 0.75) == "train_wv3"
+    assert train.sample_dataset(train.dataset_probabilities({"train_wv3": 3}), 0.1) == "train_wv3"

@@ -1,0 +1,129 @@
+"""Finetune / validation driver (reference general_sharpening_joint_random_batch_finetune.py:56-180) on tmdiff_amd.
+
+    python -m tmdiff_amd.train -c config/general_finetune.json -p train            # one GPU
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node 8 --master-addr 127.0.0.1 -m tmdiff_amd.train -c ... -p train
+
+Same option file, dataset names (``train_qb / train_gf2 / train_wv3``, ``val_QB / val_GF2 / val_WV3``), per-iteration
+random choice of the training set with the reference's weights (4, 4, 8 per batch of QB, GF2, WV3: the band counts),
+print / validation / checkpoint cadence and ``.mat`` outputs.  Multi-GPU is one process per GPU: every rank draws the
+same dataset each iteration (same seeded ``random``) but its own batches, and ``DDPM.optimize_parameters`` SUM-
+all-reduces the gradients over RCCL (the reference's DataParallel arithmetic, model.py:41).
+"""
+import argparse
+import logging
+import os
+import random
+
+import numpy as np
+import torch
+
+from . import config as Config
+from . import data as Data
+from . import dist as tdist
+from . import evaluate
+from . import model as Model
+
+TRAIN_SETS = (("train_qb", "QB", 4), ("train_gf2", "GF2", 4), ("train_wv3", "WV3", 8))
+VAL_SETS = (("val_QB", "QB"), ("val_GF2", "GF2"), ("val_WV3", "WV3"))
+
+
+def seed_all(seed=3407):
+    """reference seed_torch (:24-33)"""
+    random.seed(seed)
+    os.environ["PYTHONHASHSEED"] = str(seed)
+    np.random.seed(seed)
+    torch.manual_seed(seed)
+    if torch.cuda.is_available():
+        torch.cuda.manual_seed_all(seed)
+
+
+def dataset_probabilities(lengths):
+    """{name: number of batches} -> {name: probability}, weights 4 / 4 / 8 per batch (ref :158-160)."""
+    w = {name: wt * lengths[name] for name, _, wt in TRAIN_SETS if name in lengths}
+    total = float(sum(w.values()))
+    return {k: v / total for k, v in w.items()}
+
+
+def sample_dataset(probs, u=None):
+    """One draw of the reference's sample_data (:45-53): cumulative thresholds in the order QB, GF2, WV3."""
+    u = random.random() if u is None else u
+    acc = 0.0
+    names = [n for n, _, _ in TRAIN_SETS if n in probs]
+    for name in names[:-1]:
+        acc += probs[name]
+        if u < acc:
+            return name
+    return names[-1]
+
+
+def main(argv=None):
+    ap = argparse.ArgumentParser()
+    ap.add_argument("-c", "--config", type=str, default="config/general_finetune.json")
+    ap.add_argument("-p", "--phase", type=str, choices=["train", "val"], default="val")
+    ap.add_argument("-gpu", "--gpu_ids", type=str, default=None)
+    ap.add_argument("-debug", "-d", action="store_true")
+    ap.add_argument("--root", type=str, default="experiments", help="where the run directory is created")
+    ap.add_argument("--max-iter", type=int, default=None, help="override opt['train']['max_iter']")
+    args = ap.parse_args(argv)
+
+    world = tdist.init_from_env()
+    rank = int(os.environ.get("RANK", "0"))
+    if torch.cuda.is_available():
+        torch.cuda.set_device(int(os.environ.get("LOCAL_RANK", "0")) % torch.cuda.device_count())
+    opt = Config.parse(args.config, args.phase, args.gpu_ids, args.debug, root=args.root, make_dirs=rank == 0)
+    logging.basicConfig(level=logging.INFO if rank == 0 else logging.WARNING, format="%(asctime)s %(message)s")
+    logger = logging.getLogger("base")
+    logger.info(Config.dict2str(opt))
+    seed_all()
+
+    loaders, gens = {}, {}
+    for name, ds_opt in opt["datasets"].items():
+        is_train = name.startswith("train")
+        if is_train and args.phase == "val":
+            continue
+        ds = Data.create_dataset(ds_opt, "train" if is_train else "val")
+        g = torch.Generator().manual_seed(3407 + 1000 * rank) if is_train else None   # each rank its own batches
+        loaders[name] = Data.create_dataloader(ds, ds_opt, name, generator=g)
+        if is_train:
+            gens[name] = Data.get_data_generator(loaders[name])
+    logger.info("Initial Dataset Finished")
+
+    diffusion = Model.create_model(opt)
+    logger.info("Initial Model Finished")
+    step = diffusion.begin_step
+    diffusion.set_new_noise_schedule(opt["model"]["beta_schedule"][opt["phase"]], schedule_phase=opt["phase"])
+    results = opt["path"]["results"]
+
+    def validate():
+        scores = {}
+        if rank == 0:                       # (validation items are few; the other ranks wait at the barrier)
+            for name, prompt in VAL_SETS:
+                if name in loaders:
+                    scores.update(evaluate.val_dataset(diffusion, prompt, loaders[name], results, log=logger.info))
+        if world > 1:
+            torch.distributed.barrier()
+        return scores
+
+    if opt["phase"] == "train":
+        probs = dataset_probabilities({n: len(l) for n, l in loaders.items() if n in gens})
+        prompt_of = {n: p for n, p, _ in TRAIN_SETS}
+        max_iter = args.max_iter if args.max_iter is not None else opt["train"]["max_iter"]
+        while step < max_iter:
+            name = sample_dataset(probs)
+            step += 1
+            diffusion.feed_data(next(gens[name]))
+            diffusion.optimize_parameters(prompt_of[name])
+            if step % opt["train"]["print_freq"] == 0:
+                logs = diffusion.get_current_log()
+                logger.info("iter %d [%s] %s", step, name, " ".join(f"{k}: {float(v):.4e}" for k, v in logs.items()))
+            if step % opt["train"]["val_freq"] == 0:
+                validate()
+                if rank == 0:
+                    diffusion.save_network(step)
+        return step
+    logger.info("Begin Model Evaluation.")
+    return validate()
+
+
+if __name__ == "__main__":
+    main()
