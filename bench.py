@@ -146,6 +146,7 @@ def main():
     dt = time.perf_counter() - t0
     timer, ops.TIMER = ops.TIMER, None
     conv = timer.summary()
+    conv_by_entry = timer.summary(by_entry=True)
     assert torch.isfinite(x).all()
     log(f"timed region: {args.steps} steps in {dt:.3f} s")
 
@@ -201,6 +202,12 @@ def main():
                                    "or prologue_apply_kernel + conv3d_dma_kernel<3,..> (staged), chosen per layer",
                          "launches": n3, "avg_launch_us": round(ms3 / max(n3, 1) * 1e3, 2),
                          "algorithmic_gflop_per_launch": round(fl3 / max(n3, 1) / 1e9, 2),
+                         # per entry point, to set beside the rocprofv3 kernel averages in profiles/: "conv3d_fwd" =
+                         # conv3d_mfma_kernel<3,..>; "conv3d_fwd_staged" = prologue_apply_kernel (when the input has a
+                         # prologue) + conv3d_dma_kernel<3,..>
+                         "by_entry": {what: {"launches": n, "avg_launch_us": round(ms / n * 1e3, 2),
+                                             "tflops": round(fl / (ms * 1e-3) / 1e12, 2)}
+                                      for (k, what), (n, ms, fl) in sorted(conv_by_entry.items()) if k == 3},
                          "k1_conv": {"launches": n1, "avg_launch_us": round(ms1 / max(n1, 1) * 1e3, 2),
                                      "tflops": round(fl1 / (ms1 * 1e-3) / 1e12, 2) if ms1 > 0 else 0.0}},
             "cond_cached": {"value": round(world * args.steps / dt_cached, 4), "unit": "batch32-steps/s",

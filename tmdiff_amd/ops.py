@@ -96,14 +96,16 @@ class ConvTimer:
     object).  Events are recorded on the launch stream; ``summary()`` resolves them after a sync."""
 
     def __init__(self):
-        self.records = []        # (start_event, end_event, flops, ksize)
+        self.records = []        # (start_event, end_event, flops, ksize, entry point)
 
-    def summary(self):
+    def summary(self, by_entry=False):
+        """{ksize: (launches, ms, flops)}; with by_entry the key is (ksize, C entry point that served the launch)."""
         torch.cuda.synchronize()
         out = {}
-        for e0, e1, fl, k in self.records:
-            n, ms, f = out.get(k, (0, 0.0, 0.0))
-            out[k] = (n + 1, ms + e0.elapsed_time(e1), f + fl)
+        for e0, e1, fl, k, what in self.records:
+            key = (k, what) if by_entry else k
+            n, ms, f = out.get(key, (0, 0.0, 0.0))
+            out[key] = (n + 1, ms + e0.elapsed_time(e1), f + fl)
         return out
 
 
@@ -168,7 +170,7 @@ def conv3d(segs, w_packed, cout, ksize, out=None, math="fp32", pack_input=None, 
     e0.record()
     check(fwd(C.byref(d), stream_ptr()), what)
     e1.record()
-    TIMER.records.append((e0, e1, 2.0 * b * cout * (d.Cin // d.groups) * ksize ** 3 * n * h * w, ksize))
+    TIMER.records.append((e0, e1, 2.0 * b * cout * (d.Cin // d.groups) * ksize ** 3 * n * h * w, ksize, what))
     return y
 
 
