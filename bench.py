@@ -20,6 +20,7 @@ Extra objects on the JSON line (tier contract):
                 sampling run): the rate a real 1000-step run sees.  Reported beside, never as, `value`.
   bf16_compute  the same full-forward loop with bf16 conv operands / fp32 accumulation (the config-3 mode);
                 reduced precision, so also only beside `value`.
+  parity        PSNR(build, oracle) of a short DDPM chain with shared noise (rank 0, N == 1 only).
 """
 import argparse
 import json
@@ -84,6 +85,35 @@ def cpu_baseline():
             "sample": f"{steps} p_sample steps on {b} tiles of 8x64x64 ({dt:.1f} s), scaled to batch {BATCH}; "
                       f"torch {torch.__version__} CPU, {cores} threads",
             "sample_steps_per_s": round(b * steps / dt, 4)}
+
+
+def parity_check(dev):
+    """PSNR(build, oracle) of a short DDPM chain with shared noise (the "PSNR vs ref" half of the metric): full-width
+    network, one 8x16x16 tile, T = 10; the oracle is the checker here, as in tests/ and smoke()."""
+    from oracle import unet_ref as U
+    from oracle.diffusion_ref import GeneralDiffusionRef
+    from tmdiff_amd.Hyper_unet_general import WavBEST
+    from tmdiff_amd.diffusion_general import GeneralDiffusion
+    from tmdiff_amd.util import psnr, synthetic_tile_batch
+    ref_net = U.fill_weights_(U.WavBESTRef(channels=FULL)).eval()
+    net = WavBEST(channels=FULL)
+    net.load_state_dict(ref_net.state_dict())
+    net = net.to(dev).eval()
+    d = synthetic_tile_batch(77, 1, BANDS, 16)
+    noise = lambda like: torch.randn(like.shape, dtype=torch.float32)       # CPU generator on both sides
+    want = GeneralDiffusionRef(ref_net, "l1")
+    want.set_new_noise_schedule({"schedule": "cosine", "n_timestep": 10}, "cpu")
+    got = GeneralDiffusion(net, "l1", noise_fn=noise).to(dev)
+    got.set_new_noise_schedule({"schedule": "cosine", "n_timestep": 10}, dev)
+    torch.manual_seed(5)
+    with torch.no_grad():
+        y_ref = want.p_sample_loop(d, continous=False, prompt="WV3")
+    torch.manual_seed(5)
+    y = got.p_sample_loop({k: v.to(dev) for k, v in d.items()}, continous=False, prompt="WV3").cpu()
+    return {"psnr_db": round(float(psnr(y, y_ref)), 1), "max_abs_diff": float((y - y_ref).abs().max()),
+            "what": "10-step DDPM chain (T=10 cosine) on one 8x16x16 tile, ch 32-256, shared CPU noise: fused image of the "
+                    "HIP path vs the CPU oracle; budget PSNR >= 60 dB (tests/test_gpu_sampling.py hold 50-step and "
+                    "1000-step chains to the same)"}
 
 
 def main():
@@ -221,6 +251,8 @@ def main():
                                      "tests/test_gpu_bf16.py) -- reduced precision, never `value`"},
         }
         if world == 1 and not args.no_cpu_baseline:
+            line["parity"] = parity_check(dev)
+            log(f"parity: PSNR {line['parity']['psnr_db']} dB")
             line["cpu_baseline"] = cpu_baseline()
         print(json.dumps(line), flush=True)
     if dist is not None:
