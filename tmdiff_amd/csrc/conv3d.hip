@@ -504,7 +504,10 @@ extern "C" int tmdiff_conv3d_fwd(const tmdiff_conv3d_desc* d, tmdiff_stream_t st
   if (d->ksize == 3) {
     if (small_grid) return launch<3, 1, 2, 4, 2, 8, 8>(a, st);
     if (c64) return launch<3, 2, 2, 4, 4, 8, 8>(a, st);
-    return d->W >= 16 ? launch<3, 4, 1, 4, 4, 8, 16>(a, st) : launch<3, 2, 1, 4, 4, 8, 8>(a, st);
+    // 32-channel tiles: 512 positions when that still gives every CU a workgroup, else 256 (small batches)
+    const long wg512 = (long)d->B * d->groups * ((d->N + 3) / 4) * ((d->H + 7) / 8) * ((d->W + 15) / 16) * ((a.cout_g + 31) / 32);
+    const bool wide = d->W >= 16 && wg512 >= 256;
+    return wide ? launch<3, 4, 1, 4, 4, 8, 16>(a, st) : launch<3, 2, 1, 4, 4, 8, 8>(a, st);
   }
   if (c64) return launch<1, 2, 2, 8, 4, 8, 8>(a, st);
   return d->W >= 16 ? launch<1, 4, 1, 8, 4, 8, 16>(a, st) : launch<1, 2, 1, 8, 4, 8, 8>(a, st);
