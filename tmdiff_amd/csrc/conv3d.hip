@@ -63,7 +63,6 @@ struct ConvArgs {
   int tiles_n, tiles_h, tiles_w, tiles_co;  // tiles_co per group
   int w_vec4;                               // cout_g % 4 == 0 -> 16-byte weight loads
   unsigned total_blocks;
-  int dbg;  // experiment switches (TMDIFF_CONV_DEBUG): 1 = no in-loop global loads, 2 = no hand-off pieces, 4 = no barrier
 };
 
 // Tile geometry.  A workgroup = 4 waves; wave w owns NS position sub-tiles (32 positions each) x MSUB
@@ -491,7 +490,6 @@ extern "C" int tmdiff_conv3d_fwd(const tmdiff_conv3d_desc* d, tmdiff_stream_t st
   a.scale_stride = d->in_scale_stride > 0 ? d->in_scale_stride : (d->in_scale_stride < 0 ? 0 : d->Cin);
   a.residual = d->residual; a.out_scale = d->out_scale; a.y = d->y;
   a.w_vec4 = (a.cout_g % 4 == 0) && aligned16(d->w_packed);
-  a.dbg = 0;
   hipStream_t st = as_stream(stream);
 
   // Tile choice.  <NS, MSUB>: 2x2 = 256 positions x 64 channels when the channel count is a multiple of 64
