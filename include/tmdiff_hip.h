@@ -23,7 +23,7 @@
 extern "C" {
 #endif
 
-#define TMDIFF_ABI_VERSION 1
+#define TMDIFF_ABI_VERSION 2
 
 #define TMDIFF_OK 0
 #define TMDIFF_E_INVALID (-1)     /* bad argument / shape */
@@ -68,7 +68,19 @@ typedef struct tmdiff_conv3d_desc {
   int32_t in_act;        /* 0 = identity, 1 = SiLU */
   const float* residual; /* [B, Cout, N, H, W] or NULL */
   float out_scale;
-  float* y;              /* [B, Cout, N, H, W] */
+  float* y;              /* [B, Cout, N, H, W]; may be NULL when only y2 is wanted */
+  /* Optional second output: the consumer's prologue applied to this convolution's result,
+   *   y2 = act2(y + y2_shift[b,co]) * y2_scale[b,co]
+   * so that the consumer reads a plain tensor (e.g. conv20 -> conv21 of a ResBlock, Hyper_unet_general.py:244-248:
+   * conv21's SiLU and text modulation are applied where conv20's result is produced).  y2_bf16 == 0: fp32
+   * [B, Cout, N, H, W]; != 0: bf16 units of 8 channels [B][Cout/8][N*H*W] as tmdiff_conv3d_fwd_bf16 packs them
+   * (only the bf16 entry point writes that form; Cout/groups a multiple of 32).  Strides as in_shift_stride. */
+  float* y2;
+  const float* y2_shift;
+  const float* y2_scale;
+  int32_t y2_shift_stride, y2_scale_stride;
+  int32_t y2_act;
+  int32_t y2_bf16;
 } tmdiff_conv3d_desc;
 
 /* w [Cout, Cin/groups, k, k, k] (PyTorch layout) -> packed [g][ci][tap][co] used by the

@@ -481,3 +481,33 @@ def test_empty_batch_all_forward_variants(ops):
             wp = ops.pack_conv_weight_bf16(w) if kw.get("math") == "bf16" else ops.pack_conv_weight(w)
             y = ops.conv3d([x], wp, 32, k, in_act=True, **kw)
             assert y.shape == (0, 32, 4, 8, 8)
+
+
+@pytest.mark.parametrize("cfg", [dict(cin=32, cmid=64, N=8, H=16, W=16), dict(cin=16, cmid=32, N=4, H=12, W=20),
+                                 dict(cin=64, cmid=128, N=8, H=8, W=8)])
+def test_conv3d_second_output_is_the_consumers_prologue(ops, cfg):
+    """y2 = act(y + shift2) * scale2 written by the producer's epilogue == the consumer applying that prologue itself:
+    conv21(prologue(conv20(x))) gives the same bits either way, for the fused and the staged kernels."""
+    torch.manual_seed(31)
+    B, cin, cmid = 2, cfg["cin"], cfg["cmid"]
+    shp = (cfg["N"], cfg["H"], cfg["W"])
+    x = cu(torch.randn(B, cin, *shp))
+    w20 = ops.pack_conv_weight(cu(torch.randn(cmid, cin, 3, 3, 3) / (cin * 27) ** 0.5))
+    w21 = ops.pack_conv_weight(cu(torch.randn(cmid, cmid, 3, 3, 3) / (cmid * 27) ** 0.5))
+    bias, sh1 = cu(torch.randn(cmid)), cu(torch.randn(B, cin))
+    sh2, sc2 = cu(torch.randn(B, cmid) * 0.3), cu(torch.rand(B, cmid) + 0.5)
+    for staged in (False, True):
+        t1 = ops.conv3d([x], w20, cmid, 3, bias=bias, in_shift=sh1, in_act=True, staged=staged)
+        want = ops.conv3d([t1], w21, cmid, 3, in_shift=sh2, in_scale=sc2, in_act=True, staged=staged)
+        y, y2 = ops.conv3d([x], w20, cmid, 3, bias=bias, in_shift=sh1, in_act=True, staged=staged,
+                           emit=dict(act=True, shift=sh2, scale=sc2))
+        assert torch.equal(y, t1)
+        only = ops.conv3d([x], w20, cmid, 3, bias=bias, in_shift=sh1, in_act=True, staged=staged,
+                          emit=dict(act=True, shift=sh2, scale=sc2), keep_y=False)
+        assert torch.equal(only, y2)
+        for staged2 in (False, True):
+            got = ops.conv3d([y2], w21, cmid, 3, staged=staged2)
+            assert torch.equal(got, want), (staged, staged2)
+    # no activation / no shift variants against plain torch arithmetic
+    y, y2 = ops.conv3d([x], w20, cmid, 3, emit=dict(scale=sc2))
+    assert_close(y2, y.cpu() * sc2.cpu()[:, :, None, None, None], 1e-6, 1e-6, "scale-only second output")

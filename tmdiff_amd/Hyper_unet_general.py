@@ -272,10 +272,16 @@ class WavBEST(nn.Module):
         res_conv; conv21 with fused SiLU + text modulation + residual add."""
         rb = self.get_submodule(name)
         sh = {} if flag else self._shift(P, S, name + ".dense1")
-        t1 = self._conv(P, name + ".conv20", segs, in_act=True, **sh)
         res = self._conv(P, name + ".res_conv", segs) if isinstance(rb.res_conv, nn.Conv3d) else segs[0]
-        return self._conv(P, name + ".conv21", [t1], use_bias=False, in_act=True, residual=res,
-                          **self._scale(P, S, name + ".dense2"))
+        sc = self._scale(P, S, name + ".dense2")
+        if name + ".conv20" not in P["bf16"]:
+            # conv20's result feeds conv21 only: its epilogue applies conv21's prologue (SiLU, text modulation), and
+            # conv21 reads a plain tensor (no prologue pass in front of the staged kernel; same bits either way)
+            t1p = self._conv(P, name + ".conv20", segs, in_act=True, keep_y=False,
+                             emit=dict(act=True, scale=sc["in_scale"], scale_stride=sc["scale_stride"]), **sh)
+            return self._conv(P, name + ".conv21", [t1p], use_bias=False, residual=res)
+        t1 = self._conv(P, name + ".conv20", segs, in_act=True, **sh)
+        return self._conv(P, name + ".conv21", [t1], use_bias=False, in_act=True, residual=res, **sc)
 
     def _down(self, P, S, name, x, flag, want_high):
         """WaveletUPorDown(down=True) (ref :369-414); /2 folded into the DWT, LL-only when the

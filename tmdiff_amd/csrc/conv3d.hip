@@ -60,6 +60,10 @@ struct ConvArgs {
   const float* residual;
   float out_scale;
   float* y;
+  float* y2;              // optional second output act2(y + shift2) * scale2 (the consumer's prologue), see the header
+  const float* y2_shift;
+  const float* y2_scale;
+  int y2_shift_stride, y2_scale_stride, y2_act;
   int tiles_n, tiles_h, tiles_w, tiles_co;  // tiles_co per group
   int w_vec4;                               // cout_g % 4 == 0 -> 16-byte weight loads
   unsigned total_blocks;
@@ -168,6 +172,13 @@ __global__ void __launch_bounds__(256, 2) conv3d_mfma_kernel(const ConvArgs a) {
     const float* bp = a.bias ? a.bias + g * a.cout_g + col : a.wp;  // always a valid address
     const float raw = *bp;
     bias_v[m] = a.bias ? a.bias_scale * raw : 0.f;
+  }
+  float sh2_v[MSUB], sc2_v[MSUB];  // second-output shift / scale of channel co0 + m*32 + l31 (same readlane scheme)
+#pragma unroll
+  for (int m = 0; m < MSUB; ++m) {
+    const int col = g * a.cout_g + min(co0 + m * 32 + l31, a.cout_g - 1);
+    sh2_v[m] = (a.y2 && a.y2_shift) ? a.y2_shift[(long)b * a.y2_shift_stride + col] : 0.f;
+    sc2_v[m] = (a.y2 && a.y2_scale) ? a.y2_scale[(long)b * a.y2_scale_stride + col] : 1.f;
   }
 
   // prefetch registers of the chunk in flight
@@ -370,7 +381,24 @@ __global__ void __launch_bounds__(256, 2) conv3d_mfma_kernel(const ConvArgs a) {
       for (int r = 0; r < 16; ++r) {
         const int row = (r & 3) + 8 * (r >> 2);
         const bool ok = pok && (FAST || co0 + m * 32 + 4 * khalf + row < a.cout_g);
-        if (ok) a.y[obase + row * plane] = (acc[s][m][r] + bias_r[r] + res[r]) * a.out_scale;
+        const float v = (acc[s][m][r] + bias_r[r] + res[r]) * a.out_scale;
+        if (ok && a.y) a.y[obase + row * plane] = v;
+        acc[s][m][r] = v;
+      }
+      if (a.y2) {  // (wave-uniform) the consumer's prologue on the finished values
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int row = (r & 3) + 8 * (r >> 2);
+          const bool ok = pok && (FAST || co0 + m * 32 + 4 * khalf + row < a.cout_g);
+          const float s0 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(sh2_v[m]), row));
+          const float s1 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(sh2_v[m]), row + 4));
+          const float c0 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(sc2_v[m]), row));
+          const float c1 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(sc2_v[m]), row + 4));
+          float t = acc[s][m][r] + (khalf ? s1 : s0);
+          const float ta = tmdiff::silu_f(t);
+          t = (a.y2_act ? ta : t) * (khalf ? c1 : c0);
+          if (ok) a.y2[obase + row * plane] = t;
+        }
       }
     }
   }
@@ -467,7 +495,8 @@ extern "C" int tmdiff_conv3d_fwd(const tmdiff_conv3d_desc* d, tmdiff_stream_t st
   if (d->groups == 3)
     TMDIFF_REQUIRE(d->nseg == 1 || (d->nseg == 3 && d->seg_c[0] == d->seg_c[1] && d->seg_c[1] == d->seg_c[2]),
                    "conv3d_fwd: groups=3 wants 1 segment or 3 equal ones");
-  TMDIFF_REQUIRE(d->w_packed && d->y, "conv3d_fwd: NULL weights/output");
+  TMDIFF_REQUIRE(d->w_packed && (d->y || d->y2), "conv3d_fwd: NULL weights/output");
+  TMDIFF_REQUIRE(!d->y2 || !d->y2_bf16, "conv3d_fwd: a bf16-packed second output needs tmdiff_conv3d_fwd_bf16");
   TMDIFF_REQUIRE((long)d->N * d->H * d->W < (1L << 31), "conv3d_fwd: plane too large for 32-bit offsets");
 
   if (d->ksize == 1) {  // bandwidth kernel for the shapes it takes (every production 1x1x1 layer)
@@ -489,6 +518,9 @@ extern "C" int tmdiff_conv3d_fwd(const tmdiff_conv3d_desc* d, tmdiff_stream_t st
   a.shift_stride = d->in_shift_stride > 0 ? d->in_shift_stride : (d->in_shift_stride < 0 ? 0 : d->Cin);
   a.scale_stride = d->in_scale_stride > 0 ? d->in_scale_stride : (d->in_scale_stride < 0 ? 0 : d->Cin);
   a.residual = d->residual; a.out_scale = d->out_scale; a.y = d->y;
+  a.y2 = d->y2; a.y2_shift = d->y2_shift; a.y2_scale = d->y2_scale; a.y2_act = d->y2_act;
+  a.y2_shift_stride = d->y2_shift_stride > 0 ? d->y2_shift_stride : (d->y2_shift_stride < 0 ? 0 : d->Cout);
+  a.y2_scale_stride = d->y2_scale_stride > 0 ? d->y2_scale_stride : (d->y2_scale_stride < 0 ? 0 : d->Cout);
   a.w_vec4 = (a.cout_g % 4 == 0) && aligned16(d->w_packed);
   hipStream_t st = as_stream(stream);
 

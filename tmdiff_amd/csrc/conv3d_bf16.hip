@@ -712,6 +712,7 @@ extern "C" int tmdiff_conv3d_fwd_bf16(const tmdiff_conv3d_desc* d, void* workspa
     TMDIFF_REQUIRE(d->nseg == 1 || (d->nseg == 3 && d->seg_c[0] == d->seg_c[1] && d->seg_c[1] == d->seg_c[2]),
                    "conv3d_fwd_bf16: groups=3 wants 1 segment or 3 equal ones");
   TMDIFF_REQUIRE(d->w_packed && d->y, "conv3d_fwd_bf16: NULL weights/output");
+  if (d->y2) return fail(TMDIFF_E_UNSUPPORTED, "conv3d_fwd_bf16: second output not implemented");
   TMDIFF_REQUIRE(aligned16(d->w_packed), "conv3d_fwd_bf16: packed weights must be 16-byte aligned");
   TMDIFF_REQUIRE((long)d->N * d->H * d->W < (1L << 31), "conv3d_fwd_bf16: plane too large for 32-bit offsets");
 

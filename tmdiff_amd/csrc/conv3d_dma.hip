@@ -39,6 +39,10 @@ struct DmaArgs {
   const float* residual;
   float out_scale;
   float* y;
+  float* y2;  // optional second output act2(y + shift2) * scale2 (the consumer's prologue), see the header
+  const float* y2_shift;
+  const float* y2_scale;
+  int y2_shift_stride, y2_scale_stride, y2_act;
   int tiles_n, tiles_h, tiles_w, tiles_co;
   unsigned total_blocks;
 };
@@ -152,6 +156,13 @@ __global__ void __launch_bounds__(256, 2) conv3d_dma_kernel(const DmaArgs a) {
   float bias_v[MSUB];
 #pragma unroll
   for (int m = 0; m < MSUB; ++m) bias_v[m] = a.bias ? a.bias[g * a.cout_g + co0 + m * 32 + l31] * a.bias_scale : 0.f;
+  float sh2_v[MSUB], sc2_v[MSUB];
+#pragma unroll
+  for (int m = 0; m < MSUB; ++m) {
+    const int col = g * a.cout_g + co0 + m * 32 + l31;
+    sh2_v[m] = (a.y2 && a.y2_shift) ? a.y2_shift[(long)b * a.y2_shift_stride + col] : 0.f;
+    sc2_v[m] = (a.y2 && a.y2_scale) ? a.y2_scale[(long)b * a.y2_scale_stride + col] : 1.f;
+  }
 
   f32x16 acc[NS][MSUB];
 #pragma unroll
@@ -247,7 +258,23 @@ __global__ void __launch_bounds__(256, 2) conv3d_dma_kernel(const DmaArgs a) {
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
         const int row = (r & 3) + 8 * (r >> 2);
-        if (pok) a.y[obase + row * plane] = (acc[s][m][r] + bias_r[r] + res[r]) * a.out_scale;
+        const float v = (acc[s][m][r] + bias_r[r] + res[r]) * a.out_scale;
+        if (pok && a.y) a.y[obase + row * plane] = v;
+        acc[s][m][r] = v;
+      }
+      if (a.y2) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int row = (r & 3) + 8 * (r >> 2);
+          const float s0 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(sh2_v[m]), row));
+          const float s1 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(sh2_v[m]), row + 4));
+          const float c0 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(sc2_v[m]), row));
+          const float c1 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(sc2_v[m]), row + 4));
+          float t = acc[s][m][r] + (khalf ? s1 : s0);
+          const float ta = tmdiff::silu_f(t);
+          t = (a.y2_act ? ta : t) * (khalf ? c1 : c0);
+          if (pok) a.y2[obase + row * plane] = t;
+        }
       }
     }
   }
@@ -301,7 +328,8 @@ extern "C" int tmdiff_conv3d_fwd_staged(const tmdiff_conv3d_desc* d, void* works
     csum += d->seg_c[i];
   }
   TMDIFF_REQUIRE(csum == d->Cin, "conv3d_fwd_staged: segments hold %d channels, Cin=%d", csum, d->Cin);
-  TMDIFF_REQUIRE(d->w_packed && d->y && aligned16(d->w_packed), "conv3d_fwd_staged: NULL / unaligned weights or output");
+  TMDIFF_REQUIRE(d->w_packed && (d->y || d->y2) && aligned16(d->w_packed), "conv3d_fwd_staged: NULL / unaligned weights or output");
+  TMDIFF_REQUIRE(!d->y2 || !d->y2_bf16, "conv3d_fwd_staged: a bf16-packed second output needs tmdiff_conv3d_fwd_bf16");
   TMDIFF_REQUIRE((long)d->N * d->H * d->W * 8 < (1L << 31), "conv3d_fwd_staged: plane too large");
   hipStream_t st = as_stream(stream);
 
@@ -319,6 +347,9 @@ extern "C" int tmdiff_conv3d_fwd_staged(const tmdiff_conv3d_desc* d, void* works
   }
   a.wp = d->w_packed; a.bias = d->bias; a.bias_scale = d->bias_scale;
   a.residual = d->residual; a.out_scale = d->out_scale; a.y = d->y;
+  a.y2 = d->y2; a.y2_shift = d->y2_shift; a.y2_scale = d->y2_scale; a.y2_act = d->y2_act;
+  a.y2_shift_stride = d->y2_shift_stride > 0 ? d->y2_shift_stride : (d->y2_shift_stride < 0 ? 0 : d->Cout);
+  a.y2_scale_stride = d->y2_scale_stride > 0 ? d->y2_scale_stride : (d->y2_scale_stride < 0 ? 0 : d->Cout);
 
   // tile choice: as tmdiff_conv3d_fwd
   const bool c64 = a.cout_g % 64 == 0;

@@ -58,9 +58,11 @@ def pack_conv_weight_bf16(w, groups=1):
 
 
 def make_conv_desc(segs, w_packed, cout, ksize, y, groups=1, bias=None, bias_scale=1.0, in_shift=None, in_scale=None,
-                   shift_stride=0, scale_stride=0, in_act=False, in_mask=None, residual=None, out_scale=1.0):
+                   shift_stride=0, scale_stride=0, in_act=False, in_mask=None, residual=None, out_scale=1.0,
+                   y2=None, y2_shift=None, y2_scale=None, y2_shift_stride=0, y2_scale_stride=0, y2_act=False):
     """Fill a tmdiff_conv3d_desc.  `segs` = list of 1..3 tensors [B, c_i, N, H, W] (concat-free input).
-    in_shift / in_scale may be tensors or raw (ptr) ints into a projection bank."""
+    in_shift / in_scale may be tensors or raw (ptr) ints into a projection bank.  y may be None when only the second
+    output y2 = act2(y + y2_shift) * y2_scale (the consumer's prologue, same pointer conventions) is wanted."""
     d = Conv3dDesc()
     b, _, n, h, w = segs[0].shape
     d.B, d.N, d.H, d.W = b, n, h, w
@@ -81,13 +83,23 @@ def make_conv_desc(segs, w_packed, cout, ksize, y, groups=1, bias=None, bias_sca
     d.in_shift_stride, d.in_scale_stride = shift_stride, scale_stride
     d.in_mask = _chk(in_mask, "in_mask")
     d.in_act = 1 if in_act else 0
-    if residual is not None and tuple(residual.shape) != tuple(y.shape):
+    oshape = (b, cout, n, h, w)
+    if residual is not None and tuple(residual.shape) != oshape:
         raise ValueError("conv3d: residual shape != output shape")
     d.residual = _chk(residual, "residual")
     d.out_scale = out_scale
-    if tuple(y.shape) != (b, cout, n, h, w):
-        raise ValueError(f"conv3d: output shape {tuple(y.shape)} != {(b, cout, n, h, w)}")
+    for t, nm in ((y, "y"), (y2, "y2")):
+        if t is not None and tuple(t.shape) != oshape:
+            raise ValueError(f"conv3d: {nm} shape {tuple(t.shape)} != {oshape}")
+    if y is None and y2 is None:
+        raise ValueError("conv3d: no output")
     d.y = _chk(y, "y")
+    d.y2 = _chk(y2, "y2")
+    d.y2_shift = y2_shift if isinstance(y2_shift, int) else _chk(y2_shift, "y2_shift")
+    d.y2_scale = y2_scale if isinstance(y2_scale, int) else _chk(y2_scale, "y2_scale")
+    d.y2_shift_stride, d.y2_scale_stride = y2_shift_stride, y2_scale_stride
+    d.y2_act = 1 if y2_act else 0
+    d.y2_bf16 = 0
     return d
 
 
@@ -126,20 +138,32 @@ def _workspace(device, nbytes):
     return ws
 
 
-def conv3d(segs, w_packed, cout, ksize, out=None, math="fp32", pack_input=None, staged=None, **kw):
+def conv3d(segs, w_packed, cout, ksize, out=None, math="fp32", pack_input=None, staged=None, emit=None, keep_y=True,
+           **kw):
     """math="fp32": exact-fp32 MFMA kernel (w_packed from pack_conv_weight); "bf16": bf16 operands / fp32
     accumulation (w_packed from pack_conv_weight_bf16).  pack_input (bf16 only): True = pack the prologue output to
     bf16 once and run the staging-free kernel (default), False = one fused kernel.  staged (fp32 only): True = prologue
-    pass + global_load_lds staged kernel (default where the shape allows), False = the fused kernel."""
+    pass + global_load_lds staged kernel (default where the shape allows), False = the fused kernel.
+    emit = dict(act=, shift=, scale=, shift_stride=, scale_stride=): also produce y2 = act(y + shift) * scale, the
+    consumer's prologue applied in this convolution's epilogue; returns (y, y2), or y2 alone with keep_y=False."""
     b, _, n, h, w = segs[0].shape
-    y = out if out is not None else torch.empty(b, cout, n, h, w, device=segs[0].device, dtype=torch.float32)
+    dev = segs[0].device
+    y = out if out is not None else (torch.empty(b, cout, n, h, w, device=dev, dtype=torch.float32) if keep_y else None)
+    y2 = None
+    if emit is not None:
+        y2 = torch.empty(b, cout, n, h, w, device=dev, dtype=torch.float32)
+        kw = dict(kw, y2=y2, y2_act=emit.get("act", False), y2_shift=emit.get("shift"), y2_scale=emit.get("scale"),
+                  y2_shift_stride=emit.get("shift_stride", 0), y2_scale_stride=emit.get("scale_stride", 0))
+    elif y is None:
+        raise ValueError("conv3d: keep_y=False needs emit=")
     d = make_conv_desc(segs, w_packed, cout, ksize, y, **kw)
+    ret = y if y2 is None else ((y, y2) if y is not None else y2)
     if math == "bf16":
         if w_packed.dtype != torch.int16:
             raise TypeError("conv3d(math='bf16') needs weights from pack_conv_weight_bf16")
         if pack_input is None:
             pack_input = {"0": False, "1": True}.get(_BF16_PACK, True)   # measured: the two-kernel variant wins on every production layer
-        ws = (_workspace(y.device, lib.tmdiff_conv3d_bf16_workspace_bytes(C.byref(d))).data_ptr()
+        ws = (_workspace(dev, lib.tmdiff_conv3d_bf16_workspace_bytes(C.byref(d))).data_ptr()
               if pack_input and ksize == 3 else None)
         fwd, what = (lambda dd, st: lib.tmdiff_conv3d_fwd_bf16(dd, ws, st)), "conv3d_fwd_bf16"
     elif math == "fp32":
@@ -157,7 +181,7 @@ def conv3d(segs, w_packed, cout, ksize, out=None, math="fp32", pack_input=None, 
                 plain or cout // d.groups >= 128 or d.Cin // d.groups >= 384 or kw.get("in_mask") is not None))
         if staged and lib.tmdiff_conv3d_fwd_staged_supported(C.byref(d)):
             nb = lib.tmdiff_conv3d_fwd_staged_workspace_bytes(C.byref(d))
-            ws32 = _workspace(y.device, nb).data_ptr() if nb else None
+            ws32 = _workspace(dev, nb).data_ptr() if nb else None
             fwd, what = (lambda dd, st: lib.tmdiff_conv3d_fwd_staged(dd, ws32, st)), "conv3d_fwd_staged"
         else:
             fwd, what = lib.tmdiff_conv3d_fwd, "conv3d_fwd"
@@ -165,13 +189,13 @@ def conv3d(segs, w_packed, cout, ksize, out=None, math="fp32", pack_input=None, 
         raise ValueError(f"conv3d: unknown math {math!r}")
     if TIMER is None:
         check(fwd(C.byref(d), stream_ptr()), what)
-        return y
+        return ret
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     e0.record()
     check(fwd(C.byref(d), stream_ptr()), what)
     e1.record()
     TIMER.records.append((e0, e1, 2.0 * b * cout * (d.Cin // d.groups) * ksize ** 3 * n * h * w, ksize, what))
-    return y
+    return ret
 
 
 def stem(w, bias, out_channels, xin=None, pan=None, ms=None, silu=True, out=None):
