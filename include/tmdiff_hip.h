@@ -81,6 +81,10 @@ typedef struct tmdiff_conv3d_desc {
   int32_t y2_shift_stride, y2_scale_stride;
   int32_t y2_act;
   int32_t y2_bf16;
+  /* != 0: seg_x[0] is not fp32 but the bf16 units [B][Cin/8][N*H*W] a producer wrote as its y2 (prologue already
+   * applied): nseg 1, no shift / scale / act / mask.  Only tmdiff_conv3d_fwd_bf16 (3x3x3) accepts it; it then skips
+   * its pack pass and needs no workspace. */
+  int32_t x_bf16;
 } tmdiff_conv3d_desc;
 
 /* w [Cout, Cin/groups, k, k, k] (PyTorch layout) -> packed [g][ci][tap][co] used by the

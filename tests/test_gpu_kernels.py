@@ -511,3 +511,33 @@ def test_conv3d_second_output_is_the_consumers_prologue(ops, cfg):
     # no activation / no shift variants against plain torch arithmetic
     y, y2 = ops.conv3d([x], w20, cmid, 3, emit=dict(scale=sc2))
     assert_close(y2, y.cpu() * sc2.cpu()[:, :, None, None, None], 1e-6, 1e-6, "scale-only second output")
+
+
+@pytest.mark.parametrize("cfg", [dict(cin=32, cmid=64, N=8, H=16, W=16), dict(cin=16, cmid=32, N=4, H=12, W=20),
+                                 dict(cin=64, cmid=128, N=8, H=8, W=8), dict(cin=16, cmid=32, N=4, H=8, W=8)])
+def test_conv3d_bf16_packed_second_output(ops, cfg):
+    """bf16 mode: the producer's epilogue writes the consumer's prologue output as packed bf16 units (register quads
+    regrouped with v_permlane32_swap); feeding that to the consumer == the consumer packing the fp32 tensor itself."""
+    torch.manual_seed(37)
+    B, cin, cmid = 2, cfg["cin"], cfg["cmid"]
+    shp = (cfg["N"], cfg["H"], cfg["W"])
+    x = cu(torch.randn(B, cin, *shp))
+    w20 = ops.pack_conv_weight_bf16(cu(torch.randn(cmid, cin, 3, 3, 3) / (cin * 27) ** 0.5))
+    w21 = ops.pack_conv_weight_bf16(cu(torch.randn(cmid, cmid, 3, 3, 3) / (cmid * 27) ** 0.5))
+    bias, res = cu(torch.randn(cmid)), cu(torch.randn(B, cmid, *shp))
+    sh2, sc2 = cu(torch.randn(B, cmid) * 0.3), cu(torch.rand(B, cmid) + 0.5)
+    t1 = ops.conv3d([x], w20, cmid, 3, math="bf16", bias=bias, in_act=True)
+    want = ops.conv3d([t1], w21, cmid, 3, math="bf16", in_shift=sh2, in_scale=sc2, in_act=True, residual=res)
+    y, packed = ops.conv3d([x], w20, cmid, 3, math="bf16", bias=bias, in_act=True, emit=dict(act=True, shift=sh2, scale=sc2))
+    assert torch.equal(y, t1) and packed.dtype == torch.int16 and packed.shape == (B, cmid // 8, shp[0] * shp[1] * shp[2], 8)
+    # the packed tensor holds bf16(silu(t1 + shift) * scale), channel-octet major
+    v = t1 + sh2[:, :, None, None, None]
+    v = (v * torch.sigmoid(v)) * sc2[:, :, None, None, None]
+    ref = v.reshape(B, cmid // 8, 8, -1).permute(0, 1, 3, 2).to(torch.bfloat16)
+    got_bf = packed.view(torch.bfloat16)
+    assert (got_bf.float() - ref.float()).abs().max() <= 2 ** -7 * ref.float().abs().max()   # fast-exp vs torch: <= 1 bf16 ulp
+    got = ops.conv3d([packed], w21, cmid, 3, math="bf16", residual=res, x_bf16_shape=shp)
+    assert torch.equal(got, want)
+    only = ops.conv3d([x], w20, cmid, 3, math="bf16", bias=bias, in_act=True, keep_y=False,
+                      emit=dict(act=True, shift=sh2, scale=sc2))
+    assert torch.equal(only, packed)

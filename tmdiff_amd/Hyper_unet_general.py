@@ -22,6 +22,7 @@ dict prompt -> [1,768] tensor, or a path to a torch-saved dict) injects the pool
 defaulting to fixed seeded vectors (``synthetic_text_embeddings``).
 """
 import math
+import os
 
 import torch
 import torch.nn as nn
@@ -29,6 +30,7 @@ import torch.nn as nn
 from . import ops
 
 PROMPTS = ("QB", "WV3", "GF2", "WV2", "WV4")
+_EPILOGUE_FUSE = os.environ.get("TMDIFF_EPILOGUE_FUSE", "1") != "0"   # experiments: "0" = consumers apply their own prologue
 
 
 def synthetic_text_embeddings(seed=1234):
@@ -274,12 +276,15 @@ class WavBEST(nn.Module):
         sh = {} if flag else self._shift(P, S, name + ".dense1")
         res = self._conv(P, name + ".res_conv", segs) if isinstance(rb.res_conv, nn.Conv3d) else segs[0]
         sc = self._scale(P, S, name + ".dense2")
-        if name + ".conv20" not in P["bf16"]:
-            # conv20's result feeds conv21 only: its epilogue applies conv21's prologue (SiLU, text modulation), and
-            # conv21 reads a plain tensor (no prologue pass in front of the staged kernel; same bits either way)
+        # conv20's result feeds conv21 only: its epilogue applies conv21's prologue (SiLU, text modulation) and conv21
+        # reads that directly -- a plain fp32 tensor for the staged kernel, or the packed bf16 units in the bf16 mode
+        # (no prologue / pack pass in between; same bits either way)
+        both16 = name + ".conv20" in P["bf16"] and name + ".conv21" in P["bf16"]
+        if _EPILOGUE_FUSE and (both16 or (name + ".conv20" not in P["bf16"] and name + ".conv21" not in P["bf16"])):
             t1p = self._conv(P, name + ".conv20", segs, in_act=True, keep_y=False,
                              emit=dict(act=True, scale=sc["in_scale"], scale_stride=sc["scale_stride"]), **sh)
-            return self._conv(P, name + ".conv21", [t1p], use_bias=False, residual=res)
+            shape = tuple(res.shape[2:]) if both16 else None
+            return self._conv(P, name + ".conv21", [t1p], use_bias=False, residual=res, x_bf16_shape=shape)
         t1 = self._conv(P, name + ".conv20", segs, in_act=True, **sh)
         return self._conv(P, name + ".conv21", [t1], use_bias=False, in_act=True, residual=res, **sc)
 

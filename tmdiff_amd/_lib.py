@@ -27,7 +27,7 @@ class Conv3dDesc(C.Structure):
         ("residual", vp), ("out_scale", C.c_float),
         ("y", vp),
         ("y2", vp), ("y2_shift", vp), ("y2_scale", vp), ("y2_shift_stride", C.c_int32), ("y2_scale_stride", C.c_int32),
-        ("y2_act", C.c_int32), ("y2_bf16", C.c_int32),
+        ("y2_act", C.c_int32), ("y2_bf16", C.c_int32), ("x_bf16", C.c_int32),
     ]
 
 

@@ -44,7 +44,11 @@ struct BfArgs {
   int in_act;
   const float* residual;
   float out_scale;
-  float* y;
+  float* y;               // may be NULL when only y2 is wanted
+  uint4* y2;              // optional second output: bf16 units [B][Cout/8][plane] of act2(y + shift2) * scale2
+  const float* y2_shift;
+  const float* y2_scale;
+  int y2_shift_stride, y2_scale_stride, y2_act;
   int tiles_n, tiles_h, tiles_w, tiles_co;
   unsigned total_blocks;
 };
@@ -81,11 +85,32 @@ struct XLayout {
   }
 };
 
+// Lanes 32-63 of x trade places with lanes 0-31 of y (v_permlane32_swap_b32).
+__device__ __forceinline__ void swap_halves(unsigned& x, unsigned& y) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  const auto r = __builtin_amdgcn_permlane32_swap(x, y, false, false);
+  x = r[0], y = r[1];
+#endif
+}
+
+__device__ __forceinline__ unsigned pack_bf16x2(float lo, float hi) {
+  union { __attribute__((ext_vector_type(2))) __bf16 h; unsigned u; } p;
+  p.h[0] = (__bf16)lo, p.h[1] = (__bf16)hi;
+  return p.u;
+}
+
 // Epilogue shared by both kernels: D layout col = lane&31 (position), row (r&3) + 8*(r>>2) + 4*kg (channel);
 // bias_v[m] holds (in lane l31) the scaled bias of channel co0 + m*32 + l31.
 template <int NS, int MSUB, int TW>
 __device__ __forceinline__ void store_tile(const BfArgs& a, f32x16 (&acc)[NS][MSUB], const float (&bias_v)[MSUB], int b,
                                            int g, int co0, int n0, int h0, int w0, int wv, int l31, int kg, long plane) {
+  float sh2_v[MSUB], sc2_v[MSUB];  // second-output shift / scale of channel co0 + m*32 + l31
+#pragma unroll
+  for (int m = 0; m < MSUB; ++m) {
+    const int col = g * a.cout_g + co0 + m * 32 + l31;
+    sh2_v[m] = (a.y2 && a.y2_shift) ? a.y2_shift[(long)b * a.y2_shift_stride + col] : 0.f;
+    sc2_v[m] = (a.y2 && a.y2_scale) ? a.y2_scale[(long)b * a.y2_scale_stride + col] : 1.f;
+  }
 #pragma unroll
   for (int m = 0; m < MSUB; ++m) {
     float bias_r[16];
@@ -112,7 +137,38 @@ __device__ __forceinline__ void store_tile(const BfArgs& a, f32x16 (&acc)[NS][MS
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
         const int row = (r & 3) + 8 * (r >> 2);
-        if (pok) a.y[obase + row * plane] = (acc[s][m][r] + bias_r[r] + res[r]) * a.out_scale;
+        const float v = (acc[s][m][r] + bias_r[r] + res[r]) * a.out_scale;
+        if (pok && a.y) a.y[obase + row * plane] = v;
+        acc[s][m][r] = v;
+      }
+      if (a.y2) {
+        // The consumer's prologue on the finished values, rounded to bf16 and regrouped into units of 8 consecutive
+        // channels: register quads (0-3, 4-7) hold channels {0-3, 8-11} in lanes 0-31 and {4-7, 12-15} in lanes 32-63;
+        // trading halves gives lanes 0-31 channels 0-7 and lanes 32-63 channels 8-15 (same for quads 8-11, 12-15).
+        unsigned d[8];
+#pragma unroll
+        for (int r = 0; r < 16; r += 2) {
+          float t[2];
+#pragma unroll
+          for (int e = 0; e < 2; ++e) {
+            const int row = ((r + e) & 3) + 8 * ((r + e) >> 2);
+            const float s0 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(sh2_v[m]), row));
+            const float s1 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(sh2_v[m]), row + 4));
+            const float c0 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(sc2_v[m]), row));
+            const float c1 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(sc2_v[m]), row + 4));
+            float u = acc[s][m][r + e] + (kg ? s1 : s0);
+            const float ua = tmdiff::silu_f(u);
+            t[e] = (a.y2_act ? ua : u) * (kg ? c1 : c0);
+          }
+          d[r / 2] = pack_bf16x2(t[0], t[1]);
+        }
+        swap_halves(d[0], d[2]); swap_halves(d[1], d[3]);   // quads 0 / 1
+        swap_halves(d[4], d[6]); swap_halves(d[5], d[7]);   // quads 2 / 3
+        const long ubase = ((long)b * (a.Cout / 8) + (g * a.cout_g + co0 + m * 32) / 8 + kg) * plane + sp;
+        if (pok) {
+          a.y2[ubase] = make_uint4(d[0], d[1], d[2], d[3]);              // channel octet kg
+          a.y2[ubase + 2 * plane] = make_uint4(d[4], d[5], d[6], d[7]);  // channel octet 2 + kg
+        }
       }
     }
   }
@@ -636,14 +692,16 @@ int launch(BfArgs& a, hipStream_t st) {
 }
 
 template <int NS, int MSUB, int TH, int TW>
-int launch_dma(BfArgs& a, uint4* xp, hipStream_t st) {
+int launch_dma(BfArgs& a, uint4* xp, hipStream_t st, bool do_pack = true) {
   constexpr int CO = 32 * MSUB;
   const long plane = (long)a.N * a.H * a.W;
-  long pb = (plane + 255) / 256;
-  if (pb > 1024) pb = 1024;
-  const dim3 pgrid((unsigned)pb, (unsigned)(a.B * (a.Cin / 8)));
-  if (a.in_act) pack_x_bf16_kernel<true><<<pgrid, 256, 0, st>>>(a, xp);
-  else pack_x_bf16_kernel<false><<<pgrid, 256, 0, st>>>(a, xp);
+  if (do_pack) {
+    long pb = (plane + 255) / 256;
+    if (pb > 1024) pb = 1024;
+    const dim3 pgrid((unsigned)pb, (unsigned)(a.B * (a.Cin / 8)));
+    if (a.in_act) pack_x_bf16_kernel<true><<<pgrid, 256, 0, st>>>(a, xp);
+    else pack_x_bf16_kernel<false><<<pgrid, 256, 0, st>>>(a, xp);
+  }
   a.tiles_n = (a.N + TN - 1) / TN;
   a.tiles_h = (a.H + TH - 1) / TH;
   a.tiles_w = (a.W + TW - 1) / TW;
@@ -711,8 +769,16 @@ extern "C" int tmdiff_conv3d_fwd_bf16(const tmdiff_conv3d_desc* d, void* workspa
   if (d->groups == 3)
     TMDIFF_REQUIRE(d->nseg == 1 || (d->nseg == 3 && d->seg_c[0] == d->seg_c[1] && d->seg_c[1] == d->seg_c[2]),
                    "conv3d_fwd_bf16: groups=3 wants 1 segment or 3 equal ones");
-  TMDIFF_REQUIRE(d->w_packed && d->y, "conv3d_fwd_bf16: NULL weights/output");
-  if (d->y2) return fail(TMDIFF_E_UNSUPPORTED, "conv3d_fwd_bf16: second output not implemented");
+  TMDIFF_REQUIRE(d->w_packed && (d->y || d->y2), "conv3d_fwd_bf16: NULL weights/output");
+  if (d->y2) {
+    if (!d->y2_bf16) return fail(TMDIFF_E_UNSUPPORTED, "conv3d_fwd_bf16: the second output is written as bf16 units (y2_bf16)");
+    if (d->ksize != 3) return fail(TMDIFF_E_UNSUPPORTED, "conv3d_fwd_bf16: second output for 3x3x3 only");
+    TMDIFF_REQUIRE(aligned16(d->y2), "conv3d_fwd_bf16: y2 must be 16-byte aligned");
+  }
+  if (d->x_bf16) {
+    TMDIFF_REQUIRE(d->ksize == 3 && d->nseg == 1 && !d->in_shift && !d->in_scale && !d->in_act && aligned16(d->seg_x[0]),
+                   "conv3d_fwd_bf16: a bf16-packed input is one 16-byte aligned tensor without prologue, 3x3x3 only");
+  }
   TMDIFF_REQUIRE(aligned16(d->w_packed), "conv3d_fwd_bf16: packed weights must be 16-byte aligned");
   TMDIFF_REQUIRE((long)d->N * d->H * d->W < (1L << 31), "conv3d_fwd_bf16: plane too large for 32-bit offsets");
 
@@ -729,7 +795,16 @@ extern "C" int tmdiff_conv3d_fwd_bf16(const tmdiff_conv3d_desc* d, void* workspa
   a.shift_stride = d->in_shift_stride > 0 ? d->in_shift_stride : (d->in_shift_stride < 0 ? 0 : d->Cin);
   a.scale_stride = d->in_scale_stride > 0 ? d->in_scale_stride : (d->in_scale_stride < 0 ? 0 : d->Cin);
   a.residual = d->residual; a.out_scale = d->out_scale; a.y = d->y;
+  a.y2 = reinterpret_cast<uint4*>(d->y2); a.y2_shift = d->y2_shift; a.y2_scale = d->y2_scale; a.y2_act = d->y2_act;
+  a.y2_shift_stride = d->y2_shift_stride > 0 ? d->y2_shift_stride : (d->y2_shift_stride < 0 ? 0 : d->Cout);
+  a.y2_scale_stride = d->y2_scale_stride > 0 ? d->y2_scale_stride : (d->y2_scale_stride < 0 ? 0 : d->Cout);
   hipStream_t st = as_stream(stream);
+  if (d->x_bf16) {  // input already packed by its producer: straight to the staging-free kernel
+    const uint4* xp = reinterpret_cast<const uint4*>(d->seg_x[0]);
+    if (cout_g % 64 == 0) return launch_dma<2, 2, 8, 8>(a, const_cast<uint4*>(xp), st, false);
+    return d->W >= 16 ? launch_dma<4, 1, 8, 16>(a, const_cast<uint4*>(xp), st, false)
+                      : launch_dma<2, 1, 8, 8>(a, const_cast<uint4*>(xp), st, false);
+  }
   if (d->ksize == 1) {  // bandwidth kernel, no workspace
     if (cout_g % 128 == 0) return launch_k1<1, 4>(a, st);
     return cout_g % 64 == 0 ? launch_k1<2, 2>(a, st) : launch_k1<4, 1>(a, st);

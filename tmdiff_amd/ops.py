@@ -59,20 +59,35 @@ def pack_conv_weight_bf16(w, groups=1):
 
 def make_conv_desc(segs, w_packed, cout, ksize, y, groups=1, bias=None, bias_scale=1.0, in_shift=None, in_scale=None,
                    shift_stride=0, scale_stride=0, in_act=False, in_mask=None, residual=None, out_scale=1.0,
-                   y2=None, y2_shift=None, y2_scale=None, y2_shift_stride=0, y2_scale_stride=0, y2_act=False):
+                   y2=None, y2_shift=None, y2_scale=None, y2_shift_stride=0, y2_scale_stride=0, y2_act=False,
+                   x_bf16_shape=None):
     """Fill a tmdiff_conv3d_desc.  `segs` = list of 1..3 tensors [B, c_i, N, H, W] (concat-free input).
     in_shift / in_scale may be tensors or raw (ptr) ints into a projection bank.  y may be None when only the second
-    output y2 = act2(y + y2_shift) * y2_scale (the consumer's prologue, same pointer conventions) is wanted."""
+    output y2 = act2(y + y2_shift) * y2_scale (the consumer's prologue, same pointer conventions) is wanted.
+    A y2 of dtype int16 is written as bf16 units [B, Cout/8, N*H*W, 8]; x_bf16_shape = (N, H, W) says that segs[0] is
+    such a tensor (bf16 entry point only)."""
     d = Conv3dDesc()
-    b, _, n, h, w = segs[0].shape
-    d.B, d.N, d.H, d.W = b, n, h, w
-    d.Cin = sum(s.shape[1] for s in segs)
-    d.Cout, d.groups, d.ksize, d.nseg = cout, groups, ksize, len(segs)
-    for i, s in enumerate(segs):
-        if tuple(s.shape[2:]) != (n, h, w) or s.shape[0] != b:
-            raise ValueError("conv3d: input segments disagree on [B, N, H, W]")
-        d.seg_c[i] = s.shape[1]
-        d.seg_x[i] = _chk(s, f"segment {i}")
+    if x_bf16_shape is not None:
+        xp = segs[0]
+        if len(segs) != 1 or xp.dtype != torch.int16 or xp.dim() != 4 or xp.shape[3] != 8 or not xp.is_contiguous():
+            raise ValueError("conv3d: a bf16-packed input is one contiguous int16 tensor [B, Cin/8, N*H*W, 8]")
+        b, (n, h, w) = xp.shape[0], x_bf16_shape
+        if xp.shape[2] != n * h * w:
+            raise ValueError("conv3d: packed input does not match x_bf16_shape")
+        d.B, d.N, d.H, d.W = b, n, h, w
+        d.Cin = xp.shape[1] * 8
+        d.Cout, d.groups, d.ksize, d.nseg = cout, groups, ksize, 1
+        d.seg_c[0], d.seg_x[0], d.x_bf16 = d.Cin, xp.data_ptr(), 1
+    else:
+        b, _, n, h, w = segs[0].shape
+        d.B, d.N, d.H, d.W = b, n, h, w
+        d.Cin = sum(s.shape[1] for s in segs)
+        d.Cout, d.groups, d.ksize, d.nseg = cout, groups, ksize, len(segs)
+        for i, s in enumerate(segs):
+            if tuple(s.shape[2:]) != (n, h, w) or s.shape[0] != b:
+                raise ValueError("conv3d: input segments disagree on [B, N, H, W]")
+            d.seg_c[i] = s.shape[1]
+            d.seg_x[i] = _chk(s, f"segment {i}")
     if not isinstance(w_packed, int) and not (w_packed.is_cuda and w_packed.is_contiguous()):
         raise ValueError("w_packed: need a contiguous packed-weight tensor on the GPU")
     d.w_packed = w_packed if isinstance(w_packed, int) else w_packed.data_ptr()
@@ -88,18 +103,21 @@ def make_conv_desc(segs, w_packed, cout, ksize, y, groups=1, bias=None, bias_sca
         raise ValueError("conv3d: residual shape != output shape")
     d.residual = _chk(residual, "residual")
     d.out_scale = out_scale
-    for t, nm in ((y, "y"), (y2, "y2")):
+    y2_packed = y2 is not None and y2.dtype == torch.int16
+    for t, nm in ((y, "y"), (None if y2_packed else y2, "y2")):
         if t is not None and tuple(t.shape) != oshape:
             raise ValueError(f"conv3d: {nm} shape {tuple(t.shape)} != {oshape}")
+    if y2_packed and (tuple(y2.shape) != (b, cout // 8, n * h * w, 8) or not (y2.is_cuda and y2.is_contiguous())):
+        raise ValueError(f"conv3d: packed y2 shape {tuple(y2.shape)} != {(b, cout // 8, n * h * w, 8)}")
     if y is None and y2 is None:
         raise ValueError("conv3d: no output")
     d.y = _chk(y, "y")
-    d.y2 = _chk(y2, "y2")
+    d.y2 = y2.data_ptr() if y2_packed else _chk(y2, "y2")
     d.y2_shift = y2_shift if isinstance(y2_shift, int) else _chk(y2_shift, "y2_shift")
     d.y2_scale = y2_scale if isinstance(y2_scale, int) else _chk(y2_scale, "y2_scale")
     d.y2_shift_stride, d.y2_scale_stride = y2_shift_stride, y2_scale_stride
     d.y2_act = 1 if y2_act else 0
-    d.y2_bf16 = 0
+    d.y2_bf16 = 1 if y2_packed else 0
     return d
 
 
@@ -139,19 +157,26 @@ def _workspace(device, nbytes):
 
 
 def conv3d(segs, w_packed, cout, ksize, out=None, math="fp32", pack_input=None, staged=None, emit=None, keep_y=True,
-           **kw):
+           x_bf16_shape=None, **kw):
     """math="fp32": exact-fp32 MFMA kernel (w_packed from pack_conv_weight); "bf16": bf16 operands / fp32
     accumulation (w_packed from pack_conv_weight_bf16).  pack_input (bf16 only): True = pack the prologue output to
     bf16 once and run the staging-free kernel (default), False = one fused kernel.  staged (fp32 only): True = prologue
     pass + global_load_lds staged kernel (default where the shape allows), False = the fused kernel.
     emit = dict(act=, shift=, scale=, shift_stride=, scale_stride=): also produce y2 = act(y + shift) * scale, the
-    consumer's prologue applied in this convolution's epilogue; returns (y, y2), or y2 alone with keep_y=False."""
-    b, _, n, h, w = segs[0].shape
+    consumer's prologue applied in this convolution's epilogue; returns (y, y2), or y2 alone with keep_y=False.  In the
+    bf16 mode y2 is the packed bf16 tensor [B, Cout/8, N*H*W, 8] (int16 storage) that a following bf16 convolution takes
+    as its input with x_bf16_shape=(N, H, W), skipping its pack pass."""
+    if x_bf16_shape is not None:
+        b, (n, h, w) = segs[0].shape[0], x_bf16_shape
+        kw = dict(kw, x_bf16_shape=x_bf16_shape)
+    else:
+        b, _, n, h, w = segs[0].shape
     dev = segs[0].device
     y = out if out is not None else (torch.empty(b, cout, n, h, w, device=dev, dtype=torch.float32) if keep_y else None)
     y2 = None
     if emit is not None:
-        y2 = torch.empty(b, cout, n, h, w, device=dev, dtype=torch.float32)
+        y2 = (torch.empty(b, cout // 8, n * h * w, 8, device=dev, dtype=torch.int16) if math == "bf16"
+              else torch.empty(b, cout, n, h, w, device=dev, dtype=torch.float32))
         kw = dict(kw, y2=y2, y2_act=emit.get("act", False), y2_shift=emit.get("shift"), y2_scale=emit.get("scale"),
                   y2_shift_stride=emit.get("shift_stride", 0), y2_scale_stride=emit.get("scale_stride", 0))
     elif y is None:
@@ -164,7 +189,7 @@ def conv3d(segs, w_packed, cout, ksize, out=None, math="fp32", pack_input=None, 
         if pack_input is None:
             pack_input = {"0": False, "1": True}.get(_BF16_PACK, True)   # measured: the two-kernel variant wins on every production layer
         ws = (_workspace(dev, lib.tmdiff_conv3d_bf16_workspace_bytes(C.byref(d))).data_ptr()
-              if pack_input and ksize == 3 else None)
+              if pack_input and ksize == 3 and x_bf16_shape is None else None)
         fwd, what = (lambda dd, st: lib.tmdiff_conv3d_fwd_bf16(dd, ws, st)), "conv3d_fwd_bf16"
     elif math == "fp32":
         if not isinstance(w_packed, int) and w_packed.dtype != torch.float32:
