@@ -541,3 +541,24 @@ def test_conv3d_bf16_packed_second_output(ops, cfg):
     only = ops.conv3d([x], w20, cmid, 3, math="bf16", bias=bias, in_act=True, keep_y=False,
                       emit=dict(act=True, shift=sh2, scale=sc2))
     assert torch.equal(only, packed)
+
+
+def test_conv3d_large_plane_config3_shape(ops):
+    """One level-0 convolution at the config-3 plane size (8 x 256 x 256 = 524288 positions per channel): offsets, tiling
+    and zero padding on a large plane, for the fused, staged and bf16 kernels, against the CPU convolution."""
+    torch.manual_seed(41)
+    cin, cout = 16, 32
+    x = torch.randn(1, cin, 8, 256, 256)
+    w = torch.randn(cout, cin, 3, 3, 3) / (cin * 27) ** 0.5
+    sc = torch.rand(1, cin) + 0.5
+    xs = x * torch.sigmoid(x) * sc[:, :, None, None, None]
+    want = F.conv3d(xs, w, padding=1)
+    wp = ops.pack_conv_weight(cu(w))
+    for staged in (False, True):
+        y = ops.conv3d([cu(x)], wp, cout, 3, in_scale=cu(sc), in_act=True, staged=staged)
+        assert_close(y, want, 2e-5, 2e-6, f"large plane, staged={staged}")
+    y16 = ops.conv3d([cu(x)], ops.pack_conv_weight_bf16(cu(w)), cout, 3, math="bf16", in_scale=cu(sc), in_act=True)
+    assert_close(y16, want, 3e-2, 1e-2, "large plane, bf16")
+    # borders are where the padding logic lives: compare them separately at full precision budget
+    for sl in (np.s_[..., 0, :, :], np.s_[..., -1, :, :], np.s_[..., :, 0, :], np.s_[..., :, -1, :], np.s_[..., 0], np.s_[..., -1]):
+        assert_close(y.cpu()[sl], want[sl], 2e-5, 2e-6, "border")
