@@ -45,9 +45,10 @@ __device__ __forceinline__ float block_sum_256(float v, float* red) {
 //   K step = 2 positions.
 // x' (the prologue output) is formed once per convolution by prologue_apply_kernel (it used to be re-evaluated by
 // every channel tile); the wgrad kernel then only copies.  A workgroup owns a 32x32 (co, ci) tile and walks a list
-// of 2x8x8 position boxes; per box it stages the g box [32][128] and the haloed x' box [32][4*10*10] in LDS (odd
-// row strides: conflict-free column reads).  The next box is fetched into registers while the MFMAs of this one
-// run (a box is 64 K-steps x 7 taps = 448 MFMAs per wave); all LDS operand reads have compile-time offsets.
+// of 2x8x8 position boxes; per box the g box [32][128] and the haloed x' box [32][4*10*10] are brought into LDS
+// (odd row strides: conflict-free column reads) by global_load_lds -- no registers, no ds_write -- into one of two
+// stages while the MFMAs of the previous box run out of the other (a box is 64 K-steps x 7 taps = 448 MFMAs per
+// wave; one barrier per box; all LDS operand reads have compile-time offsets).
 // KS=3: wave w accumulates taps w, w+4, ... (7 accumulators, the g operand is shared by all of them); KS=1: the
 // four waves split the positions of the box and their partials are separate splits.
 // Partials go to workspace[split][g][tap][co][ci]; wgrad_reduce_kernel sums the splits into PyTorch layout.
@@ -97,18 +98,27 @@ __global__ void __launch_bounds__(256) prologue_apply_kernel(const ApplyArgs a) 
   }
 }
 
+__device__ const float kZeroWord = 0.f;  // DMA source of zero padding / out-of-range channels
+
+__device__ __forceinline__ void dma_word(const float* src, float* dst) {
+#if defined(__HIP_DEVICE_COMPILE__)  // the builtin exists in the device pass only
+  __builtin_amdgcn_global_load_lds(src, dst, 4, 0, 0);  // 64 lanes x 4 bytes -> dst + lane*4 (dst wave-uniform)
+#endif
+}
+
 template <int KS>
-__global__ void __launch_bounds__(256, 2) conv3d_wgrad_kernel(const WgradArgs a) {
+__global__ void __launch_bounds__(256, 1) conv3d_wgrad_kernel(const WgradArgs a) {
   constexpr int TAPS = KS * KS * KS, HALO = KS / 2;
   constexpr int BN = 2, BH = 8, BW = 8, POSB = BN * BH * BW;            // 128 positions per box
   constexpr int HN = BN + 2 * HALO, HH = BH + 2 * HALO, HW = BW + 2 * HALO;
   constexpr int XE = HN * HH * HW;                                      // haloed box elements
-  constexpr int GS = POSB + 1, XS = XE | 1;                             // odd LDS row strides
+  constexpr int XJ = (XE + 63) / 64, GJ = POSB / 64;                    // wave-wide 256-byte pieces per channel row
+  constexpr int GS = GJ * 64 + 1, XS = XJ * 64 + 1;                     // odd LDS row strides holding whole pieces
   constexpr int NT = KS == 3 ? 7 : 1;                                   // accumulators per wave
-  constexpr int XJ = (XE + 63) / 64, GJ = POSB / 64;  // wave-wide pieces per channel row (x': the last one is partial)
-  constexpr int DUMMY = 32 * XS;                     // LDS word that absorbs the lanes of a partial piece
-  __shared__ float gt[32 * GS];
-  __shared__ float xt[32 * XS + 1];
+  constexpr int STAGE = 32 * GS + 32 * XS;                              // g box [32][GS], then x' box [32][XS]
+  constexpr int NPIECE = 8 * (GJ + XJ);                                 // pieces per wave per box (8 channel rows)
+  __shared__ float st0[STAGE];
+  __shared__ float st1[STAGE];
 
   const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, l31 = lane & 31, khalf = lane >> 5;
   int id = blockIdx.x;
@@ -125,100 +135,120 @@ __global__ void __launch_bounds__(256, 2) conv3d_wgrad_kernel(const WgradArgs a)
 #pragma unroll
     for (int r = 0; r < 16; ++r) acc[j][r] = 0.f;
 
-  // ---- staging: wave w copies channels 8w .. 8w+7 of both boxes; a load instruction covers 64 consecutive box
-  //      elements of ONE channel, so the channel base is wave-uniform (scalar) and the per-lane position offset is
-  //      shared by all 8 channels: per box XJ + GJ offset computations per lane instead of one per element.
-  float gr[8][GJ], xr[8][XJ];
-  unsigned gok = 0, xok = 0;  // bit j: piece j of this lane lies inside the image
-  auto prefetch = [&](long bx) __attribute__((always_inline)) {
+  // ---- staging by LDS-DMA: wave w brings in channel rows 8w .. 8w+7 of both boxes, one 64-element piece per
+  //      instruction (the channel base is wave-uniform; the per-lane position offset is shared by the 8 rows).
+  //      Out-of-image positions, layout filler and out-of-range channels read a zero word.
+  int goff[GJ], xoff[XJ];  // position offset inside a channel plane, or -1
+  const float* gbase;      // g  [b][g*cout_g + co0]
+  const float* xbase;      // x' [b][g*cin_g + ci0]
+  auto locate = [&](long bx) __attribute__((always_inline)) {
     unsigned t = (unsigned)bx;
     const int bw_i = (int)(t % (unsigned)a.nbw); t /= (unsigned)a.nbw;
     const int bh_i = (int)(t % (unsigned)a.nbh); t /= (unsigned)a.nbh;
     const int bn_i = (int)(t % (unsigned)a.nbn);
     const int b = (int)(t / (unsigned)a.nbn);
     const int n0 = bn_i * BN, h0 = bh_i * BH, w0 = bw_i * BW;
-    // (bitwise & on purpose: && would branch around the loads)
-    unsigned goff[GJ], xoff[XJ];
-    gok = 0; xok = 0;
 #pragma unroll
     for (int j = 0; j < GJ; ++j) {
       const int p = j * 64 + lane;
       const int n = n0 + p / (BH * BW), h = h0 + (p / BW) % BH, w = w0 + p % BW;
       const bool ok = (n < a.N) & (h < a.H) & (w < a.W);
-      goff[j] = ok ? (unsigned)((n * a.H + h) * a.W + w) : 0u;
-      gok |= (unsigned)ok << j;
+      goff[j] = ok ? (n * a.H + h) * a.W + w : -1;
     }
 #pragma unroll
     for (int j = 0; j < XJ; ++j) {
       const int e = j * 64 + lane;
       const int n = n0 + e / (HH * HW) - HALO, h = h0 + (e / HW) % HH - HALO, w = w0 + e % HW - HALO;
       const bool ok = (e < XE) & ((unsigned)n < (unsigned)a.N) & ((unsigned)h < (unsigned)a.H) & ((unsigned)w < (unsigned)a.W);
-      xoff[j] = ok ? (unsigned)((n * a.H + h) * a.W + w) : 0u;
-      xok |= (unsigned)ok << j;
+      xoff[j] = ok ? (n * a.H + h) * a.W + w : -1;
     }
-#pragma unroll
-    for (int c = 0; c < 8; ++c) {
-      const int ch = wv * 8 + c;  // wave-uniform
-      const float* gb = a.g + ((long)b * a.Cout + g * a.cout_g + (co0 + ch < a.cout_g ? co0 + ch : 0)) * plane;
-      const float* xb = a.xp + ((long)b * a.Cin + g * a.cin_g + (ci0 + ch < a.cin_g ? ci0 + ch : 0)) * plane;
-#pragma unroll
-      for (int j = 0; j < GJ; ++j) gr[c][j] = gb[goff[j]];
-#pragma unroll
-      for (int j = 0; j < XJ; ++j) xr[c][j] = xb[xoff[j]];
-    }
+    gbase = a.g + ((long)b * a.Cout + g * a.cout_g + co0) * plane;
+    xbase = a.xp + ((long)b * a.Cin + g * a.cin_g + ci0) * plane;
   };
-  auto stage = [&]() __attribute__((always_inline)) {
-#pragma unroll
-    for (int c = 0; c < 8; ++c) {
-      const int ch = wv * 8 + c;
-      const bool gch = co0 + ch < a.cout_g, xch = ci0 + ch < a.cin_g;
-#pragma unroll
-      for (int j = 0; j < GJ; ++j) gt[ch * GS + j * 64 + lane] = (gch & ((gok >> j) & 1)) ? gr[c][j] : 0.f;
-#pragma unroll
-      for (int j = 0; j < XJ; ++j) {
-        const int e = j * 64 + lane;
-        xt[(XE % 64 == 0 || j + 1 < XJ || e < XE) ? ch * XS + e : DUMMY] = (xch & ((xok >> j) & 1)) ? xr[c][j] : 0.f;
+  auto issue_piece = [&](auto ic, float* st) __attribute__((always_inline)) {
+    constexpr int i = decltype(ic)::value;
+    if constexpr (i < NPIECE) {
+      constexpr int c = i / (GJ + XJ), j = i % (GJ + XJ);
+      const int ch = wv * 8 + c;  // wave-uniform
+      if constexpr (j < GJ) {
+        const bool ok = (goff[j] >= 0) & (co0 + ch < a.cout_g);
+        dma_word(ok ? gbase + (long)ch * plane + goff[j] : &kZeroWord, st + ch * GS + j * 64);
+      } else {
+        constexpr int jj = j - GJ;
+        const bool ok = (xoff[jj] >= 0) & (ci0 + ch < a.cin_g);
+        dma_word(ok ? xbase + (long)ch * plane + xoff[jj] : &kZeroWord, st + 32 * GS + ch * XS + jj * 64);
       }
     }
   };
-  const float* ga = gt + l31 * GS + khalf;   // A operand of K-step ks: ga[2*ks]
-  const float* xa = xt + l31 * XS + khalf;   // B operand: xa[box offset of position 2*ks + tap offset]
-  const float* xj[NT];                       // ... with the (wave-uniform) tap offset of accumulator j folded in
+
+  const int ga_off = l31 * GS + khalf;              // A operand of K-step ks: st[ga_off + 2*ks]
+  int xj_off[NT];                                   // B operand base with the (wave-uniform) tap offset folded in
 #pragma unroll
   for (int j = 0; j < NT; ++j) {
     const int tap = KS == 3 ? min(wv + 4 * j, TAPS - 1) : 0;
-    xj[j] = xa + ((tap / (KS * KS)) * HH + (tap / KS) % KS) * HW + tap % KS;
+    xj_off[j] = 32 * GS + l31 * XS + khalf + ((tap / (KS * KS)) * HH + (tap / KS) % KS) * HW + tap % KS;
   }
-  auto mfma_box = [&]() __attribute__((always_inline)) {
+  // MFMAs of the box in `st`; the pieces of the next box go into `st_next`, spread evenly between the K-steps
+  // (a burst of 72 DMA issues would keep the wave off the matrix pipe for a quarter of the box).
+  auto mfma_box = [&](const float* st, float* st_next) __attribute__((always_inline)) {
     constexpr int KSTEPS = POSB / 2, PER_WAVE = KS == 3 ? KSTEPS : KSTEPS / 4;
-    static_for<0, PER_WAVE>([&](auto kc) __attribute__((always_inline)) {
+    float av[2], bv[2][NT];
+    // operands of K-step k (one workgroup per CU = one wave per SIMD: nobody else hides the LDS latency, so the
+    // reads of step k+1 are requested behind the first MFMA of step k)
+    auto fetch = [&](auto kc) __attribute__((always_inline)) {
       constexpr int k0 = decltype(kc)::value;
       if constexpr (KS == 3) {
         constexpr int p = 2 * k0;
         constexpr int pn = p / (BH * BW), ph = (p / BW) % BH, pw = p % BW;
-        const float av = ga[p];
+        av[k0 & 1] = st[ga_off + p];
 #pragma unroll
-        for (int j = 0; j < NT; ++j) {
-          // (wave 3 has no 7th tap: it repeats tap 26 into an accumulator that is never stored)
-          acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, xj[j][(pn * HH + ph) * HW + pw], acc[j], 0, 0, 0);
-        }
+        for (int j = 0; j < NT; ++j) bv[k0 & 1][j] = st[xj_off[j] + (pn * HH + ph) * HW + pw];
       } else {
         const int p = 2 * (wv * PER_WAVE + k0);
-        acc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(ga[p], xa[p], acc[0], 0, 0, 0);
+        av[k0 & 1] = st[ga_off + p];
+        bv[k0 & 1][0] = st[xj_off[0] + p];
       }
-      if constexpr (k0 % 2 == 1) __builtin_amdgcn_sched_barrier(0);  // keep the operand reads of later K-steps out of flight
+    };
+    fetch(std::integral_constant<int, 0>{});
+    static_for<0, PER_WAVE>([&](auto kc) __attribute__((always_inline)) {
+      constexpr int k0 = decltype(kc)::value;
+      static_for<0, NT>([&](auto jc) __attribute__((always_inline)) {
+        constexpr int j = decltype(jc)::value;
+        // (wave 3 has no 7th tap: it repeats tap 26 into an accumulator that is never stored)
+        acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[k0 & 1], bv[k0 & 1][j], acc[j], 0, 0, 0);
+        if constexpr (j == 0) {
+          __builtin_amdgcn_sched_barrier(0);
+          if constexpr (k0 + 1 < PER_WAVE) fetch(std::integral_constant<int, k0 + 1>{});
+          __builtin_amdgcn_sched_barrier(0);
+        }
+      });
+      __builtin_amdgcn_sched_barrier(0);
+      // (all pieces go out in the first 5/8 of the box, so that the last ones have landed when the barrier comes)
+      constexpr int SPAN = PER_WAVE * 5 / 8 > 0 ? PER_WAVE * 5 / 8 : 1;
+      constexpr int p_lo = k0 < SPAN ? k0 * NPIECE / SPAN : NPIECE, p_hi = k0 < SPAN ? (k0 + 1) * NPIECE / SPAN : NPIECE;
+      static_for<p_lo, p_hi>([&](auto ic) __attribute__((always_inline)) { issue_piece(ic, st_next); });
+      __builtin_amdgcn_sched_barrier(0);
     });
   };
 
   const long box_lo = (long)split * a.boxes_per_split;
   const long box_hi = min(box_lo + a.boxes_per_split, a.total_boxes);
-  if (box_lo < box_hi) prefetch(box_lo);
-  for (long bx = box_lo; bx < box_hi; ++bx) {
-    __syncthreads();  // previous box fully consumed
-    stage();
+  if (box_lo < box_hi) {
+    locate(box_lo);
+    static_for<0, NPIECE>([&](auto ic) __attribute__((always_inline)) { issue_piece(ic, st0); });
+  }
+  __syncthreads();
+  for (long bx = box_lo; bx < box_hi; bx += 2) {
+    // (past the last box the first box is fetched again into the idle stage: valid addresses, nobody reads it, and
+    //  the MFMA stream stays free of branches)
+    locate(bx + 1 < box_hi ? bx + 1 : box_lo);
+    mfma_box(st0, st1);
     __syncthreads();
-    if (bx + 1 < box_hi) prefetch(bx + 1);
-    mfma_box();
+    if (bx + 1 < box_hi) {
+      locate(bx + 2 < box_hi ? bx + 2 : box_lo);
+      mfma_box(st1, st0);
+      __syncthreads();
+    }
   }
   // ---- partial sums -> workspace[slot][g][tap][co][ci]; D layout: col = l31 (ci), row = co ----------------------
   const int slot = KS == 3 ? split : split * 4 + wv;
