@@ -228,6 +228,9 @@ def main():
             "unet_tflops": round(BATCH * GFLOP_PER_SAMPLE * 1e-3 * args.steps / dt, 2),
             "roofline": {"bound": "mfma", "achieved": round(achieved, 2), "peak": PEAK_FP32_MFMA, "unit": "TFLOP/s",
                          "frac": round(achieved / PEAK_FP32_MFMA, 4), "traffic": None,
+                         "traffic_note": "not collected live; PMC passes over the same layer shapes (profiles/"
+                                         "r01_conv_pmc_microbench.txt): 14.7 GB per B=32 forward over its 51 3x3x3 launches "
+                                         "= 288 MB per launch against 188 MB of input + output bytes",
                          "kernel": "3x3x3 conv launches, fp32 v_mfma_f32_32x32x2_f32: conv3d_mfma_kernel<3,..> (fused prologue) "
                                    "or prologue_apply_kernel + conv3d_dma_kernel<3,..> (staged), chosen per layer",
                          "launches": n3, "avg_launch_us": round(ms3 / max(n3, 1) * 1e3, 2),
