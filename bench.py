@@ -81,7 +81,14 @@ def cpu_baseline():
             if steps % 8 == 0:
                 log(f"cpu_baseline: step {steps} at {time.perf_counter() - t0:.1f} s")
         dt = time.perf_counter() - t0
-    return {"value": round(b * steps / dt / BATCH, 6), "unit": "batch32-steps/s", "cores": cores, "kind": "port",
+    model = "unknown"
+    try:
+        with open("/proc/cpuinfo") as f:
+            model = next((l.split(":", 1)[1].strip() for l in f if l.startswith("model name")), model)
+    except OSError:
+        pass
+    return {"value": round(b * steps / dt / BATCH, 6), "unit": "batch32-steps/s", "cores": cores, "cpu_model": model,
+            "kind": "port",
             "sample": f"{steps} p_sample steps on {b} tiles of 8x64x64 ({dt:.1f} s), scaled to batch {BATCH}; "
                       f"torch {torch.__version__} CPU, {cores} threads",
             "sample_steps_per_s": round(b * steps / dt, 4)}
