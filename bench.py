@@ -5,11 +5,18 @@ A *step* is one ``GeneralDiffusion.p_sample`` call on the batch: the full WavBES
 branches, 172.39 conv-GFLOP per sample -- exactly the work the reference does per step) plus the
 fused DDPM update.  Inputs are resident in HBM before the timed region.  fp32 throughout.
 
-    python bench.py [--gpus N] [--steps K] [--warmup W]
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--mode sample|train]
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
 
 With N > 1 every rank denoises its own batch of 32 tiles (inference is batch-parallel: no collective on
-the data path, "scaling": "weak"); value = N*K / max-over-ranks time.
+the data path, "scaling": "weak"); value = N*K / max-over-ranks time.  Started WITHOUT a launcher (no WORLD_SIZE in
+the environment) and with --gpus N > 1, this script is its own launcher: the parent starts N worker processes (one
+per GPU, RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* set, backend nccl = RCCL) before it has touched the GPU, waits
+for them and exits with their status -- it never initialises HIP and never re-execs itself.
+
+--mode train measures the finetune step of BASELINE configs[3] instead (local batch 8 per GPU, ch 32-256, dropout on,
+forward + backward + SUM all-reduce of the gradients over RCCL overlapped with backward + AdamW + EMA); the default
+mode also reports a short run of it as `train_step`, beside `value`.
 
 Extra objects on the JSON line (tier contract):
   roofline      conv3d 3x3x3 MFMA kernel: algorithmic FLOPs / summed HIP-event kernel durations measured
@@ -25,10 +32,10 @@ Extra objects on the JSON line (tier contract):
 import argparse
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
-
-import torch
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
@@ -37,6 +44,27 @@ FULL = [32, 64, 128, 256]
 BATCH, BANDS, SIZE, T = 32, 8, 64, 1000
 GFLOP_PER_SAMPLE = 172.39          # algorithmic conv FLOPs per sample per forward
 PEAK_FP32_MFMA = 157.3             # TFLOP/s, MI355X_MICROARCH.md
+
+
+def launch_ranks(args):
+    """Parent of a launcher-less multi-GPU run: start one worker per GPU and wait.  Nothing here touches the GPU
+    (torch.cuda.device_count() does not initialise HIP on this image; it is only read to fail early and loudly)."""
+    n = args.gpus
+    if not args.rehearse:
+        import torch
+        ndev = torch.cuda.device_count()
+        if ndev < n:
+            raise SystemExit(f"bench.py --gpus {n}: only {ndev} GPU(s) visible")
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    procs = []
+    for r in range(n):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n),
+                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0")
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env))
+    rcs = [p.wait() for p in procs]
+    return max(abs(rc) for rc in rcs)
 
 
 def log(msg):
@@ -58,6 +86,7 @@ def usable_cores():
 
 def cpu_baseline():
     """The oracle on the host cores: p_sample steps on a bounded sample (~10-30 s), scaled to batch 32."""
+    import torch
     from oracle import unet_ref as U
     from oracle.diffusion_ref import GeneralDiffusionRef
     from tmdiff_amd.util import synthetic_tile_batch
@@ -97,6 +126,7 @@ def cpu_baseline():
 def parity_check(dev):
     """PSNR(build, oracle) of a short DDPM chain with shared noise (the "PSNR vs ref" half of the metric): full-width
     network, one 8x16x16 tile, T = 10; the oracle is the checker here, as in tests/ and smoke()."""
+    import torch
     from oracle import unet_ref as U
     from oracle.diffusion_ref import GeneralDiffusionRef
     from tmdiff_amd.Hyper_unet_general import WavBEST
@@ -123,25 +153,168 @@ def parity_check(dev):
                     "1000-step chains to the same)"}
 
 
+def rehearse(world, rank, args):
+    """Launcher rehearsal without a GPU (--rehearse; used by tests/test_bench_launcher.py): the same rendezvous,
+    barrier-bracketed timed region and MAX-over-ranks reduction as the real run, over gloo, with a token CPU step."""
+    import torch
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        dist.init_process_group("gloo")
+    x = torch.ones(64, 64)
+    barrier = (lambda: dist.barrier()) if dist is not None else (lambda: None)
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        x = (x @ x) / 64.0
+    barrier()
+    tt = torch.tensor([time.perf_counter() - t0], dtype=torch.float64)
+    ranks = torch.tensor([float(rank + 1)])
+    if dist is not None:
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        dist.all_reduce(ranks, op=dist.ReduceOp.SUM)          # every rank took part: 1 + 2 + ... + world
+    if rank == 0:
+        print(json.dumps({"metric": "launcher rehearsal (no GPU work)", "rehearsal": True, "n_gpus": world,
+                          "steps": args.steps, "warmup": args.warmup, "rank_sum": float(ranks[0]),
+                          "value": round(world * args.steps / float(tt[0]), 3), "unit": "token-steps/s"}), flush=True)
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+def load_traffic():
+    """HBM bytes per 3x3x3 conv launch from the committed PMC passes over this same command (tools/bench_traffic.py:
+    separate `rocprofv3 --pmc FETCH_SIZE` / `--pmc WRITE_SIZE` runs of bench.py, FETCH_SIZE doubled as
+    MI355X_MICROARCH.md prescribes for gfx950).  Counters cannot be read from inside the process, so the line carries
+    the figure of the last committed collection and says where it came from."""
+    path = os.path.join(ROOT, "profiles", "r02_bench_traffic.json")
+    try:
+        with open(path) as fh:
+            t = json.load(fh)
+        return t["bytes_per_k3_launch"], {"file": "profiles/r02_bench_traffic.json", **{k: t[k] for k in t if k != "bytes_per_k3_launch"}}
+    except (OSError, KeyError, ValueError):
+        return None, "profiles/r02_bench_traffic.json missing: run tools/bench_traffic.sh on the GPU box"
+
+
+def train_leg(dev, world, rank, dist, steps, warmup):
+    """BASELINE configs[3] per-GPU share: local batch 8 of 8x64x64 tiles, ch 32-256, dropout on, forward + backward +
+    SUM all-reduce (overlapped with backward, tmdiff_amd.dist.GradReducer) + AdamW + EMA (reference model.py:40-47,
+    general_finetune.json:64-66, utils/EmaUpdater.py).  Returns seconds for `steps` steps plus all-reduce figures."""
+    import copy
+    import numpy as np
+    from tmdiff_amd.model import DDPM, EmaUpdater
+    from tmdiff_amd.util import fill_weights_, synthetic_tile_batch
+    opt = {"phase": "train", "gpu_ids": [dev.index], "distributed": world > 1, "path": {"resume": None},
+           "model": {"unet": {"channel_multiplier": FULL}, "diffusion": {"loss_type": "l1"}, "init_type": "orthogonal"},
+           "train": {"optimizer": {"lr": 1e-4}, "max_iter": 150000}}
+    m = DDPM(opt)
+    fill_weights_(m.netG.denoise_fn)                     # same weights on every rank (replicas start identical)
+    m.netG.denoise_fn.invalidate_prepared()
+    m.set_new_noise_schedule({"schedule": "cosine", "n_timestep": T}, "train")
+    ema = EmaUpdater(m, copy.deepcopy(m))
+    np.random.seed(3407 + rank)
+    d = synthetic_tile_batch(4000 + rank, 8, BANDS, SIZE, device=dev)
+    d["LR"] = d["MS"]
+
+    def barrier():
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    def run(n, it0):
+        for i in range(n):
+            m.feed_data(d)
+            m.optimize_parameters("WV3")
+            ema.update(it0 + i)
+
+    run(max(warmup, 2), 0)          # step 1 lays out the gradient buckets; overlapped all-reduce from step 2 on
+    barrier()
+    t0 = time.perf_counter()
+    run(steps, 10)
+    barrier()
+    dt = time.perf_counter() - t0
+    out = {"seconds": dt, "loss": float(m.get_current_log()["l_pix"]), "allreduce": None}
+    if dist is not None:
+        red = m.reducer
+        nbytes = sum(bk["flat"].numel() * 4 for bk in red.buckets)
+        # the same exchange un-overlapped (all buckets back to back, nothing else running), for the exposed share
+        barrier()
+        t1 = time.perf_counter()
+        for _ in range(5):
+            hs = [dist.all_reduce(bk["flat"], async_op=True) for bk in red.buckets]
+            for h in hs:
+                h.wait()
+        barrier()
+        alone = (time.perf_counter() - t1) / 5
+        # and the step without any exchange
+        red.active = False
+        run(2, 100)
+        barrier()
+        t2 = time.perf_counter()
+        run(steps, 200)
+        barrier()
+        dt_noex = time.perf_counter() - t2
+        red.active = True
+        tt = torch.tensor([dt, alone, dt_noex], device=dev, dtype=torch.float64)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        dt, alone, dt_noex = (float(v) for v in tt)
+        out["seconds"] = dt
+        out["allreduce"] = {"buckets": len(red.buckets), "launched_from_backward_hooks": red.launched,
+                            "payload_mb": round(nbytes / 1e6, 1), "standalone_ms": round(alone * 1e3, 3),
+                            "bus_gb_s": round(2 * (world - 1) / world * nbytes / alone / 1e9, 1),
+                            "step_ms_without_exchange": round(dt_noex / steps * 1e3, 3),
+                            "exposed_ms_per_step": round((dt - dt_noex) / steps * 1e3, 3)}
+    del m, ema
+    torch.cuda.empty_cache()
+    return out
+
+
+TRAIN_GFLOP_PER_SAMPLE = 3 * GFLOP_PER_SAMPLE      # SURVEY 8(d): training step ~ forward + dgrad + wgrad = 517 GF/sample
+
+
+def train_object(leg, world, steps):
+    dt = leg["seconds"]
+    return {"value": round(world * 8 * steps / dt, 2), "unit": "samples/s", "ms_per_step": round(dt / steps * 1e3, 3),
+            "steps": steps, "global_batch": 8 * world, "tflops_per_gpu": round(8 * TRAIN_GFLOP_PER_SAMPLE * 1e-3 * steps / dt, 2),
+            "frac_of_fp32_mfma_peak": round(8 * TRAIN_GFLOP_PER_SAMPLE * 1e-3 * steps / dt / PEAK_FP32_MFMA, 4),
+            "loss": round(leg["loss"], 5), "allreduce": leg["allreduce"],
+            "what": "BASELINE configs[3] per-GPU share: local batch 8 of 8x64x64 tiles, ch 32-256, dropout 0.2 on, fwd + bwd + "
+                    "SUM all-reduce of 216 gradient tensors (RCCL, flat buckets, started from backward hooks) + AdamW + EMA"}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--mode", choices=["sample", "train"], default="sample")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-extras", action="store_true", help="only the timed region and the instrumented pass "
+                    "(no cond-cached / bf16 / train / parity / cpu legs): what tools/bench_traffic.sh profiles")
+    ap.add_argument("--rehearse", action="store_true", help="CPU-only launcher rehearsal over gloo (tests)")
     args = ap.parse_args()
 
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(launch_ranks(args))          # parent: starts the ranks, never touches the GPU
+
+    global torch
+    import torch
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        log(f"--gpus {args.gpus} but the launcher started WORLD_SIZE={world}: reporting n_gpus={world}")
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    if args.rehearse:
+        return rehearse(world, rank, args)
     dist = None
     ndev = torch.cuda.device_count()
-    local_dev = local % max(ndev, 1)      # (rehearsals on a 1-GPU box map every rank to device 0)
+    backend = os.environ.get("TMDIFF_BENCH_BACKEND", "nccl")      # nccl == RCCL over xGMI
+    if world > 1 and backend == "nccl" and ndev < world:
+        raise SystemExit(f"bench.py: {world} ranks need {world} GPUs, {ndev} visible (one device per rank)")
+    local_dev = local % max(ndev, 1)      # (gloo rehearsals on a 1-GPU box map every rank to device 0)
     if world > 1:
         import torch.distributed as dist
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        # nccl == RCCL over xGMI; TMDIFF_BENCH_BACKEND=gloo lets the multi-rank path be rehearsed on one GPU
-        backend = os.environ.get("TMDIFF_BENCH_BACKEND", "nccl")
         kw = {"device_id": torch.device("cuda", local_dev)} if backend == "nccl" else {}
         dist.init_process_group(backend, **kw)
     torch.cuda.set_device(local_dev)
@@ -152,17 +325,35 @@ def main():
     from tmdiff_amd.diffusion_general import GeneralDiffusion
     from tmdiff_amd.util import fill_weights_, synthetic_tile_batch
 
+    def barrier():
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    if args.mode == "train":
+        log(f"rank {rank}/{world}: finetune step on {torch.cuda.get_device_name(dev)}")
+        leg = train_leg(dev, world, rank, dist, args.steps, args.warmup)
+        if rank == 0:
+            obj = train_object(leg, world, args.steps)
+            line = {"metric": "finetune train samples/sec (8-ch 64x64 tiles, local batch 8 per GPU)", "value": obj["value"],
+                    "unit": "samples/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+                    "ms_per_step": obj["ms_per_step"], "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+                    "dtype": "f32", "data": "synthetic",
+                    "config": {"workload": "BASELINE configs[3]: " + obj["what"], "global_batch": 8 * world,
+                               "parallelism": f"data-parallel x{world}, SUM all-reduce"},
+                    "train_step": obj}
+            print(json.dumps(line), flush=True)
+        if dist is not None:
+            dist.barrier()
+            dist.destroy_process_group()
+        return
+
     net = fill_weights_(WavBEST(channels=FULL)).to(dev).eval()
     diff = GeneralDiffusion(net, "l1").to(dev)
     diff.set_new_noise_schedule({"schedule": "cosine", "n_timestep": T}, dev)
     d = synthetic_tile_batch(3407 + rank, BATCH, BANDS, SIZE, device=dev)      # resident in HBM from here on
     torch.manual_seed(1234 + rank)
     torch.cuda.manual_seed(1234 + rank)
-
-    def barrier():
-        if dist is not None:
-            dist.barrier()
-        torch.cuda.synchronize()
 
     def run(steps, first_t, x):
         for i in range(steps):
@@ -174,50 +365,75 @@ def main():
     x = run(args.warmup, T - 1, x)
     torch.cuda.synchronize()
     log("warm-up done")
-    # ---- timed region: K full steps ---------------------------------------------------------------
-    ops.TIMER = ops.ConvTimer()
+    # ---- timed region: K full steps, nothing but the hot path inside --------------------------------------------
     barrier()
     t0 = time.perf_counter()
     x = run(args.steps, T - 1 - args.warmup, x)
     barrier()
     dt = time.perf_counter() - t0
-    timer, ops.TIMER = ops.TIMER, None
-    conv = timer.summary()
-    conv_by_entry = timer.summary(by_entry=True)
     assert torch.isfinite(x).all()
     log(f"timed region: {args.steps} steps in {dt:.3f} s")
 
-    # ---- the same loop with the condition branch hoisted (a real sampling run), outside `value` -------
+    # ---- the same K steps again with a HIP event pair around every conv launch (roofline object).  Kept out of the
+    # run that produces `value`; its wall time is reported so the two can be compared. -------------------------------
+    ops.TIMER = ops.ConvTimer()
     barrier()
-    t1 = time.perf_counter()
-    net.begin_condition_cache(d["PAN"], d["MS"], "WV3")
-    x2 = run(args.steps, T - 1, torch.randn_like(d["Res"]))
-    net.end_condition_cache()
+    ti = time.perf_counter()
+    xi = run(args.steps, T - 1 - args.warmup, x)
     barrier()
-    dt_cached = time.perf_counter() - t1
-    log(f"cond-cached loop: {args.steps} steps in {dt_cached:.3f} s")
+    dt_instr = time.perf_counter() - ti
+    timer, ops.TIMER = ops.TIMER, None
+    conv = timer.summary()
+    conv_by_entry = timer.summary(by_entry=True)
+    del xi
 
-    # ---- the full-forward loop again with bf16-operand convolutions (SURVEY 8d config-3 mode), outside `value` ----
-    net.set_compute_dtype("bf16")
-    x3 = run(2, T - 1, torch.randn_like(d["Res"]))          # packs the bf16 weights
-    barrier()
-    t2 = time.perf_counter()
-    x3 = run(args.steps, T - 1, x3)
-    barrier()
-    dt_bf16 = time.perf_counter() - t2
-    net.set_compute_dtype("fp32")
-    assert torch.isfinite(x3).all()
-    log(f"bf16-compute loop: {args.steps} steps in {dt_bf16:.3f} s")
+    dt_cached = dt_bf16 = None
+    train = None
+    if not args.no_extras:
+        # ---- the same loop with the condition branch hoisted (a real sampling run), outside `value` -------
+        barrier()
+        t1 = time.perf_counter()
+        net.begin_condition_cache(d["PAN"], d["MS"], "WV3")
+        x2 = run(args.steps, T - 1, torch.randn_like(d["Res"]))
+        net.end_condition_cache()
+        barrier()
+        dt_cached = time.perf_counter() - t1
+        log(f"cond-cached loop: {args.steps} steps in {dt_cached:.3f} s")
+
+        # ---- the full-forward loop again with bf16-operand convolutions (SURVEY 8d config-3 mode), outside `value` ----
+        net.set_compute_dtype("bf16")
+        x3 = run(2, T - 1, torch.randn_like(d["Res"]))          # packs the bf16 weights
+        barrier()
+        t2 = time.perf_counter()
+        x3 = run(args.steps, T - 1, x3)
+        barrier()
+        dt_bf16 = time.perf_counter() - t2
+        net.set_compute_dtype("fp32")
+        assert torch.isfinite(x3).all()
+        log(f"bf16-compute loop: {args.steps} steps in {dt_bf16:.3f} s")
+        del x2, x3
 
     if dist is not None:
-        tt = torch.tensor([dt, dt_cached, dt_bf16], device=dev, dtype=torch.float64)
+        tt = torch.tensor([dt, dt_cached or 0.0, dt_bf16 or 0.0, dt_instr], device=dev, dtype=torch.float64)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-        dt, dt_cached, dt_bf16 = float(tt[0]), float(tt[1]), float(tt[2])
+        dt, dt_cached, dt_bf16, dt_instr = (float(v) for v in tt)
+
+    if not args.no_extras:
+        # ---- finetune step (BASELINE configs[3] share of this GPU), a short run beside `value` ---------------------
+        del net, diff
+        torch.cuda.empty_cache()
+        tsteps = max(3, min(args.steps, 8))
+        try:
+            train = train_object(train_leg(dev, world, rank, dist, tsteps, 2), world, tsteps)
+            log(f"train leg: {train['ms_per_step']} ms/step")
+        except Exception as e:       # the headline line must survive a failure of this side measurement
+            train = {"error": f"{type(e).__name__}: {e}"}
 
     if rank == 0:
         n3, ms3, fl3 = conv.get(3, (0, 0.0, 0.0))
         n1, ms1, fl1 = conv.get(1, (0, 0.0, 0.0))
         achieved = fl3 / (ms3 * 1e-3) / 1e12 if ms3 > 0 else 0.0
+        traffic, traffic_src = load_traffic()
         line = {
             "metric": "UNet denoise-steps/sec (8-ch 64x64, batch 32)",
             "value": round(world * args.steps / dt, 4),
@@ -234,12 +450,11 @@ def main():
             "sample_steps_per_s": round(world * BATCH * args.steps / dt, 2),
             "unet_tflops": round(BATCH * GFLOP_PER_SAMPLE * 1e-3 * args.steps / dt, 2),
             "roofline": {"bound": "mfma", "achieved": round(achieved, 2), "peak": PEAK_FP32_MFMA, "unit": "TFLOP/s",
-                         "frac": round(achieved / PEAK_FP32_MFMA, 4), "traffic": None,
-                         "traffic_note": "not collected live; PMC passes over the same layer shapes (profiles/"
-                                         "r01_conv_pmc_microbench.txt): 14.7 GB per B=32 forward over its 51 3x3x3 launches "
-                                         "= 288 MB per launch against 188 MB of input + output bytes",
+                         "frac": round(achieved / PEAK_FP32_MFMA, 4), "traffic": traffic, "traffic_source": traffic_src,
                          "kernel": "3x3x3 conv launches, fp32 v_mfma_f32_32x32x2_f32: conv3d_mfma_kernel<3,..> (fused prologue) "
                                    "or prologue_apply_kernel + conv3d_dma_kernel<3,..> (staged), chosen per layer",
+                         "measured_in": f"a second pass of the same {args.steps} steps with a HIP event pair around every conv "
+                                        f"launch ({round(dt_instr / args.steps * 1e3, 3)} ms/step), outside the run that gives `value`",
                          "launches": n3, "avg_launch_us": round(ms3 / max(n3, 1) * 1e3, 2),
                          "algorithmic_gflop_per_launch": round(fl3 / max(n3, 1) / 1e9, 2),
                          # per entry point, to set beside the rocprofv3 kernel averages in profiles/: "conv3d_fwd" =
@@ -250,17 +465,19 @@ def main():
                                       for (k, what), (n, ms, fl) in sorted(conv_by_entry.items()) if k == 3},
                          "k1_conv": {"launches": n1, "avg_launch_us": round(ms1 / max(n1, 1) * 1e3, 2),
                                      "tflops": round(fl1 / (ms1 * 1e-3) / 1e12, 2) if ms1 > 0 else 0.0}},
-            "cond_cached": {"value": round(world * args.steps / dt_cached, 4), "unit": "batch32-steps/s",
-                            "note": "condition branch (62.82 of 172.39 GFLOP/sample, independent of x_t and t) "
-                                    "evaluated once inside the timed run instead of every step; outputs are "
-                                    "bit-identical (tests/test_gpu_sampling.py)"},
-            "bf16_compute": {"value": round(world * args.steps / dt_bf16, 4), "unit": "batch32-steps/s",
-                             "unet_tflops": round(BATCH * GFLOP_PER_SAMPLE * 1e-3 * args.steps / dt_bf16, 2),
-                             "note": "same full-forward steps with bf16 conv operands / fp32 accumulation "
-                                     "(set_compute_dtype('bf16'), the config-3 mode; forward rel-L2 7e-3 vs fp32, "
-                                     "tests/test_gpu_bf16.py) -- reduced precision, never `value`"},
         }
-        if world == 1 and not args.no_cpu_baseline:
+        if not args.no_extras:
+            line["cond_cached"] = {"value": round(world * args.steps / dt_cached, 4), "unit": "batch32-steps/s",
+                                   "note": "condition branch (62.82 of 172.39 GFLOP/sample, independent of x_t and t) "
+                                           "evaluated once inside the timed run instead of every step; outputs are "
+                                           "bit-identical (tests/test_gpu_sampling.py)"}
+            line["bf16_compute"] = {"value": round(world * args.steps / dt_bf16, 4), "unit": "batch32-steps/s",
+                                    "unet_tflops": round(BATCH * GFLOP_PER_SAMPLE * 1e-3 * args.steps / dt_bf16, 2),
+                                    "note": "same full-forward steps with bf16 conv operands / fp32 accumulation "
+                                            "(set_compute_dtype('bf16'), the config-3 mode; forward rel-L2 7e-3 vs fp32, "
+                                            "tests/test_gpu_bf16.py) -- reduced precision, never `value`"}
+            line["train_step"] = train
+        if world == 1 and not args.no_cpu_baseline and not args.no_extras:
             line["parity"] = parity_check(dev)
             log(f"parity: PSNR {line['parity']['psnr_db']} dB")
             line["cpu_baseline"] = cpu_baseline()

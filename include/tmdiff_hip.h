@@ -172,6 +172,12 @@ int tmdiff_head_fwd(const float* x, const float* w, const float* scale, int32_t 
 int tmdiff_stem_bwd(const float* xin, const float* pan, const float* ms, const float* w, const float* bias,
                     const float* gy, float* dwb, int32_t B, int32_t Cout, int32_t N, int32_t H, int32_t W,
                     tmdiff_stream_t stream);
+/* stem backward w.r.t. its inputs (WavBEST.forward is differentiable in x_t / PAN / MS in the reference, :605-609):
+ * xin form: dx[B,N,H,W] = sum_co gy*SiLU'(u)*w;  (pan, ms) form: dx = d_ms = -that, dpan[B,H,W] = sum over the N bands.
+ * Either output may be NULL. */
+int tmdiff_stem_bwd_input(const float* xin, const float* pan, const float* ms, const float* w, const float* bias,
+                          const float* gy, float* dx, float* dpan, int32_t B, int32_t Cout, int32_t N, int32_t H,
+                          int32_t W, tmdiff_stream_t stream);
 int tmdiff_head_bwd(const float* x, const float* w, const float* scale, const float* gy, float* dx, float* dws,
                     int32_t B, int32_t C, int64_t P, tmdiff_stream_t stream);
 

@@ -29,6 +29,7 @@ from oracle.unet_ref import fill_weights_, synthetic_text_embeddings  # noqa: E4
 OUT = os.path.join(ROOT, "tests", "golden")
 TINY = [4, 8, 16, 32]
 FULL = [32, 64, 128, 256]
+WIDE = [64, 128, 256, 512]
 
 
 # ----------------------------------------------------------------------------------------
@@ -47,6 +48,18 @@ def case_inputs(seed, b, c, h, w=None):
 
 def randn(seed, *shape):
     return torch.randn(*shape, generator=torch.Generator(device="cpu").manual_seed(seed))
+
+
+def gauss_model(ns, std=0.5):
+    """Closed-form optimal noise prediction for data ~ N(0, std^2 I): eps = sigma_t x / (alpha_t^2 std^2 + sigma_t^2),
+    as a "noise"-type model taking the discrete model time (t_cont - 1/N) * 1000.  A contraction towards the data
+    manifold, so solver outputs are well conditioned (unlike the `toy` drift, whose solution is a 1e-4 remainder of
+    cancellations).  `ns` is the caller's NoiseScheduleVP (reference, oracle or build)."""
+    def model(x, t_in):
+        t = t_in.reshape(-1)[:1].float().cpu() / 1000.0 + 1.0 / 1000
+        a, sg = float(ns.marginal_alpha(t)[0]), float(ns.marginal_std(t)[0])
+        return x * (sg / (a * a * std * std + sg * sg))
+    return model
 
 
 ONLY = set(a for a in sys.argv[1:] if not a.startswith("-"))   # e.g. `make_golden.py attnpp`: rewrite just that file
@@ -191,6 +204,16 @@ def main():
     save("unet_full", y=netF(d["x_t"], torch.tensor([[250]]), d["PAN"], d["MS"], "WV3"))
     del netF
 
+    # ---- (7b) BASELINE configs[2] network: channel_multiplier [64,128,256,512] (config/general.json:52-54) ------------
+    if not ONLY or "unet_c3" in ONLY:
+        netW = fill_weights_(RU.WavBEST(channels=WIDE)).eval()
+        d = case_inputs(3408, 1, 8, 64)
+        arrs = {"y64": netW(d["x_t"], torch.tensor([[612]]), d["PAN"], d["MS"], "WV3")}
+        d = case_inputs(3409, 1, 8, 256)             # the config's tile size, one forward (fractional DPM-Solver time)
+        arrs["y256"] = netW(d["x_t"], torch.tensor([431.7]), d["PAN"], d["MS"], "WV3")
+        save("unet_c3", **arrs)
+        del netW
+
     # ---- (8) q_sample / training loss -------------------------------------------------------
     torch.set_grad_enabled(True)
     arrs = {}
@@ -268,6 +291,34 @@ def main():
             arrs[f"toy_{algo}_{method}_{order}_{skip}_{stype}"] = s2.sample(xT, steps=9, order=order, skip_type=skip,
                                                                           method=method, solver_type=stype)
     save("dpm_solver", **arrs)
+
+    # ---- (10b) adaptive driver, add_noise, inverse (dpm_solver_pytorch.py:982-1079) ---------------------------------
+    # The adaptive `toy_*` cases above are ill conditioned: a 1e-7 relative change of x_T moves the REFERENCE's own
+    # output by O(1) relative (stored below as evidence), so they cannot serve as parity vectors for an implementation
+    # whose arithmetic differs in the last bit.  The Gaussian-denoiser model is the parity problem for the driver.
+    arrs = {}
+    gm = gauss_model(ns)
+    xg = randn(153, 2, 4, 8, 8)
+    for algo in ("dpmsolver", "dpmsolver++"):
+        mk = lambda model: RS.DPM_Solver(RS.model_wrapper(model, ns, model_type="noise"), ns, algorithm_type=algo)
+        for order in (2, 3):
+            arrs[f"gauss_{algo}_adaptive_{order}"] = mk(gm).sample(xg, order=order, method="adaptive", skip_type="logSNR")
+            arrs[f"gauss_{algo}_adaptive_{order}_tight"] = mk(gm).sample(xg, order=order, method="adaptive",
+                                                                      skip_type="logSNR", atol=1e-4, rtol=1e-3)
+            arrs[f"gauss_{algo}_adaptive_{order}_perturbed"] = mk(gm).sample(xg * (1 + 1e-6), order=order,
+                                                                          method="adaptive", skip_type="logSNR")
+        arrs[f"toy_{algo}_adaptive_3_perturbed"] = mk(toy).sample(xT * (1 + 1e-7), steps=9, order=3, skip_type="logSNR",
+                                                                 method="adaptive", solver_type="dpmsolver")
+        # inverse (data -> noise along the ODE) and back, fixed-step multistep order 2
+        data = 0.5 * randn(154, 2, 4, 8, 8)
+        z = mk(gm).inverse(data, steps=12, order=2, skip_type="time_uniform", method="multistep")
+        arrs[f"gauss_{algo}_inverse"] = z
+        arrs[f"gauss_{algo}_inverse_back"] = mk(gm).sample(z, steps=12, order=2, skip_type="time_uniform", method="multistep")
+    sol = RS.DPM_Solver(RS.model_wrapper(gm, ns, model_type="noise"), ns)
+    xn = randn(155, 2, 4, 8, 8)
+    arrs["add_noise_t1"] = sol.add_noise(xn, torch.tensor([0.3]), noise=randn(156, 1, 2, 4, 8, 8))
+    arrs["add_noise_t2"] = sol.add_noise(xn, torch.tensor([0.1, 0.9]), noise=randn(157, 2, 2, 4, 8, 8))
+    save("dpm_adaptive", **arrs)
 
     # ---- (11) core/Attention.py standalone ops ---------------------------------------------------
     arrs = {}

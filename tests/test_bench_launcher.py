@@ -1,0 +1,38 @@
+"""`bench.py --gpus N` without a launcher must start N ranks itself: rehearsed here on the CPU over gloo
+(`--rehearse` swaps the GPU work for a token step; rendezvous, barriers and the MAX-over-ranks reduction are the real ones)."""
+import json
+import os
+import subprocess
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _run(*flags):
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT")}
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), *flags], capture_output=True, text=True, env=env,
+                       timeout=300)
+    assert p.returncode == 0, p.stderr[-2000:]
+    lines = [l for l in p.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, p.stdout                     # exactly one JSON line, from rank 0
+    return json.loads(lines[0])
+
+
+def test_gpus_2_spawns_two_ranks():
+    line = _run("--gpus", "2", "--rehearse", "--steps", "2", "--warmup", "0")
+    assert line["n_gpus"] == 2 and line["rank_sum"] == 3.0 and line["steps"] == 2
+
+
+def test_gpus_1_stays_single_process():
+    line = _run("--gpus", "1", "--rehearse", "--steps", "2")
+    assert line["n_gpus"] == 1 and line["rank_sum"] == 1.0
+
+
+def test_under_a_launcher_world_size_wins():
+    """The driver's form: torch.distributed.run sets WORLD_SIZE; bench.py must not spawn again."""
+    p = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
+                        "--master-addr", "127.0.0.1", "--master-port", "29731", os.path.join(ROOT, "bench.py"),
+                        "--gpus", "2", "--rehearse", "--steps", "1"], capture_output=True, text=True, timeout=300)
+    assert p.returncode == 0, p.stderr[-2000:]
+    lines = [l for l in p.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1 and json.loads(lines[0])["n_gpus"] == 2

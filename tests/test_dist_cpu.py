@@ -86,3 +86,86 @@ def test_single_process_is_a_noop():
     t = torch.ones(2, 3)
     assert D.gather_images(t) is t
     assert D.shard_batch({"x": torch.arange(6.0).reshape(6, 1)}, rank=1, world=3)["x"].flatten().tolist() == [2.0, 3.0]
+
+
+# ---- overlapped bucketed all-reduce (GradReducer) ---------------------------------------------------------------
+def _reducer_worker(rank, world, port, q):
+    os.environ.update({"MASTER_ADDR": "127.0.0.1", "MASTER_PORT": str(port), "RANK": str(rank),
+                       "WORLD_SIZE": str(world)})
+    from tmdiff_amd import dist as D
+    assert D.init_from_env("gloo") == world
+    torch.manual_seed(0)
+    net = torch.nn.Sequential(torch.nn.Linear(6, 5), torch.nn.Linear(5, 3), torch.nn.Linear(3, 2), torch.nn.Linear(3, 2))
+    red = D.GradReducer(net, op="sum", bucket_bytes=80)          # tiny buckets: several per step
+    opt = torch.optim.SGD(net.parameters(), lr=0.1)
+    x = torch.arange(8 * 6, dtype=torch.float32).reshape(8, 6) / 10
+    shard = D.shard_batch({"x": x})["x"]
+    log = []
+    for step in range(4):
+        h = net[1](net[0](shard))
+        # net[2] never gets a gradient; net[3] only from step 2 on (a parameter joining the layout late)
+        loss = h.abs().mean() + (net[3](h).square().mean() if step >= 2 else 0.0)
+        loss.backward()
+        n = red.finish()
+        log.append((n, red.launched, [None if p.grad is None else p.grad.clone().numpy() for p in net.parameters()]))
+        opt.step()
+        red.zero_grad()
+    w = [p.detach().clone().numpy() for p in net.parameters()]
+    q.put((rank, log, w))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_grad_reducer_world2_matches_single_process_sum():
+    world, port = 2, _free_port()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_reducer_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = sorted((q.get(timeout=120) for _ in range(world)), key=lambda t: t[0])
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    (_, log0, w0), (_, log1, w1) = res
+    # single-process reference: gradient of the SUM of the two replica losses, same SGD
+    torch.manual_seed(0)
+    net = torch.nn.Sequential(torch.nn.Linear(6, 5), torch.nn.Linear(5, 3), torch.nn.Linear(3, 2), torch.nn.Linear(3, 2))
+    opt = torch.optim.SGD(net.parameters(), lr=0.1)
+    x = torch.arange(8 * 6, dtype=torch.float32).reshape(8, 6) / 10
+    for step in range(4):
+        total = 0.0
+        for part in (x[:4], x[4:]):
+            h = net[1](net[0](part))
+            total = total + h.abs().mean() + (net[3](h).square().mean() if step >= 2 else 0.0)
+        opt.zero_grad()
+        total.backward()
+        n0, launched0, g0 = log0[step]
+        n1, launched1, g1 = log1[step]
+        assert n0 == n1 and n0 >= 1
+        for p, a, b in zip(net.parameters(), g0, g1):
+            if p.grad is None:
+                assert a is None and b is None
+                continue
+            assert a is not None and torch.allclose(torch.from_numpy(a), p.grad, atol=1e-6), step
+            assert (a == b).all()                                   # identical on both ranks
+        if step == 1:
+            assert launched0 == n0 and launched0 > 1                 # every bucket went out from a backward hook
+        opt.step()
+    for p, a, b in zip(net.parameters(), w0, w1):
+        assert torch.allclose(p.detach(), torch.from_numpy(a), atol=1e-6) and (a == b).all()
+
+
+def test_ranks_draw_different_randomness():
+    """every rank used to seed NumPy / torch identically, so all replicas drew the same timesteps, noise and
+    dropout masks.  seed_all(rank=r) keeps `random` shared (the per-iteration dataset choice) and offsets the rest."""
+    import random
+    import numpy as np
+    from tmdiff_amd.train import per_rank_batch, seed_all
+    draws = []
+    for r in (0, 1):
+        seed_all(3407, rank=r)
+        draws.append((random.random(), np.random.randint(1, 1001, size=8).tolist(), torch.randn(4).tolist()))
+    assert draws[0][0] == draws[1][0]
+    assert draws[0][1] != draws[1][1] and draws[0][2] != draws[1][2]
+    assert per_rank_batch(64, 8) == 8 and per_rank_batch(4, 8) == 1 and per_rank_batch(32, 1) == 32

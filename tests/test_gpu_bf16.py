@@ -10,6 +10,15 @@ from oracle.diffusion_ref import GeneralDiffusionRef
 from oracle.make_golden import FULL, case_inputs
 
 pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(autouse=True)
+def _inference_mode():
+    """Sampling runs under torch.no_grad() in the reference (diffusion_general.py:154, :203, :210): these tests exercise
+    that (fused inference) path of WavBEST.forward; the differentiable path is covered by test_gpu_training.py /
+    test_gpu_backward.py."""
+    with torch.no_grad():
+        yield
 MID = [32, 64, 128, 256]
 
 

@@ -1,0 +1,212 @@
+"""BASELINE.json configs exercised at their own sizes on the GPU (VERDICT r1 "configs_untested"):
+
+  configs[1]  batch-32 8-ch 64x64 tiles, ch 32-256 (the benchmark workload): reference fixture + replication property;
+  configs[2]  channel_multiplier [64,128,256,512] (config/general.json:52-54), 8-ch 64x64 and 256x256 forwards against
+              REFERENCE-generated fixtures (tests/golden/unet_c3.npz) in fp32 and in the bf16 compute mode, and the
+              21-NFE DPM-Solver++ run in bf16 against the oracle;
+  configs[3]  finetune step at full width, local batch 8, 8-ch 64x64 (general_finetune.json:64-66);
+  configs[4]  mixed GF-2 (4 bands) / WV-3 (8 bands) sub-batches with per-sample prompts at full width, tiled scene.
+"""
+import numpy as np
+import pytest
+import torch
+
+from conftest import assert_close, rel_err
+from oracle import unet_ref as U
+from oracle.diffusion_ref import GeneralDiffusionRef
+from oracle.make_golden import FULL, WIDE, case_inputs, randn
+
+pytestmark = pytest.mark.gpu
+
+
+def cu(t):
+    return t.detach().cuda().contiguous()
+
+
+def _hip_net(channels, ref=None):
+    from tmdiff_amd.Hyper_unet_general import WavBEST
+    net = WavBEST(channels=channels)
+    if ref is not None:
+        net.load_state_dict(ref.state_dict())
+    else:
+        U.fill_weights_(net)
+    return net.cuda().eval()
+
+
+# ---- configs[1]: batch 32 -------------------------------------------------------------------------------------------
+def test_config2_batch32_full_width(golden):
+    """B = 32 selects other tile instantiations than B <= 4 at the 32x32 / 16x16 / 8x8 levels (conv3d.hip dispatch): a
+    replicated reference tile must come back 32 times, bit-identical, and equal to the reference's output."""
+    net = _hip_net(FULL)
+    d = case_inputs(3407, 1, 8, 64)
+    rep = lambda t: cu(t.repeat(32, *([1] * (t.dim() - 1))))
+    with torch.no_grad():
+        y = net(rep(d["x_t"]), torch.full((32, 1), 250).cuda(), rep(d["PAN"]), rep(d["MS"]), "WV3").cpu()
+    for i in range(1, 32):
+        assert torch.equal(y[i], y[0]), f"row {i} differs from row 0"
+    m, l2 = rel_err(y[:1], golden("unet_full")["y"])
+    print(f"B=32 full-width forward vs reference: max-rel {m:.3e} rel-L2 {l2:.3e}")
+    assert m <= 1e-4 and l2 <= 1e-5
+    # distinct tiles in one batch of 32 equal the same tiles run four at a time (batch independence at B = 32)
+    d32 = {k: cu(v) for k, v in case_inputs(11, 32, 8, 64).items()}
+    t = torch.arange(1, 33, dtype=torch.float32).reshape(32, 1).cuda() * 31
+    with torch.no_grad():
+        y32 = net(d32["x_t"], t, d32["PAN"], d32["MS"], "WV3")
+        y4 = net(d32["x_t"][12:16].contiguous(), t[12:16].contiguous(), d32["PAN"][12:16].contiguous(),
+                 d32["MS"][12:16].contiguous(), "WV3")
+    assert_close(y32[12:16], y4, 2e-6, 2e-6, "rows 12..15 of a batch of 32 vs a batch of 4")
+
+
+# ---- configs[2]: the WorldView-3 network of config/general.json ---------------------------------------------------------
+@pytest.fixture(scope="module")
+def wide_net():
+    return _hip_net(WIDE)
+
+
+@pytest.mark.parametrize("key,seed,size,t", [("y64", 3408, 64, torch.tensor([[612]])), ("y256", 3409, 256, torch.tensor([431.7]))])
+def test_config3_wide_network_vs_reference(golden, wide_net, key, seed, size, t):
+    g = golden("unet_c3")
+    d = {k: cu(v) for k, v in case_inputs(seed, 1, 8, size).items()}
+    with torch.no_grad():
+        y32 = wide_net(d["x_t"], t.cuda(), d["PAN"], d["MS"], "WV3").cpu()
+        wide_net.set_compute_dtype("bf16")
+        try:
+            y16 = wide_net(d["x_t"], t.cuda(), d["PAN"], d["MS"], "WV3").cpu()
+        finally:
+            wide_net.set_compute_dtype("fp32")
+    m32, l32 = rel_err(y32, g[key])
+    m16, l16 = rel_err(y16, g[key])
+    print(f"ch 64-512, 8x{size}x{size} vs reference: fp32 max-rel {m32:.2e} rel-L2 {l32:.2e}; bf16 max-rel {m16:.2e} rel-L2 {l16:.2e}")
+    assert m32 <= 1e-4 and l32 <= 1e-5            # SURVEY 8(d) fp32 single-forward tolerance
+    assert l16 <= 1e-2                            # SURVEY 8(d) bf16 tolerance (rel-L2)
+
+
+def test_config3_dpmsolver20_bf16_vs_oracle(wide_net):
+    """DPM-Solver++ 20 steps (21 NFE) at ch 64-512 in the bf16 compute mode against the fp32 CPU oracle with shared
+    noise; SURVEY 8(d): PSNR >= 35 dB (bf16), >= 60 dB / 2e-3 (fp32)."""
+    from tmdiff_amd.diffusion_general import GeneralDiffusion
+    from tmdiff_amd.util import psnr
+    ref = U.fill_weights_(U.WavBESTRef(channels=WIDE)).eval()
+    d = case_inputs(3410, 1, 8, 32)
+    noise = randn(3411, 1, 8, 32, 32)
+    ora = GeneralDiffusionRef(ref, "l1", noise_fn=lambda like: noise)
+    ora.set_new_noise_schedule({"schedule": "cosine", "n_timestep": 1000}, "cpu")
+    with torch.no_grad():
+        want = ora.sample_by_dpmsolver(d, "WV3", steps=20)
+    diff = GeneralDiffusion(wide_net, "l1", noise_fn=lambda like: noise).cuda()
+    diff.set_new_noise_schedule({"schedule": "cosine", "n_timestep": 1000}, "cuda")
+    dc = {k: cu(v) for k, v in d.items()}
+    got32 = diff.sample_by_dpmsolver(dc, "WV3", steps=20).cpu()
+    assert diff.last_solver.nfe == 21
+    wide_net.set_compute_dtype("bf16")
+    try:
+        got16 = diff.sample_by_dpmsolver(dc, "WV3", steps=20).cpu()
+    finally:
+        wide_net.set_compute_dtype("fp32")
+    p32, p16 = psnr(got32, want), psnr(got16, want)
+    print(f"config 3, 21 NFE: PSNR vs oracle fp32 {p32:.1f} dB, bf16 {p16:.1f} dB")
+    assert p32 >= 60.0 and (got32 - want).abs().max() <= 2e-3
+    assert p16 >= 35.0
+
+
+# ---- configs[3]: finetune step at full width, local batch 8 ---------------------------------------------------------------
+def test_config4_finetune_step_full_size():
+    """Local batch 8 of 8x64x64 tiles, ch 32-256.  Size-independent properties of p_losses_dynamic (ref :349-370):
+    (1) dropout off: the gradient of the batch-8 mean-L1 loss is the mean of the two half-batch gradients (same
+    timesteps and noise) -- checks every backward kernel at the production tile configurations; (2) dropout on: finite
+    loss and gradients, 56 gradient-free tensors, and the step is reproducible from the seeds."""
+    from tmdiff_amd.diffusion_general import GeneralDiffusion
+    net = _hip_net(FULL)
+    diff = GeneralDiffusion(net, "l1").cuda()
+    diff.set_loss("cuda")
+    diff.set_new_noise_schedule({"schedule": "cosine", "n_timestep": 1000}, "cuda")
+    d = {k: cu(v) for k, v in case_inputs(3412, 8, 8, 64).items()}
+    noise = cu(randn(3413, 8, 8, 64, 64))
+    times = np.random.RandomState(5).randint(1, 1001, size=8)
+
+    def grads(sl):
+        state = {"lo": sl.start}
+        diff.noise_fn = lambda like: noise[sl]
+        orig = np.random.randint
+        np.random.randint = lambda lo, hi, size: times[sl]
+        try:
+            net.zero_grad()
+            loss = diff({k: v[sl].contiguous() for k, v in d.items()}, "WV3")
+            loss.backward()
+        finally:
+            np.random.randint = orig
+        return float(loss), {k: p.grad.clone() for k, p in net.named_parameters() if p.grad is not None}
+
+    net.eval()
+    l8, g8 = grads(slice(0, 8))
+    la, ga = grads(slice(0, 4))
+    lb, gb = grads(slice(4, 8))
+    assert abs(l8 - 0.5 * (la + lb)) <= 1e-5 * abs(l8)
+    assert len(g8) == 272 - 56
+    worst = 0.0
+    for k in g8:
+        m, l2 = rel_err(g8[k], 0.5 * (ga[k] + gb[k]))
+        worst = max(worst, m)
+        assert m <= 2e-4 and l2 <= 5e-5, (k, m, l2)
+    print(f"batch-8 gradient vs mean of half-batch gradients: worst max-rel {worst:.2e} over {len(g8)} tensors")
+    net.train()
+    diff.noise_fn = None
+    outs = []
+    for _ in range(2):
+        np.random.seed(1); torch.manual_seed(2); torch.cuda.manual_seed(2)
+        net.zero_grad()
+        loss = diff(d, "WV3")
+        loss.backward()
+        outs.append((float(loss), net.final.conv20.conv20.weight.grad.clone()))
+    assert np.isfinite(outs[0][0]) and all(torch.isfinite(p.grad).all() for p in net.parameters() if p.grad is not None)
+    assert outs[0][0] == outs[1][0] and torch.equal(outs[0][1], outs[1][1])
+    assert abs(outs[0][0] - l8) > 1e-6                   # dropout really was active
+
+
+# ---- configs[4]: mixed satellites, per-sample prompts, tiled scene ----------------------------------------------------------
+def test_config5_mixed_satellites_full_width():
+    """4-band GF-2 / QB and 8-band WV-3 / WV-4 sub-batches (the reference never mixes band counts inside a batch,
+    general_sharpening...py:45-53) with per-sample prompts at full width: one DDPM step each against the oracle."""
+    from tmdiff_amd.diffusion_general import GeneralDiffusion
+    ref = U.fill_weights_(U.WavBESTRef(channels=FULL)).eval()
+    net = _hip_net(FULL, ref)
+    diff = GeneralDiffusion(net, "l1").cuda()
+    diff.set_new_noise_schedule({"schedule": "cosine", "n_timestep": 1000}, "cuda")
+    ora = GeneralDiffusionRef(ref, "l1")
+    ora.set_new_noise_schedule({"schedule": "cosine", "n_timestep": 1000}, "cpu")
+    for bands, prompts, seed in ((4, ["GF2", "QB"], 3414), (8, ["WV3", "WV4"], 3415)):
+        d = case_inputs(seed, 2, bands, 64)
+        noise = randn(seed + 10, 2, bands, 64, 64)
+        ora.noise_fn = diff.noise_fn = lambda like: noise
+        dc = {k: cu(v) for k, v in d.items()}
+        got = diff.p_sample(dc["x_t"], 700, condition_x=dc, prompt=prompts).cpu()
+        with torch.no_grad():
+            want = torch.cat([ora.p_sample(d["x_t"][i:i + 1], 700, condition_x={k: v[i:i + 1] for k, v in d.items()},
+                                           prompt=prompts[i]) for i in range(2)])
+        ora.noise_fn = lambda like: noise[:like.shape[0]]
+        m, l2 = rel_err(got, want)
+        print(f"{bands}-band sub-batch {prompts}: max-rel {m:.2e} rel-L2 {l2:.2e}")
+        assert m <= 1e-4 and l2 <= 1e-5
+
+
+def test_config5_tiled_512_scene():
+    """A 512x512 4-band scene cut into 64 tiles of 64x64 (config 5's tiling) sampled in batches of 32 at full width with a
+    short DPM-Solver run: stitched shape, finiteness, and tile (3, 5) alone with the noise it saw gives the same pixels."""
+    from tmdiff_amd.diffusion_general import GeneralDiffusion
+    from tmdiff_amd.tiling import sample_tiled, split_tiles
+    net = _hip_net(FULL)
+    diff = GeneralDiffusion(net, "l1", noise_fn=lambda like: torch.randn(like.shape)).cuda()
+    diff.set_new_noise_schedule({"schedule": "cosine", "n_timestep": 1000}, "cuda")
+    d = case_inputs(3416, 1, 4, 512)
+    scene = {"MS": cu(d["MS"]), "PAN": cu(d["PAN"])}
+    torch.manual_seed(6)
+    fused = sample_tiled(diff, scene, "GF2", tile=64, method="dpmsolver", steps=3, max_batch=32)
+    assert fused.shape == (1, 4, 512, 512) and torch.isfinite(fused).all()
+    idx = 3 * 8 + 5                                        # row 3, col 5 -> batch 0 (tiles 0..31), slot 29
+    torch.manual_seed(6)
+    first = torch.randn(32, 4, 64, 64)
+    tiles = {"MS": split_tiles(scene["MS"], 64, 64)[idx:idx + 1], "PAN": split_tiles(scene["PAN"], 64, 64)[idx:idx + 1]}
+    tiles["Res"] = torch.zeros_like(tiles["MS"])
+    diff.noise_fn = lambda like: first[idx:idx + 1]
+    alone = diff.sample_by_dpmsolver(tiles, "GF2", steps=3)
+    assert (alone[0] - fused[0, :, 192:256, 320:384]).abs().max() <= 1e-4

@@ -13,6 +13,15 @@ from oracle.make_golden import TINY, FULL, case_inputs, randn
 pytestmark = pytest.mark.gpu
 
 
+@pytest.fixture(autouse=True)
+def _inference_mode():
+    """Sampling runs under torch.no_grad() in the reference (diffusion_general.py:154, :203, :210): these tests exercise
+    that (fused inference) path of WavBEST.forward; the differentiable path is covered by test_gpu_training.py /
+    test_gpu_backward.py."""
+    with torch.no_grad():
+        yield
+
+
 @pytest.fixture(scope="module")
 def ops():
     assert torch.cuda.is_available(), "these tests need the MI355X"
@@ -311,8 +320,9 @@ def test_per_operator_abi_names(ops):
     ws = torch.empty(max(1, L.tmdiff_conv3d_wgrad_workspace_bytes(C.byref(d))), dtype=torch.uint8, device="cuda")
     dw = torch.empty_like(w3)
     assert L.tmdiff_conv3d_k3_wgrad(C.byref(d), p(g), p(dw), p(ws), S) == 0
-    wd = w3.cpu().double().requires_grad_()
-    F.conv3d(x.cpu().double(), wd, padding=1).backward(g.cpu().double())
+    with torch.enable_grad():
+        wd = w3.cpu().double().requires_grad_()
+        F.conv3d(x.cpu().double(), wd, padding=1).backward(g.cpu().double())
     assert_close(dw.cpu(), wd.grad.float(), 2e-5, 2e-5, "k3_wgrad")
     # haar fronts and their adjoints: <DWT(x), g> == <x, DWT_bwd(g)>, likewise for IDWT
     xs = cu(torch.randn(6, 8, 12))

@@ -12,6 +12,15 @@ from oracle.make_golden import TINY, case_inputs, randn
 pytestmark = pytest.mark.gpu
 
 
+@pytest.fixture(autouse=True)
+def _inference_mode():
+    """Sampling runs under torch.no_grad() in the reference (diffusion_general.py:154, :203, :210): these tests exercise
+    that (fused inference) path of WavBEST.forward; the differentiable path is covered by test_gpu_training.py /
+    test_gpu_backward.py."""
+    with torch.no_grad():
+        yield
+
+
 def cu(t):
     return t.cuda().contiguous()
 
@@ -121,9 +130,10 @@ def test_solver_families_on_toy_model(golden):
         m, l2 = rel_err(y, g[key])
         report.append(f"{key}: max-rel {m:.2e} rel-L2 {l2:.2e}")
         if method == "adaptive":
-            # thousands of accept/reject decisions on an error norm, on a toy drift that grows to 1e5: a last-bit
-            # difference changes the step sequence, so this case only has to run and stay finite here; the
-            # adaptive driver is compared on a well-conditioned problem below.
+            # Not a parity vector: the reference's own output for this drift moves by O(1) relative under a 1e-7
+            # relative change of x_T (tests/golden/dpm_adaptive.npz `toy_*_adaptive_3_perturbed`, asserted in
+            # tests/test_oracle_golden.py) -- the solution is a 1e-4 remainder of cancellations.  The adaptive driver
+            # is held to the reference on a well-conditioned problem in test_adaptive_add_noise_inverse below.
             assert torch.isfinite(y).all()
             continue
         if not (m <= 5e-5 and l2 <= 5e-5):
@@ -131,23 +141,42 @@ def test_solver_families_on_toy_model(golden):
     print("\n".join(report))
     assert not bad, bad
 
-    # adaptive driver on a well-conditioned problem: data ~ N(0, 0.5^2 I) has the closed-form optimal
-    # noise prediction eps = sigma_t x / (alpha_t^2 s^2 + sigma_t^2); product (GPU) vs oracle (CPU).
-    from oracle import dpm_solver_ref as R
-    ns_ref = R.NoiseScheduleVP("discrete", betas=d.betas)
 
-    def gauss(x, t_in):
-        t = t_in.reshape(-1)[:1].float().cpu() / 1000.0 + 1.0 / 1000
-        a, sg = float(ns.marginal_alpha(t)[0]), float(ns.marginal_std(t)[0])
-        return x * (sg / (a * a * 0.25 + sg * sg))
-
-    x0 = randn(153, 2, 4, 8, 8)
+def test_adaptive_add_noise_inverse(golden):
+    """dpm_solver_adaptive, add_noise, inverse (dpm_solver_pytorch.py:982-1079) against the REFERENCE's outputs on the
+    Gaussian-denoiser model (oracle.make_golden.gauss_model).  Tolerances: the step-size controller takes accept /
+    reject decisions on an error norm, so a last-bit difference can change the step sequence; the fixture records how far
+    the reference itself moves under a 1e-6 relative input change (`*_perturbed`: up to 1.5e-2 at the default
+    atol / rtol) -- the default-tolerance cases are held to 5e-2, the tight-tolerance ones (rtol 1e-3) to 5e-3."""
+    from tmdiff_amd.diffusion_general import GeneralDiffusion
+    from tmdiff_amd.dpm_solver import DPM_Solver, NoiseScheduleVP, model_wrapper
+    from oracle.make_golden import gauss_model
+    g = golden("dpm_adaptive")
+    d = GeneralDiffusion(None)
+    d.set_new_noise_schedule({"schedule": "cosine", "n_timestep": 1000}, "cpu")
+    ns = NoiseScheduleVP("discrete", betas=d.betas)
+    gm, xg = gauss_model(ns), cu(randn(153, 2, 4, 8, 8))
     for algo in ("dpmsolver", "dpmsolver++"):
-        got = DPM_Solver(model_wrapper(gauss, ns, model_type="noise"), ns, algorithm_type=algo).sample(
-            cu(x0), order=3, method="adaptive", skip_type="logSNR").cpu()
-        want = R.DPM_Solver(R.model_wrapper(gauss, ns_ref, model_type="noise"), ns_ref, algorithm_type=algo).sample(
-            x0, order=3, method="adaptive", skip_type="logSNR")
-        assert_close(got, want, 5e-2, 5e-2, f"adaptive {algo} on the Gaussian model")
+        mk = lambda: DPM_Solver(model_wrapper(gm, ns, model_type="noise"), ns, algorithm_type=algo)
+        for order in (2, 3):
+            y = mk().sample(xg, order=order, method="adaptive", skip_type="logSNR").cpu()
+            sens = rel_err(g[f"gauss_{algo}_adaptive_{order}_perturbed"], g[f"gauss_{algo}_adaptive_{order}"])[1]
+            m, l2 = rel_err(y, g[f"gauss_{algo}_adaptive_{order}"])
+            print(f"adaptive {algo} order {order}: max-rel {m:.2e} rel-L2 {l2:.2e} (reference sensitivity {sens:.1e})")
+            assert m <= 5e-2 and l2 <= 5e-2
+            y = mk().sample(xg, order=order, method="adaptive", skip_type="logSNR", atol=1e-4, rtol=1e-3).cpu()
+            assert_close(y, g[f"gauss_{algo}_adaptive_{order}_tight"], 5e-3, 5e-3, f"adaptive {algo} order {order} tight")
+        data = cu(0.5 * randn(154, 2, 4, 8, 8))
+        z = mk().inverse(data, steps=12, order=2, skip_type="time_uniform", method="multistep")
+        assert_close(z.cpu(), g[f"gauss_{algo}_inverse"], 1e-4, 1e-4, f"inverse {algo}")
+        back = mk().sample(z, steps=12, order=2, skip_type="time_uniform", method="multistep")
+        assert_close(back.cpu(), g[f"gauss_{algo}_inverse_back"], 1e-4, 1e-4, f"inverse round trip {algo}")
+    sol = DPM_Solver(model_wrapper(gm, ns, model_type="noise"), ns)
+    xn = cu(randn(155, 2, 4, 8, 8))
+    y1 = sol.add_noise(xn, torch.tensor([0.3]), noise=cu(randn(156, 1, 2, 4, 8, 8)))
+    assert_close(y1.cpu(), g["add_noise_t1"], 1e-6, 1e-6, "add_noise, one t")
+    y2 = sol.add_noise(xn, torch.tensor([0.1, 0.9]), noise=cu(randn(157, 2, 2, 4, 8, 8)))
+    assert_close(y2.cpu(), g["add_noise_t2"], 1e-6, 1e-6, "add_noise, two t")
 
 
 def test_full_size_properties():

@@ -49,10 +49,48 @@ class Swish(nn.Module):
         raise RuntimeError("Swish is fused into the HIP kernels; it is never called as a module")
 
 
+# ---- block modules -------------------------------------------------------------------------------------------------
+# Same constructors, parameter names and ``forward`` signatures as the reference blocks (:158-273, :334-414).  Their
+# ``forward`` is the differentiable path through the autograd-wrapped HIP operators (tmdiff_amd.autograd) and is what
+# ``WavBEST.forward_train`` is assembled from (``run`` = the same block with its Dense() projections already evaluated,
+# so the network can evaluate all of them in two launches); the fused no-grad inference path of ``WavBEST.forward``
+# reads the parameters directly and never calls these.
+
+_MASK_FN = None
+
+
+def set_dropout_mask_fn(fn):
+    """Parity hook: ``fn(shape) -> CPU/GPU float tensor`` supplies every dropout mask (already scaled by 1/(1-p)), in
+    the order the reference's nn.Dropout modules are called; ``None`` restores the device generator."""
+    global _MASK_FN
+    _MASK_FN = fn
+
+
+def _drop_mask(module, shape, p, device):
+    if not module.training or p <= 0.0:
+        return None
+    if _MASK_FN is not None:
+        return _MASK_FN(tuple(shape)).to(device=device, dtype=torch.float32).contiguous()
+    return (torch.rand(shape, device=device) >= p).float() / (1.0 - p)     # nn.Dropout(p) semantics
+
+
+def _lin(x, layer):
+    from . import autograd as A
+    return A.linear(x, layer.weight, layer.bias)
+
+
+def _need_gpu(t):
+    if t.device.type != "cuda":
+        raise RuntimeError("tmdiff_amd blocks run on the HIP kernels only: move the module and its inputs to a GPU")
+
+
 class Dense(nn.Module):
     def __init__(self, input_dim, output_dim):
         super().__init__()
         self.dense = nn.Linear(input_dim, output_dim)
+
+    def forward(self, x):
+        return _lin(x, self.dense)[..., None, None]
 
 
 class AdaptionModulateBEST(nn.Module):
@@ -62,6 +100,18 @@ class AdaptionModulateBEST(nn.Module):
         self.conv21 = nn.Conv3d(channel_out, channel_out, 3, padding=1)
         self.act = Swish()
         self.dense2 = Dense(embed_dim, channel_out)
+
+    def run(self, scale, **inp):
+        """inp: xin=[B,N,H,W], or pan=[B,1,H,W] and ms=[B,N,H,W] (the condition PAN*1 - MS formed in the kernel)."""
+        from . import autograd as A
+        a0 = A.stem(self.conv20.weight, self.conv20.bias, **inp)
+        return A.conv3d([a0], self.conv21.weight, None, scale=scale)
+
+    def forward(self, h, embed, context):
+        _need_gpu(h)
+        if h.shape[1] != 1:
+            raise ValueError("AdaptionModulateBEST takes a one-channel input [B, 1, N, H, W]")
+        return self.run(_lin(context, self.dense2.dense), xin=h[:, 0].contiguous())
 
 
 class ResBlockModulateBEST(nn.Module):
@@ -75,6 +125,22 @@ class ResBlockModulateBEST(nn.Module):
         self.res_conv = nn.Conv3d(channel_in, channel_out, 1) if channel_in != channel_out else nn.Identity()
         self.act = Swish()
         self.flag = flag
+
+    def run(self, segs, shift, scale):
+        """segs: the channel segments of the input (a torch.cat the reference materialises, :631-634)."""
+        from . import autograd as A
+        b, _, n, h, w = segs[0].shape
+        cin = sum(s.shape[1] for s in segs)
+        dev = segs[0].device
+        t1 = A.conv3d(segs, self.conv20.weight, self.conv20.bias, shift=None if self.flag else shift, act=True,
+                      mask=_drop_mask(self, (b, cin, n, h, w), self.dropout.p, dev))
+        res = A.conv3d(segs, self.res_conv.weight, self.res_conv.bias) if isinstance(self.res_conv, nn.Conv3d) else segs[0]
+        return A.conv3d([t1], self.conv21.weight, None, scale=scale, act=True,
+                        mask=_drop_mask(self, t1.shape, self.dropout.p, dev), residual=res)
+
+    def forward(self, x, embed, prompt):
+        _need_gpu(x)
+        return self.run([x], None if self.flag else _lin(embed, self.dense1.dense), _lin(prompt, self.dense2.dense))
 
 
 class WaveletUPorDown(nn.Module):
@@ -100,12 +166,38 @@ class WaveletUPorDown(nn.Module):
         self.dense1 = Dense(zemb_dim, in_ch)
         self.dense2 = Dense(zemb_dim, in_ch)      # exists in the reference (:366), unused by its forward
 
+    def run(self, x, shift, scale, skipH=None, want_high=True):
+        from . import autograd as A
+        hh = A.conv3d([x], self.Conv_0.weight, self.Conv_0.bias, act=True)
+        xx = A.conv3d([x], self.Conv_2.weight, self.Conv_2.bias)
+        hH = None
+        if self.up:
+            ch = self.convH_0[0]
+            bands = A.conv3d(list(skipH), ch.weight, ch.bias, bias_scale=2.0, groups=3)      # convH_0(cat/2)*2
+            h_in, x_in = A.haar_idwt2d_pair(hh, xx, bands, in_scale=2.0)
+        elif self.down:
+            h_in, lh, hl, hhh = A.haar_dwt2d(hh, want_high=want_high, ll_scale=0.5)
+            x_in = A.haar_dwt2d(xx, want_high=False, ll_scale=0.5)[0]
+            hH = (lh, hl, hhh)
+        else:
+            raise NotImplementedError("WavBEST only instantiates up or down wavelet blocks")
+        out = A.conv3d([h_in], self.Conv_1.weight, None, shift=None if self.flag else shift, scale=scale, act=True,
+                       mask=_drop_mask(self, h_in.shape, self.Dropout_0.p, h_in.device), residual=x_in)
+        return (out, hH) if self.down else out
+
+    def forward(self, x, temb=None, zemb=None, skipH=None):
+        _need_gpu(x)
+        return self.run(x, None if self.flag else _lin(temb, self.Dense_0), _lin(zemb, self.dense1.dense), skipH)
+
 
 class ResblockDownOneModulateBEST(nn.Module):
     def __init__(self, channel_in, channel_out, embed_dim, flag=False):
         super().__init__()
         self.conv20 = ResBlockModulateBEST(channel_in, channel_out, embed_dim, flag)
         self.down = WaveletUPorDown(in_ch=channel_out, temb_dim=embed_dim, zemb_dim=embed_dim, down=True, flag=flag)
+
+    def forward(self, x, embed, prompt):
+        return self.down(self.conv20(x, embed, prompt), embed, prompt)
 
 
 class ResblockUpOneModulateBEST(nn.Module):
@@ -114,6 +206,9 @@ class ResblockUpOneModulateBEST(nn.Module):
         self.up1 = WaveletUPorDown(in_ch=channel_out, temb_dim=embed_dim, zemb_dim=embed_dim, up=True,
                                    hi_in_ch=channel_in)
         self.conv20 = ResBlockModulateBEST(channel_in * 3, channel_out, embed_dim)
+
+    def forward(self, x, embed, skipH, prompt):
+        return self.up1(self.conv20(x, embed, prompt), embed, prompt, skipH)
 
 
 class FinalBlockModulateBEST(nn.Module):
@@ -126,6 +221,15 @@ class FinalBlockModulateBEST(nn.Module):
         self.conv24 = nn.Conv3d(channel_in, channel_out, 1)
         self.dense2 = Dense(embed_dim, channel_in)
         self.act = Swish()
+
+    def forward(self, x, embed, prompt):
+        from . import autograd as A
+        if self.conv24.out_channels != 1:
+            raise NotImplementedError("the head kernel produces one output channel (WavBEST: channel_out = 1)")
+        h = x
+        for blk in (self.conv20, self.conv21, self.conv22, self.conv23):
+            h = blk(h, embed, prompt)
+        return A.head(h, self.conv24.weight, _lin(prompt, self.dense2.dense)).unsqueeze(1)
 
 
 class _Bank:
@@ -340,20 +444,43 @@ class WavBEST(nn.Module):
             cond[f"bands{lvl}"] = self._conv(P, upn + ".up1.convH_0.0", list(skip), bias_scale=2.0)
         return cond
 
+    @staticmethod
+    def _tensor_key(t):
+        return (t.data_ptr(), t._version, tuple(t.shape), tuple(t.stride()))
+
     def begin_condition_cache(self, PAN, MS, prompt):
-        """Compute the x_t/t-independent half of the network once; later ``forward`` calls given the
-        same PAN / MS tensor objects and prompt reuse it until ``end_condition_cache``."""
-        self._cond = self._condition(self._prepare(), PAN, MS, prompt)
+        """Compute the x_t/t-independent half of the network once; later ``forward`` calls given the same PAN / MS
+        storage (same pointer, shape and version counter: an in-place update invalidates it) and prompt reuse it until
+        ``end_condition_cache``."""
+        with torch.no_grad():
+            self._cond = self._condition(self._prepare(), PAN, MS, prompt)
+        self._cond["key"] = (self._tensor_key(PAN), self._tensor_key(MS), prompt)
 
     def end_condition_cache(self):
         self._cond = None
 
+    def invalidate_prepared(self):
+        """Drop the packed weights / projection banks / condition cache.  ``_prepare`` notices parameter updates that
+        bump ``Parameter._version`` (optimizers, ``load_state_dict``); call this after writing parameters through
+        ``.data`` or a raw kernel (the EMA update does)."""
+        self._prep = None
+        self._cond = None
+
     # ---- forward ------------------------------------------------------------------------------------
-    @torch.no_grad()
     def forward(self, x_t, t_input, PAN=None, MS=None, prompt=None):
+        """Reference ``WavBEST.forward`` (:600-636).  Under ``torch.no_grad()`` (sampling) this is the fused
+        inference path; with grad mode on and anything that requires grad (a parameter or an input) it is the
+        differentiable path (``forward_train``), as the reference's forward is."""
+        if torch.is_grad_enabled() and (any(p.requires_grad for p in self.parameters()) or any(
+                torch.is_tensor(t) and t.requires_grad for t in (x_t, PAN, MS))):
+            return self.forward_train(x_t, t_input, PAN, MS, prompt)
+        with torch.no_grad():
+            return self._forward_infer(x_t, t_input, PAN, MS, prompt)
+
+    def _forward_infer(self, x_t, t_input, PAN, MS, prompt):
         P = self._prepare()
         cond = self._cond
-        if not (cond is not None and cond["pan"] is PAN and cond["ms"] is MS and cond["prompt"] == prompt):
+        if not (cond is not None and cond.get("key") == (self._tensor_key(PAN), self._tensor_key(MS), prompt)):
             cond = self._condition(P, PAN, MS, prompt)
         b = x_t.shape[0]
         t = t_input.reshape(-1).to(device=x_t.device, dtype=torch.float32)
@@ -382,51 +509,6 @@ class WavBEST(nn.Module):
         return ops.head(h, self.final.conv24.weight.detach().reshape(-1), sc["in_scale"], sc["scale_stride"])
 
     # ---- training path (finetune): same graph through the autograd-wrapped HIP ops ----------------------------
-    def _drop_mask(self, like_shape, p, device):
-        if not self.training or p <= 0.0:
-            return None
-        return (torch.rand(like_shape, device=device) >= p).float() / (1.0 - p)     # nn.Dropout(p) semantics
-
-    def _t_resblock(self, name, segs, shifts, scales, flag):
-        from . import autograd as A
-        rb = self.get_submodule(name)
-        b, _, n, h, w = segs[0].shape
-        cin = sum(s.shape[1] for s in segs)
-        dev = segs[0].device
-        t1 = A.conv3d(segs, rb.conv20.weight, rb.conv20.bias, shift=None if flag else shifts[name + ".dense1"],
-                      act=True, mask=self._drop_mask((b, cin, n, h, w), rb.dropout.p, dev))
-        if isinstance(rb.res_conv, nn.Conv3d):
-            res = A.conv3d(segs, rb.res_conv.weight, rb.res_conv.bias)
-        else:
-            res = segs[0]
-        return A.conv3d([t1], rb.conv21.weight, None, scale=scales[name + ".dense2"], act=True,
-                        mask=self._drop_mask(t1.shape, rb.dropout.p, dev), residual=res)
-
-    def _t_wavelet_tail(self, name, wl, h_in, x_in, shifts, scales, flag):
-        from . import autograd as A
-        return A.conv3d([h_in], wl.Conv_1.weight, None, shift=None if flag else shifts[name + ".Dense_0"],
-                        scale=scales[name + ".dense1"], act=True,
-                        mask=self._drop_mask(h_in.shape, wl.Dropout_0.p, h_in.device), residual=x_in)
-
-    def _t_down(self, name, x, shifts, scales, flag, want_high):
-        from . import autograd as A
-        wl = self.get_submodule(name)
-        hh = A.conv3d([x], wl.Conv_0.weight, wl.Conv_0.bias, act=True)
-        xx = A.conv3d([x], wl.Conv_2.weight, wl.Conv_2.bias)
-        hll, lh, hl, hhh = A.haar_dwt2d(hh, want_high=want_high, ll_scale=0.5)
-        xll = A.haar_dwt2d(xx, want_high=False, ll_scale=0.5)[0]
-        return self._t_wavelet_tail(name, wl, hll, xll, shifts, scales, flag), (lh, hl, hhh)
-
-    def _t_up(self, name, x, skip, shifts, scales):
-        from . import autograd as A
-        wl = self.get_submodule(name)
-        hh = A.conv3d([x], wl.Conv_0.weight, wl.Conv_0.bias, act=True)
-        xx = A.conv3d([x], wl.Conv_2.weight, wl.Conv_2.bias)
-        ch = wl.convH_0[0]
-        bands = A.conv3d(list(skip), ch.weight, ch.bias, bias_scale=2.0, groups=3)      # convH_0(cat/2)*2
-        h_up, x_up = A.haar_idwt2d_pair(hh, xx, bands, in_scale=2.0)
-        return self._t_wavelet_tail(name, wl, h_up, x_up, shifts, scales, False)
-
     def forward_train(self, x_t, t_input, PAN=None, MS=None, prompt=None):
         """Differentiable forward (dropout active when ``self.training``); used by
         ``GeneralDiffusion.p_losses_dynamic``.  Same graph as ``forward``, nothing cached."""
@@ -465,29 +547,33 @@ class WavBEST(nn.Module):
             return res
 
         shifts, scales = bank(temb, shift_layers), bank(pemb, scale_layers)
+        sh = lambda name: shifts.get(name)          # flag=True blocks have no shift entry (and ignore it)
 
-        def stem_block(blk, name, **inp):
-            a0 = A.stem(blk.conv20.weight, blk.conv20.bias, **inp)
-            return A.conv3d([a0], blk.conv21.weight, None, scale=scales[name + ".dense2"])
+        def resblock(name, segs):
+            return self.get_submodule(name).run(segs, sh(name + ".dense1"), scales[name + ".dense2"])
 
-        cond = {0: stem_block(self.conv1, "conv1", pan=PAN.contiguous(), ms=MS.contiguous())}
+        def down(name, x, want_high):
+            return self.get_submodule(name).run(x, sh(name + ".Dense_0"), scales[name + ".dense1"], want_high=want_high)
+
+        cond = {0: self.conv1.run(scales["conv1.dense2"], pan=PAN.contiguous(), ms=MS.contiguous())}
         skips = {}
         h = cond[0]
         for lvl, dn in enumerate(("down1_1", "down2_1", "down3_1"), start=1):
-            h = self._t_resblock(dn + ".conv20", [h], shifts, scales, True)
-            h, skips[lvl] = self._t_down(dn + ".down", h, shifts, scales, True, True)
+            h = resblock(dn + ".conv20", [h])
+            h, skips[lvl] = down(dn + ".down", h, True)
             cond[lvl] = h
-        hs = [stem_block(self.conv2, "conv2", xin=x_t.contiguous())]
+        hs = [self.conv2.run(scales["conv2.dense2"], xin=x_t.contiguous())]
         h = hs[0]
         for dn in ("down1", "down2", "down3"):
-            h = self._t_resblock(dn + ".conv20", [h], shifts, scales, False)
-            h, _ = self._t_down(dn + ".down", h, shifts, scales, False, False)
+            h = resblock(dn + ".conv20", [h])
+            h, _ = down(dn + ".down", h, False)
             hs.append(h)
-        h = self._t_resblock("middle1", [hs[3]], shifts, scales, False)
+        h = resblock("middle1", [hs[3]])
         for lvl, upn in ((3, "up1"), (2, "up2"), (1, "up3")):
-            h = self._t_resblock(upn + ".conv20", [h, cond[lvl], hs[lvl]], shifts, scales, False)
-            h = self._t_up(upn + ".up1", h, skips[lvl], shifts, scales)
-        h = self._t_resblock("final.conv20", [h, cond[0], hs[0]], shifts, scales, False)
+            h = resblock(upn + ".conv20", [h, cond[lvl], hs[lvl]])
+            h = self.get_submodule(upn + ".up1").run(h, sh(upn + ".up1.Dense_0"), scales[upn + ".up1.dense1"],
+                                                     skipH=skips[lvl])
+        h = resblock("final.conv20", [h, cond[0], hs[0]])
         for k in (1, 2, 3):
-            h = self._t_resblock(f"final.conv2{k}", [h], shifts, scales, False)
+            h = resblock(f"final.conv2{k}", [h])
         return A.head(h, self.final.conv24.weight, scales["final.dense2"])

@@ -49,6 +49,8 @@ SIGNATURES = {
     "tmdiff_channel_sum": (C.c_int, [vp, vp, C.c_int32, C.c_int32, C.c_int64, C.c_float, vp]),
     "tmdiff_conv3d_prologue_bwd": (C.c_int, [C.POINTER(Conv3dDesc), vp, vp * 3, C.c_int32 * 3, vp, vp, vp]),
     "tmdiff_stem_bwd": (C.c_int, [vp, vp, vp, vp, vp, vp, vp, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32, vp]),
+    "tmdiff_stem_bwd_input": (C.c_int, [vp, vp, vp, vp, vp, vp, vp, vp, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32,
+                                        vp]),
     "tmdiff_head_bwd": (C.c_int, [vp, vp, vp, vp, vp, vp, C.c_int32, C.c_int32, C.c_int64, vp]),
     "tmdiff_linear_bwd": (C.c_int, [vp, vp, vp, vp, vp, vp, vp, vp, C.c_int32, C.c_int32, C.c_int32, C.c_int32, vp]),
     "tmdiff_stem_fwd": (C.c_int, [vp, vp, vp, vp, vp, vp, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32,

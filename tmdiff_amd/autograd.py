@@ -136,8 +136,18 @@ class _Stem(torch.autograd.Function):
     def backward(ctx, gy):
         w, bias, *ins = ctx.saved_tensors
         kw = {"xin": ins[0]} if ctx.mode else {"pan": ins[0], "ms": ins[1]}
-        dwb = ops.stem_bwd(w, bias, gy.contiguous(), **kw).sum(0)       # [C0, 2], tiny
-        return dwb[:, 0].reshape(ctx.wshape), dwb[:, 1].contiguous(), None, None, None
+        gy = gy.contiguous()
+        need = ctx.needs_input_grad          # (weight, bias, xin, pan, ms)
+        d_w = d_b = None
+        if need[0] or need[1]:
+            dwb = ops.stem_bwd(w, bias, gy, **kw).sum(0)       # [C0, 2], tiny
+            d_w, d_b = dwb[:, 0].reshape(ctx.wshape), dwb[:, 1].contiguous()
+        d_xin = d_pan = d_ms = None
+        if ctx.mode and need[2]:
+            d_xin, _ = ops.stem_bwd_input(w, bias, gy, **kw)
+        elif not ctx.mode and (need[3] or need[4]):
+            d_ms, d_pan = ops.stem_bwd_input(w, bias, gy, need_x=need[4], need_pan=need[3], **kw)
+        return d_w, d_b, d_xin, d_pan, d_ms
 
 
 def stem(weight, bias, xin=None, pan=None, ms=None):

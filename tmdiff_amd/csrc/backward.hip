@@ -409,6 +409,33 @@ __global__ void __launch_bounds__(256) stem_bwd_kernel(const float* __restrict__
   }
 }
 
+// stem backward w.r.t. the inputs: dx[b,p] = sum_co gy[b,co,p] * SiLU'(w_co x + b_co) * w_co.  One thread per (b, hw) walks
+// the N bands: in the (pan, ms) form x = pan[b,hw] - ms[b,n,hw], so d_ms = -dx and d_pan[b,hw] = sum_n dx[b,n,hw].
+__global__ void __launch_bounds__(256) stem_bwd_input_kernel(const float* __restrict__ xin, const float* __restrict__ pan,
+                                                             const float* __restrict__ ms, const float* __restrict__ w,
+                                                             const float* __restrict__ bias, const float* __restrict__ gy,
+                                                             float* __restrict__ dx, float* __restrict__ dpan, int Cout,
+                                                             int N, long HW) {
+  const long hw = blockIdx.x * 256L + threadIdx.x;
+  const int b = blockIdx.y;
+  if (hw >= HW) return;
+  const long P = HW * N;
+  float acc_pan = 0.f;
+  for (int n = 0; n < N; ++n) {
+    const long p = n * HW + hw;
+    const float x = ms ? pan[b * HW + hw] - ms[b * P + p] : xin[b * P + p];
+    float s = 0.f;
+    for (int co = 0; co < Cout; ++co) {
+      const float wc = w[co];
+      const float u = __fadd_rn(__fmul_rn(wc, x), bias ? bias[co] : 0.f);
+      s += gy[((long)b * Cout + co) * P + p] * silu_grad(u) * wc;
+    }
+    acc_pan += s;
+    if (dx) dx[b * P + p] = ms ? -s : s;
+  }
+  if (dpan) dpan[b * HW + hw] = acc_pan;
+}
+
 // head backward: one workgroup per (c, b)
 __global__ void __launch_bounds__(256) head_bwd_kernel(const float* __restrict__ x, const float* __restrict__ w,
                                                        const float* __restrict__ scale, const float* __restrict__ gy,
@@ -644,6 +671,20 @@ extern "C" int tmdiff_stem_bwd(const float* xin, const float* pan, const float* 
   const long HW = (long)H * W;
   stem_bwd_kernel<<<dim3(Cout, B), 256, 0, as_stream(stream)>>>(xin, pan, ms, w, bias, gy, dwb, Cout, HW * N, HW);
   return check_launch("stem_bwd");
+}
+
+extern "C" int tmdiff_stem_bwd_input(const float* xin, const float* pan, const float* ms, const float* w,
+                                     const float* bias, const float* gy, float* dx, float* dpan, int32_t B, int32_t Cout,
+                                     int32_t N, int32_t H, int32_t W, tmdiff_stream_t stream) {
+  using namespace tmdiff;
+  TMDIFF_REQUIRE(w && gy && (dx || dpan), "stem_bwd_input: NULL pointer");
+  TMDIFF_REQUIRE((ms && pan) || (!ms && xin), "stem_bwd_input: give either (pan, ms) or xin");
+  TMDIFF_REQUIRE(ms || !dpan, "stem_bwd_input: d_pan only exists in the (pan, ms) form");
+  TMDIFF_REQUIRE(B > 0 && B <= 65535 && Cout > 0 && N > 0 && H > 0 && W > 0, "stem_bwd_input: bad extents");
+  const long HW = (long)H * W;
+  stem_bwd_input_kernel<<<dim3((unsigned)((HW + 255) / 256), B), 256, 0, as_stream(stream)>>>(xin, pan, ms, w, bias, gy, dx,
+                                                                                            dpan, Cout, N, HW);
+  return check_launch("stem_bwd_input");
 }
 
 extern "C" int tmdiff_head_bwd(const float* x, const float* w, const float* scale, const float* gy, float* dx,

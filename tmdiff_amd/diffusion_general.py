@@ -123,6 +123,17 @@ class GeneralDiffusion(nn.Module):
         return mean, self.posterior_log_variance_clipped[t]
 
     @torch.no_grad()
+    def p_mean_variance_xo(self, x, t, clip_denoised=True, x_in=None, prompt="QB", guidance=1.0):
+        """x0-parameterised twin of ``p_mean_variance`` (ref :173-190, called by nothing there): the network output is
+        taken as x_0 directly, clamped, and fed to the posterior.  Same fused kernel with predict_start coefficients
+        (0, -1): 0*x + 1*out is exact."""
+        time_in = torch.full((x.shape[0], 1), t + 1, device=x.device, dtype=torch.float32)
+        x0 = self.denoise_fn(x, time_in, x_in["PAN"], x_in["MS"], prompt)
+        _, _, c1, c2, _ = self._step_coef[t]
+        mean = ops.ddpm_step(x, x0, None, 0.0, -1.0, c1, c2, 0.0, clip=clip_denoised)
+        return mean, self.posterior_log_variance_clipped[t]
+
+    @torch.no_grad()
     def p_sample(self, x, t, clip_denoised=True, condition_x=None, prompt="QB", guidance=1.0, _img_out=None):
         time_in = torch.full((x.shape[0], 1), t + 1, device=x.device, dtype=torch.float32)
         eps = self.denoise_fn(x, time_in, condition_x["PAN"], condition_x["MS"], prompt)

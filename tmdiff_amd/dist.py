@@ -5,9 +5,12 @@ batch, sums the replica losses (``model.py:41`` ``.sum()``) and so ends up with 
 gradients.  The MI355X-native equivalent: each rank holds a full replica and its share of the batch;
 
   * inference / sampling: ``shard_batch`` splits the image dict; no collective touches the data path;
-  * finetune: after ``loss.backward()`` call ``allreduce_gradients(module)`` -- ONE exchange per step: gradients
-    are flattened into a few large fp32 buckets (fully connected xGMI favours few large collectives) and
-    all-reduced with SUM (default, the reference's DataParallel arithmetic) or averaged.
+  * finetune: ONE exchange per step -- gradients live in a few large flat fp32 buckets (fully connected xGMI
+    favours few large collectives) that are all-reduced with SUM (default, the reference's DataParallel arithmetic)
+    or averaged.  ``GradReducer`` makes ``p.grad`` a view of its bucket and starts a bucket's all-reduce from a
+    post-accumulate hook as soon as backward has produced its last gradient (buckets follow the order in which
+    backward produces gradients), so the exchange overlaps the rest of backward and there is no flatten / copy-back
+    pass.  ``allreduce_gradients(module)`` is the simple after-backward form (used for the first step, and by tests).
 
 Backend: ``nccl`` (= RCCL over xGMI) on GPUs, ``gloo`` on CPU tensors (used by the CPU tests).  Parameters whose
 gradient is None on this rank (56 WavBEST tensors never get one) are left untouched on every rank, so the bucket
@@ -56,8 +59,11 @@ def allreduce_gradients(module, op="sum", bucket_bytes=64 << 20, group=None):
         raise ValueError("op must be 'sum' (DataParallel semantics of the reference) or 'mean'")
     if not dist.is_initialized() or dist.get_world_size(group) == 1:
         return 0
+    return _allreduce_tensors([p.grad for p in module.parameters() if p.grad is not None], op, bucket_bytes, group)
+
+
+def _allreduce_tensors(grads, op, bucket_bytes, group):
     world = dist.get_world_size(group)
-    grads = [p.grad for p in module.parameters() if p.grad is not None]
     buckets, cur, cur_bytes = [], [], 0
     for g in grads:
         nb = g.numel() * g.element_size()
@@ -78,6 +84,127 @@ def allreduce_gradients(module, op="sum", bucket_bytes=64 << 20, group=None):
             g.copy_(flat[off:off + g.numel()].view_as(g))
             off += g.numel()
     return len(buckets)
+
+
+class GradReducer:
+    """Bucketed gradient all-reduce overlapped with backward ("bucketed and overlapped with backward").
+
+    Step 1 runs backward normally, records the order in which parameters received their gradients and reduces with
+    ``allreduce_gradients``.  ``finish()`` of that step then lays the gradients out in flat buckets in that order
+    (parameters that got no gradient -- 56 WavBEST tensors never do -- stay outside, identically on every rank) and
+    re-points ``p.grad`` at views of them.  From step 2 on, autograd accumulates into the views in place, the
+    post-accumulate hook of the last parameter of a bucket launches ``all_reduce(async_op=True)`` on the flat bucket
+    (RCCL runs it on its own stream after the producing kernels), and ``finish()`` waits for the handles before
+    the optimizer step.  Use ``zero_grad()`` of this object (zeroes the buckets in place) instead of
+    ``optimizer.zero_grad()`` (which would drop the views).
+    """
+
+    def __init__(self, module, op="sum", bucket_bytes=32 << 20, group=None):
+        if op not in ("sum", "mean"):
+            raise ValueError("op must be 'sum' (DataParallel semantics of the reference) or 'mean'")
+        self.module, self.op, self.bucket_bytes, self.group = module, op, bucket_bytes, group
+        self.active = dist.is_initialized() and dist.get_world_size(group) > 1
+        self.world = dist.get_world_size(group) if self.active else 1
+        self.buckets = None          # list of dicts {flat, params, pending}
+        self._order, self._bucket_of, self._handles = [], {}, []
+        self.launched = 0            # all-reduces started from hooks during the last backward
+        self._hooks = []
+        if self.active:
+            for p in module.parameters():
+                if p.requires_grad:
+                    self._hooks.append(p.register_post_accumulate_grad_hook(self._on_grad))
+
+    def _on_grad(self, p):
+        if not self.active:
+            return
+        if self.buckets is None:
+            self._order.append(p)
+            return
+        bk = self._bucket_of.get(id(p))
+        if bk is None:               # a parameter outside the recorded layout got a gradient: rebuild after this step
+            self._order.append(p)
+            return
+        bk["pending"] -= 1
+        if bk["pending"] == 0:
+            self._handles.append(dist.all_reduce(bk["flat"], op=dist.ReduceOp.SUM, group=self.group, async_op=True))
+            self.launched += 1
+
+    def _build(self):
+        params = [p for p in self._order if p.grad is not None]
+        seen, uniq = set(), []
+        for p in params:
+            if id(p) not in seen:
+                seen.add(id(p))
+                uniq.append(p)
+        self.buckets, self._bucket_of = [], {}
+        cur, cur_bytes = [], 0
+        groups = []
+        for p in uniq:
+            nb = p.numel() * 4
+            if cur and cur_bytes + nb > self.bucket_bytes:
+                groups.append(cur)
+                cur, cur_bytes = [], 0
+            cur.append(p)
+            cur_bytes += nb
+        if cur:
+            groups.append(cur)
+        for ps in groups:
+            flat = torch.zeros(sum(p.numel() for p in ps), device=ps[0].device, dtype=torch.float32)
+            off = 0
+            for p in ps:
+                view = flat[off:off + p.numel()].view_as(p)
+                view.copy_(p.grad)
+                p.grad = view
+                off += p.numel()
+            bk = {"flat": flat, "params": ps, "pending": len(ps)}
+            self.buckets.append(bk)
+            for p in ps:
+                self._bucket_of[id(p)] = bk
+        self._order = []
+
+    def finish(self):
+        """Call after backward, before the optimizer step.  Returns the number of all-reduces of this step."""
+        if not self.active:
+            return 0
+        if self.buckets is None:     # first step: plain path, then lay the buckets out in the recorded order
+            n = allreduce_gradients(self.module, self.op, self.bucket_bytes, self.group)
+            self._build()
+            return n
+        # buckets whose hooks did not all fire (a parameter got no gradient this step: its slot is still zero)
+        for bk in self.buckets:
+            if bk["pending"] > 0:
+                self._handles.append(dist.all_reduce(bk["flat"], op=dist.ReduceOp.SUM, group=self.group, async_op=True))
+                bk["pending"] = 0
+        for h in self._handles:
+            h.wait()
+        n, self._handles = len(self._handles), []
+        if self.op == "mean":
+            for bk in self.buckets:
+                bk["flat"] /= self.world
+        if self._order:              # gradients outside the layout (graph changed): reduce them now, extend the layout
+            stray = [p for p in self._order if p.grad is not None]
+            n += _allreduce_tensors([p.grad for p in stray], self.op, self.bucket_bytes, self.group)
+            self._order = [p for bk in self.buckets for p in bk["params"]] + stray
+            self._build()
+        return n
+
+    def zero_grad(self):
+        self.launched = 0
+        if self.buckets is None:
+            self.module.zero_grad(set_to_none=True)
+            self._order = []
+            return
+        for bk in self.buckets:
+            bk["flat"].zero_()
+            bk["pending"] = len(bk["params"])
+        for p in self.module.parameters():           # gradient-free parameters stay None
+            if p.grad is not None and id(p) not in self._bucket_of:
+                p.grad = None
+
+    def close(self):
+        for h in self._hooks:
+            h.remove()
+        self._hooks = []
 
 
 def gather_images(local, group=None):

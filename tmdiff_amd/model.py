@@ -6,7 +6,8 @@ save_network, load_network), same option keys, same checkpoint files (``I{iter}_
 state_dict, ``I{iter}_opt.pth`` = {iter, scheduler, optimizer}).  Differences: the LR schedule
 (``transformers.get_scheduler("linear", warmup 100)``, model.py:32) is an equivalent LambdaLR so that transformers is
 not required, and with more than one process the gradients are SUM-all-reduced over RCCL before the optimizer
-step (``tmdiff_amd.dist``) instead of wrapping the module in nn.DataParallel.
+step (``tmdiff_amd.dist.GradReducer``: flat buckets, all-reduces started from backward hooks so the exchange overlaps
+the rest of backward) instead of wrapping the module in nn.DataParallel.
 """
 import logging
 import os
@@ -59,6 +60,7 @@ class DDPM(BaseModel):
         self.netG = self.set_device(networks.define_General(opt))
         self.schedule_phase = None
         self.grad_reduce = (opt.get("train") or {}).get("grad_reduce", "sum") if isinstance(opt, dict) else "sum"
+        self.reducer = None
         self.set_loss()
         if self.opt["phase"] == "train":
             self.netG.train()
@@ -73,12 +75,14 @@ class DDPM(BaseModel):
         self.data = self.set_device(data)
 
     def optimize_parameters(self, prompt=None):
+        if self.reducer is None:       # created here: the process group exists by the first step
+            self.reducer = tdist.GradReducer(self.netG, op=self.grad_reduce)
         l_pix = self.netG(self.data, prompt).sum()
-        l_pix.backward()
-        tdist.allreduce_gradients(self.netG, op=self.grad_reduce)      # no-op in a single process
+        l_pix.backward()                # bucket all-reduces start from hooks while backward is still running
+        self.reducer.finish()           # no-op in a single process
         self.optG.step()
         self.scheduler.step()
-        self.optG.zero_grad()
+        self.reducer.zero_grad()
         self.log_dict["l_pix"] = l_pix.detach()
         self.log_dict["lr"] = self.optG.state_dict()["param_groups"][0]["lr"]
 
@@ -159,6 +163,11 @@ class EmaUpdater:
         else:
             for p, p_ema in pairs:
                 p_ema.data.copy_(p.data)
+        # the writes above go through .data / a raw kernel and do not bump Parameter._version, which is what WavBEST
+        # keys its packed convolution weights and projection banks on: drop them explicitly
+        net = self.ema_model.netG.denoise_fn
+        if hasattr(net, "invalidate_prepared"):
+            net.invalidate_prepared()
 
     def load_ema_params(self):
         self.model.netG.denoise_fn.load_state_dict(self.ema_model.netG.denoise_fn.state_dict())

@@ -381,6 +381,17 @@ def stem_bwd(w, bias, gy, xin=None, pan=None, ms=None):
     return dwb
 
 
+def stem_bwd_input(w, bias, gy, xin=None, pan=None, ms=None, need_x=True, need_pan=False):
+    """Gradients w.r.t. the stem's inputs: (d_xin, None) or (d_ms, d_pan)."""
+    b, c0, n, h, wd = gy.shape
+    dx = torch.empty(b, n, h, wd, device=gy.device, dtype=torch.float32) if need_x else None
+    dpan = torch.empty(b, 1, h, wd, device=gy.device, dtype=torch.float32) if (need_pan and ms is not None) else None
+    check(lib.tmdiff_stem_bwd_input(_chk(xin, "xin"), _chk(pan, "pan"), _chk(ms, "ms"), _chk(w, "w"), _chk(bias, "bias"),
+                                    _chk(gy, "gy"), _chk(dx, "dx"), _chk(dpan, "dpan"), b, c0, n, h, wd, stream_ptr()),
+          "stem_bwd_input")
+    return dx, dpan
+
+
 def head_bwd(x, w, scale, gy, need_dx=True):
     b, c, n, h, wd = x.shape
     dx = torch.empty_like(x) if need_dx else None

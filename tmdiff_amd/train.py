@@ -6,7 +6,8 @@
 Same option file, dataset names (``train_qb / train_gf2 / train_wv3``, ``val_QB / val_GF2 / val_WV3``), per-iteration
 random choice of the training set with the reference's weights (4, 4, 8 per batch of QB, GF2, WV3: the band counts),
 print / validation / checkpoint cadence and ``.mat`` outputs.  Multi-GPU is one process per GPU: every rank draws the
-same dataset each iteration (same seeded ``random``) but its own batches, and ``DDPM.optimize_parameters`` SUM-
+same dataset each iteration (same seeded ``random``) but its own batches (``batch_size // world`` items: the option
+file's batch size is the global one, as under DataParallel), timesteps, noise and dropout masks, and ``DDPM.optimize_parameters`` SUM-
 all-reduces the gradients over RCCL (the reference's DataParallel arithmetic, model.py:41).
 """
 import argparse
@@ -27,14 +28,23 @@ TRAIN_SETS = (("train_qb", "QB", 4), ("train_gf2", "GF2", 4), ("train_wv3", "WV3
 VAL_SETS = (("val_QB", "QB"), ("val_GF2", "GF2"), ("val_WV3", "WV3"))
 
 
-def seed_all(seed=3407):
-    """reference seed_torch (:24-33)"""
+def seed_all(seed=3407, rank=0):
+    """reference seed_torch (:24-33).  ``random`` (the per-iteration choice of the training set, shared by all ranks)
+    is seeded identically everywhere; NumPy (the timesteps of p_losses_dynamic), torch and the device generator
+    (noise, dropout masks) are offset by the rank, so that the ranks draw different (t, eps, mask) like the
+    reference's DataParallel replicas do."""
     random.seed(seed)
     os.environ["PYTHONHASHSEED"] = str(seed)
-    np.random.seed(seed)
-    torch.manual_seed(seed)
+    np.random.seed(seed + rank)
+    torch.manual_seed(seed + rank)
     if torch.cuda.is_available():
-        torch.cuda.manual_seed_all(seed)
+        torch.cuda.manual_seed_all(seed + rank)
+
+
+def per_rank_batch(batch_size, world):
+    """The option file's ``batch_size`` is the GLOBAL batch: nn.DataParallel (reference networks.py:88-91) scatters it
+    over the GPUs, so one process per GPU takes batch_size // world (at least 1)."""
+    return max(1, int(batch_size) // max(1, world))
 
 
 def dataset_probabilities(lengths):
@@ -74,7 +84,7 @@ def main(argv=None):
     logging.basicConfig(level=logging.INFO if rank == 0 else logging.WARNING, format="%(asctime)s %(message)s")
     logger = logging.getLogger("base")
     logger.info(Config.dict2str(opt))
-    seed_all()
+    seed_all(rank=rank)
 
     loaders, gens = {}, {}
     for name, ds_opt in opt["datasets"].items():
@@ -82,6 +92,8 @@ def main(argv=None):
         if is_train and args.phase == "val":
             continue
         ds = Data.create_dataset(ds_opt, "train" if is_train else "val")
+        if is_train and world > 1:
+            ds_opt = dict(ds_opt, batch_size=per_rank_batch(ds_opt["batch_size"], world))
         g = torch.Generator().manual_seed(3407 + 1000 * rank) if is_train else None   # each rank its own batches
         loaders[name] = Data.create_dataloader(ds, ds_opt, name, generator=g)
         if is_train:
