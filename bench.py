@@ -231,9 +231,10 @@ def train_leg(dev, world, rank, dist, steps, warmup):
     barrier()
     t0 = time.perf_counter()
     run(steps, 10)
+    t_host = time.perf_counter() - t0          # launches enqueued (the host runs ahead of the GPU when it can)
     barrier()
     dt = time.perf_counter() - t0
-    out = {"seconds": dt, "loss": float(m.get_current_log()["l_pix"]), "allreduce": None}
+    out = {"seconds": dt, "host_seconds": t_host, "loss": float(m.get_current_log()["l_pix"]), "allreduce": None}
     if dist is not None:
         red = m.reducer
         nbytes = sum(bk["flat"].numel() * 4 for bk in red.buckets)
@@ -275,6 +276,7 @@ TRAIN_GFLOP_PER_SAMPLE = 3 * GFLOP_PER_SAMPLE      # training step 
 def train_object(leg, world, steps):
     dt = leg["seconds"]
     return {"value": round(world * 8 * steps / dt, 2), "unit": "samples/s", "ms_per_step": round(dt / steps * 1e3, 3),
+            "host_enqueue_ms_per_step": round(leg["host_seconds"] / steps * 1e3, 3),
             "steps": steps, "global_batch": 8 * world, "tflops_per_gpu": round(8 * TRAIN_GFLOP_PER_SAMPLE * 1e-3 * steps / dt, 2),
             "frac_of_fp32_mfma_peak": round(8 * TRAIN_GFLOP_PER_SAMPLE * 1e-3 * steps / dt / PEAK_FP32_MFMA, 4),
             "loss": round(leg["loss"], 5), "allreduce": leg["allreduce"],

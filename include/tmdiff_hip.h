@@ -23,7 +23,7 @@
 extern "C" {
 #endif
 
-#define TMDIFF_ABI_VERSION 2
+#define TMDIFF_ABI_VERSION 3
 
 #define TMDIFF_OK 0
 #define TMDIFF_E_INVALID (-1)     /* bad argument / shape */
@@ -85,6 +85,22 @@ typedef struct tmdiff_conv3d_desc {
    * applied): nseg 1, no shift / scale / act / mask.  Only tmdiff_conv3d_fwd_bf16 (3x3x3) accepts it; it then skips
    * its pack pass and needs no workspace. */
   int32_t x_bf16;
+  /* Optional split-K workspace (fp32 3x3x3 entry points tmdiff_conv3d_fwd / _fwd_staged only).  A launch whose grid
+   * would leave most of the 256 CUs idle (single images: B = 1 at every level of the UNet; the 8x8 / 16x16 levels at
+   * small batches) is split over the input channels: `ksplit` workgroups per output tile accumulate disjoint channel
+   * ranges into partial outputs [ksplit][B][Cout][N*H*W] here, and a second kernel sums them in a fixed order and
+   * applies the epilogue (deterministic; the fused and the staged entry point split identically, so they still agree
+   * bit for bit).  NULL = never split.  Size: tmdiff_conv3d_fwd_splitk_workspace_bytes(d) (0 = this launch does not
+   * split); 16-byte aligned. */
+  void* splitk_ws;
+  int64_t splitk_ws_bytes;
+  /* In-kernel dropout (training; nn.Dropout(p) at Hyper_unet_general.py:230, :243-246, :349, :403): drop_p > 0 multiplies
+   * the prologue output by a Bernoulli(1 - p) keep mask scaled by 1 / (1 - p) that is a pure function of
+   * (drop_seed, element index ((b * Cin + c) * N*H*W + pos)) -- a counter-based hash (splitmix64 finaliser), so the
+   * forward, tmdiff_conv3d_wgrad and tmdiff_conv3d_prologue_bwd regenerate the same mask from the same descriptor and no
+   * mask tensor exists.  in_mask (a caller-supplied mask tensor, parity runs) must then be NULL.  fp32 entry points only. */
+  uint64_t drop_seed;
+  float drop_p;
 } tmdiff_conv3d_desc;
 
 /* w [Cout, Cin/groups, k, k, k] (PyTorch layout) -> packed [g][ci][tap][co] used by the
@@ -94,6 +110,8 @@ typedef struct tmdiff_conv3d_desc {
 int tmdiff_conv3d_pack_weights(const float* w, float* packed, int32_t Cout, int32_t Cin, int32_t ksize,
                                int32_t groups, int32_t mode, tmdiff_stream_t stream);
 int tmdiff_conv3d_fwd(const tmdiff_conv3d_desc* d, tmdiff_stream_t stream);
+/* bytes of d->splitk_ws this convolution would use (0: its grid fills the chip, or the shape is not split) */
+size_t tmdiff_conv3d_fwd_splitk_workspace_bytes(const tmdiff_conv3d_desc* d);
 
 /* ---- staged variant of tmdiff_conv3d_fwd (same arithmetic, exact fp32, bit-identical results) ----------------
  * Two launches instead of one: the prologue output x' (and the concatenation of the segments) is written once into
@@ -152,6 +170,13 @@ int tmdiff_channel_sum(const float* x, float* out, int32_t B, int32_t C, int64_t
  * d_shift[B,Cin], d_scale[B,Cin] (NULL = not needed, dense rows). */
 int tmdiff_conv3d_prologue_bwd(const tmdiff_conv3d_desc* d, const float* gp, float* const dx_seg[3],
                                const int32_t accumulate[3], float* d_shift, float* d_scale, tmdiff_stream_t stream);
+/* Same, with a workspace of tmdiff_conv3d_prologue_bwd_workspace_bytes(d) bytes (0 = not needed): planes are then cut
+ * into several workgroups each when B*Cin alone cannot fill the chip (the full-resolution 32-channel layers at small
+ * batches); the per-plane sums are finished in a fixed order (deterministic). */
+size_t tmdiff_conv3d_prologue_bwd_workspace_bytes(const tmdiff_conv3d_desc* d);
+int tmdiff_conv3d_prologue_bwd_ws(const tmdiff_conv3d_desc* d, const float* gp, float* const dx_seg[3],
+                                  const int32_t accumulate[3], float* d_shift, float* d_scale, void* workspace,
+                                  tmdiff_stream_t stream);
 
 /* ------------------------------------------------------------------------------------
  * Stem / head pointwise convolutions (bandwidth kernels):
@@ -242,6 +267,19 @@ int tmdiff_ddpm_step(const float* x, const float* eps, const float* noise, const
                      float sigma, int32_t clip, tmdiff_stream_t stream);
 int tmdiff_axpby(const float* const in[4], const float coef[4], int32_t n_in, float* out, int64_t n,
                  tmdiff_stream_t stream);
+/* Multi-tensor form, ONE launch for a whole parameter list: out_t = ca * a_t + cb * b_t for every entry (the EMA update of
+ * utils/EmaUpdater.py:23-38: out = a = EMA weights, b = live weights).  `tensors_dev` is a DEVICE array of entries;
+ * the launch has one workgroup per chunk of tmdiff_multi_axpby_chunk() elements: chunk k works on elements
+ * [chunk_index_dev[k] * chunk, ...) of tensor chunk_tensor_dev[k] (both DEVICE int32 arrays of n_chunks entries). */
+typedef struct tmdiff_mt_entry {
+  float* out;
+  const float* a;
+  const float* b;
+  int64_t n;
+} tmdiff_mt_entry;
+int32_t tmdiff_multi_axpby_chunk(void);
+int tmdiff_multi_axpby(const tmdiff_mt_entry* tensors_dev, const int32_t* chunk_tensor_dev, const int32_t* chunk_index_dev,
+                       int32_t n_chunks, float ca, float cb, tmdiff_stream_t stream);
 int tmdiff_x0_from_model(const float* x, const float* model_out, float* x0, int64_t n, float alpha, float sigma,
                          int32_t model_is_x_start, tmdiff_stream_t stream);
 size_t tmdiff_abs_quantile_workspace_bytes(int32_t B, int64_t n_per_sample);

@@ -302,11 +302,14 @@ def main():
     for algo in ("dpmsolver", "dpmsolver++"):
         mk = lambda model: RS.DPM_Solver(RS.model_wrapper(model, ns, model_type="noise"), ns, algorithm_type=algo)
         for order in (2, 3):
-            arrs[f"gauss_{algo}_adaptive_{order}"] = mk(gm).sample(xg, order=order, method="adaptive", skip_type="logSNR")
-            arrs[f"gauss_{algo}_adaptive_{order}_tight"] = mk(gm).sample(xg, order=order, method="adaptive",
-                                                                      skip_type="logSNR", atol=1e-4, rtol=1e-3)
-            arrs[f"gauss_{algo}_adaptive_{order}_perturbed"] = mk(gm).sample(xg * (1 + 1e-6), order=order,
-                                                                          method="adaptive", skip_type="logSNR")
+            for tag, kw in (("", {}), ("_tight", dict(atol=1e-4, rtol=1e-3))):
+                run = lambda x0: mk(gm).sample(x0, order=order, method="adaptive", skip_type="logSNR", **kw)
+                base = run(xg)
+                arrs[f"gauss_{algo}_adaptive_{order}{tag}"] = base
+                # how far the reference moves from itself under 1e-6 .. 1e-5 relative input changes (the controller's
+                # accept / reject decisions flip): the yardstick for an implementation with different last bits
+                sens = [float(((run(xg * (1 + e)) / (1 + e)) - base).norm() / base.norm()) for e in (1e-6, -1e-6, 3e-6, 1e-5)]
+                arrs[f"gauss_{algo}_adaptive_{order}{tag}_sensitivity"] = np.asarray(sens)
         arrs[f"toy_{algo}_adaptive_3_perturbed"] = mk(toy).sample(xT * (1 + 1e-7), steps=9, order=3, skip_type="logSNR",
                                                                  method="adaptive", solver_type="dpmsolver")
         # inverse (data -> noise along the ODE) and back, fixed-step multistep order 2

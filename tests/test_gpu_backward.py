@@ -113,7 +113,7 @@ def _check_block(g, tag, ref_mod, hip_mod, args, seed=60, grad_names=None):
             got = torch.stack([p_h.grad.sum(), p_h.grad.abs().sum()]).cpu().numpy()
             assert abs(got[1] - ref[1]) <= 2e-4 * max(ref[1], 1e-6) and abs(got[0] - ref[0]) <= 2e-4 * max(ref[1], 1e-6), (k, got, ref)
             n += 1
-    assert n > 0
+    assert n > 0 or not any(k.startswith(f"{tag}_gp_") for k in g.files)   # (the fixture's `up` case stores no checksums)
 
 
 @pytest.mark.parametrize("n", [4, 8])
@@ -309,3 +309,42 @@ def test_ema_update_refreshes_packed_weights(tmp_path):
         want = fresh.cuda().eval()(dc["x_t"], t, dc["PAN"], dc["MS"], "WV3")
     assert not torch.equal(after, before)
     assert torch.equal(after, want)
+
+
+def test_in_kernel_dropout_matches_explicit_mask():
+    """Dropout inside the kernels (no mask tensor): the keep mask is a pure function of (seed, element index), so the
+    forward (fused and staged kernels), the weight gradient and the prologue backward all see the same mask.  Recover the
+    mask through an identity convolution, then compare every output of the DropSpec path with the same operator fed that
+    mask as a tensor (the path that test_dropout_with_host_masks_vs_oracle pins to the oracle)."""
+    from tmdiff_amd import autograd as A, ops
+    torch.manual_seed(5)
+    b, cin, cout, shp = 2, 8, 32, (4, 16, 16)
+    seed, p = 123456789123, 0.2
+    ident = torch.zeros(cin, cin, 3, 3, 3)
+    for c in range(cin):
+        ident[c, c, 1, 1, 1] = 1.0
+    ones = torch.ones(b, cin, *shp, device="cuda")
+    wp = ops.pack_conv_weight(cu(ident))
+    m_fused = ops.conv3d([ones], wp, cin, 3, drop=(seed, p), staged=False)
+    m_staged = ops.conv3d([ones], wp, cin, 3, drop=(seed, p), staged=True)
+    assert torch.equal(m_fused, m_staged)
+    vals = torch.unique(m_fused)
+    assert vals.numel() == 2 and float(vals[0]) == 0.0 and abs(float(vals[1]) - 1.25) < 1e-6
+    keep = float((m_fused > 0).float().mean())
+    assert abs(keep - 0.8) < 0.01, keep                      # 16k elements: sigma = 0.003
+    per_plane = (m_fused > 0).float().flatten(2).mean(-1)
+    assert float(per_plane.min()) > 0.7 and float(per_plane.max()) < 0.9
+    assert torch.equal(ops.conv3d([ones], wp, cin, 3, drop=(seed, p)), m_fused)           # repeatable
+    other = ops.conv3d([ones], wp, cin, 3, drop=(seed + 1, p))
+    assert 0.55 < float(((other > 0) == (m_fused > 0)).float().mean()) < 0.8             # independent: 0.68 expected
+    # full operator: forward and every gradient, DropSpec vs explicit mask tensor
+    mk = lambda s, *shape: leaf(randn(s, *shape))
+    outs = []
+    for mask in (A.DropSpec(seed, p), m_fused.clone()):
+        x, w, bias = mk(1, b, cin, *shp), mk(2, cout, cin, 3, 3, 3), mk(3, cout)
+        shift, scale, res = mk(4, b, cin), leaf(1 + 0.3 * randn(5, b, cin)), mk(6, b, cout, *shp)
+        y = A.conv3d([x], w, bias, shift=shift, scale=scale, act=True, mask=mask, residual=res)
+        y.backward(cu(randn(7, *y.shape)))
+        outs.append([y.detach()] + [t.grad for t in (x, w, bias, shift, scale, res)])
+    for name, a_, b_ in zip(("y", "dx", "dw", "dbias", "dshift", "dscale", "dres"), *outs):
+        assert_close(a_, b_, 1e-6, 1e-6, f"in-kernel dropout {name}")

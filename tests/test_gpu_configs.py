@@ -54,7 +54,8 @@ def test_config2_batch32_full_width(golden):
         y32 = net(d32["x_t"], t, d32["PAN"], d32["MS"], "WV3")
         y4 = net(d32["x_t"][12:16].contiguous(), t[12:16].contiguous(), d32["PAN"][12:16].contiguous(),
                  d32["MS"][12:16].contiguous(), "WV3")
-    assert_close(y32[12:16], y4, 2e-6, 2e-6, "rows 12..15 of a batch of 32 vs a batch of 4")
+    # (other tile configurations and split-K factors at B = 4: a different fp32 summation order, not different maths)
+    assert_close(y32[12:16], y4, 1e-5, 1e-5, "rows 12..15 of a batch of 32 vs a batch of 4")
 
 
 # ---- configs[2]: the WorldView-3 network of config/general.json ---------------------------------------------------------
@@ -112,12 +113,14 @@ def test_config3_dpmsolver20_bf16_vs_oracle(wide_net):
 # ---- configs[3]: finetune step at full width, local batch 8 ---------------------------------------------------------------
 def test_config4_finetune_step_full_size():
     """Local batch 8 of 8x64x64 tiles, ch 32-256.  Size-independent properties of p_losses_dynamic (ref :349-370):
-    (1) dropout off: the gradient of the batch-8 mean-L1 loss is the mean of the two half-batch gradients (same
-    timesteps and noise) -- checks every backward kernel at the production tile configurations; (2) dropout on: finite
+    (1) dropout off: the gradient of the batch-8 mean-squared loss is the mean of the two half-batch gradients (same
+    timesteps and noise) -- checks every backward kernel at the production tile configurations (the L2 loss, because the
+    L1 loss's sign() is discontinuous: one element whose residual changes sign between the B = 8 and the B = 4 forward
+    moves a cancellation-dominated gradient by ~1/sqrt(#elements), seen as 1e-3 on convH_0); (2) dropout on, L1: finite
     loss and gradients, 56 gradient-free tensors, and the step is reproducible from the seeds."""
     from tmdiff_amd.diffusion_general import GeneralDiffusion
     net = _hip_net(FULL)
-    diff = GeneralDiffusion(net, "l1").cuda()
+    diff = GeneralDiffusion(net, "l2").cuda()
     diff.set_loss("cuda")
     diff.set_new_noise_schedule({"schedule": "cosine", "n_timestep": 1000}, "cuda")
     d = {k: cu(v) for k, v in case_inputs(3412, 8, 8, 64).items()}
@@ -143,14 +146,20 @@ def test_config4_finetune_step_full_size():
     lb, gb = grads(slice(4, 8))
     assert abs(l8 - 0.5 * (la + lb)) <= 1e-5 * abs(l8)
     assert len(g8) == 272 - 56
-    worst = 0.0
+    stats = []
     for k in g8:
         m, l2 = rel_err(g8[k], 0.5 * (ga[k] + gb[k]))
-        worst = max(worst, m)
-        assert m <= 2e-4 and l2 <= 5e-5, (k, m, l2)
-    print(f"batch-8 gradient vs mean of half-batch gradients: worst max-rel {worst:.2e} over {len(g8)} tensors")
+        stats.append((m, l2, k, float(g8[k].abs().max())))
+    stats.sort(reverse=True)
+    print("batch-8 gradient vs mean of half-batch gradients, worst tensors (max-rel, rel-L2, name, max|grad|):")
+    for m, l2, k, mag in stats[:8]:
+        print(f"  {m:.2e} {l2:.2e} {k} {mag:.2e}")
+    # (fp32 sums over 8 x 32768 positions taken in two different orders)
+    assert stats[0][0] <= 2e-5 and max(s_[1] for s_ in stats) <= 2e-5, stats[:3]
     net.train()
     diff.noise_fn = None
+    diff.loss_type = "l1"
+    diff.set_loss("cuda")
     outs = []
     for _ in range(2):
         np.random.seed(1); torch.manual_seed(2); torch.cuda.manual_seed(2)
@@ -160,7 +169,9 @@ def test_config4_finetune_step_full_size():
         outs.append((float(loss), net.final.conv20.conv20.weight.grad.clone()))
     assert np.isfinite(outs[0][0]) and all(torch.isfinite(p.grad).all() for p in net.parameters() if p.grad is not None)
     assert outs[0][0] == outs[1][0] and torch.equal(outs[0][1], outs[1][1])
-    assert abs(outs[0][0] - l8) > 1e-6                   # dropout really was active
+    net.eval()
+    np.random.seed(1); torch.manual_seed(2); torch.cuda.manual_seed(2)
+    assert abs(outs[0][0] - float(diff(d, "WV3"))) > 1e-6        # dropout really was active
 
 
 # ---- configs[4]: mixed satellites, per-sample prompts, tiled scene ----------------------------------------------------------
@@ -177,13 +188,16 @@ def test_config5_mixed_satellites_full_width():
     for bands, prompts, seed in ((4, ["GF2", "QB"], 3414), (8, ["WV3", "WV4"], 3415)):
         d = case_inputs(seed, 2, bands, 64)
         noise = randn(seed + 10, 2, bands, 64, 64)
-        ora.noise_fn = diff.noise_fn = lambda like: noise
+        diff.noise_fn = lambda like: noise
         dc = {k: cu(v) for k, v in d.items()}
         got = diff.p_sample(dc["x_t"], 700, condition_x=dc, prompt=prompts).cpu()
-        with torch.no_grad():
-            want = torch.cat([ora.p_sample(d["x_t"][i:i + 1], 700, condition_x={k: v[i:i + 1] for k, v in d.items()},
-                                           prompt=prompts[i]) for i in range(2)])
-        ora.noise_fn = lambda like: noise[:like.shape[0]]
+        rows = []
+        for i in range(2):
+            ora.noise_fn = lambda like, i=i: noise[i:i + 1]
+            with torch.no_grad():
+                rows.append(ora.p_sample(d["x_t"][i:i + 1], 700, condition_x={k: v[i:i + 1] for k, v in d.items()},
+                                         prompt=prompts[i]))
+        want = torch.cat(rows)
         m, l2 = rel_err(got, want)
         print(f"{bands}-band sub-batch {prompts}: max-rel {m:.2e} rel-L2 {l2:.2e}")
         assert m <= 1e-4 and l2 <= 1e-5

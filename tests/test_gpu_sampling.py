@@ -144,10 +144,11 @@ def test_solver_families_on_toy_model(golden):
 
 def test_adaptive_add_noise_inverse(golden):
     """dpm_solver_adaptive, add_noise, inverse (dpm_solver_pytorch.py:982-1079) against the REFERENCE's outputs on the
-    Gaussian-denoiser model (oracle.make_golden.gauss_model).  Tolerances: the step-size controller takes accept /
-    reject decisions on an error norm, so a last-bit difference can change the step sequence; the fixture records how far
-    the reference itself moves under a 1e-6 relative input change (`*_perturbed`: up to 1.5e-2 at the default
-    atol / rtol) -- the default-tolerance cases are held to 5e-2, the tight-tolerance ones (rtol 1e-3) to 5e-3."""
+    Gaussian-denoiser model (oracle.make_golden.gauss_model).  Tolerance: the step-size controller takes accept / reject
+    decisions on an error norm, so a last-bit difference can change the step sequence, and the solver only bounds the LOCAL
+    error.  The fixture records how far the reference moves from ITSELF under 1e-6 .. 1e-5 relative input changes
+    (`*_sensitivity`: 2e-7 for dpmsolver++ order 3 up to 9e-2 for dpmsolver order 2 at the default atol / rtol); the HIP
+    path is held to 3x the largest of those, and never looser than 1e-4 where the reference is stable."""
     from tmdiff_amd.diffusion_general import GeneralDiffusion
     from tmdiff_amd.dpm_solver import DPM_Solver, NoiseScheduleVP, model_wrapper
     from oracle.make_golden import gauss_model
@@ -159,13 +160,13 @@ def test_adaptive_add_noise_inverse(golden):
     for algo in ("dpmsolver", "dpmsolver++"):
         mk = lambda: DPM_Solver(model_wrapper(gm, ns, model_type="noise"), ns, algorithm_type=algo)
         for order in (2, 3):
-            y = mk().sample(xg, order=order, method="adaptive", skip_type="logSNR").cpu()
-            sens = rel_err(g[f"gauss_{algo}_adaptive_{order}_perturbed"], g[f"gauss_{algo}_adaptive_{order}"])[1]
-            m, l2 = rel_err(y, g[f"gauss_{algo}_adaptive_{order}"])
-            print(f"adaptive {algo} order {order}: max-rel {m:.2e} rel-L2 {l2:.2e} (reference sensitivity {sens:.1e})")
-            assert m <= 5e-2 and l2 <= 5e-2
-            y = mk().sample(xg, order=order, method="adaptive", skip_type="logSNR", atol=1e-4, rtol=1e-3).cpu()
-            assert_close(y, g[f"gauss_{algo}_adaptive_{order}_tight"], 5e-3, 5e-3, f"adaptive {algo} order {order} tight")
+            for tag, kw in (("", {}), ("_tight", dict(atol=1e-4, rtol=1e-3))):
+                key = f"gauss_{algo}_adaptive_{order}{tag}"
+                y = mk().sample(xg, order=order, method="adaptive", skip_type="logSNR", **kw).cpu()
+                tol = max(1e-4, 3.0 * float(g[key + "_sensitivity"].max()))
+                m, l2 = rel_err(y, g[key])
+                print(f"{key}: max-rel {m:.2e} rel-L2 {l2:.2e} (tolerance {tol:.1e} = 3 x reference self-sensitivity)")
+                assert l2 <= tol and m <= 2 * tol, key
         data = cu(0.5 * randn(154, 2, 4, 8, 8))
         z = mk().inverse(data, steps=12, order=2, skip_type="time_uniform", method="multistep")
         assert_close(z.cpu(), g[f"gauss_{algo}_inverse"], 1e-4, 1e-4, f"inverse {algo}")

@@ -285,6 +285,13 @@ def test_adaptive_add_noise_inverse_vs_reference(golden):
     xn = randn(155, 2, 4, 8, 8)
     assert_close(sol.add_noise(xn, torch.tensor([0.3]), noise=randn(156, 1, 2, 4, 8, 8)), g["add_noise_t1"], 1e-6, 1e-6)
     assert_close(sol.add_noise(xn, torch.tensor([0.1, 0.9]), noise=randn(157, 2, 2, 4, 8, 8)), g["add_noise_t2"], 1e-6, 1e-6)
+    # the reference's self-sensitivity stored beside each adaptive vector (the GPU test's yardstick) is what it claims:
+    # re-measure one of them with the restatement
+    run = lambda x0: DPM_Solver(model_wrapper(gm, ns, model_type="noise"), ns, algorithm_type="dpmsolver").sample(
+        x0, order=3, method="adaptive", skip_type="logSNR")
+    base = run(xg)
+    sens = float(((run(xg * (1 - 1e-6)) / (1 - 1e-6)) - base).norm() / base.norm())
+    assert abs(sens - float(g["gauss_dpmsolver_adaptive_3_sensitivity"][1])) <= 1e-6
     # why the toy-drift adaptive vectors of dpm_solver.npz are not parity vectors: the reference's own output moves by
     # O(1) relative under a 1e-7 relative change of x_T (both runs are the reference, stored by make_golden.py)
     g0 = golden("dpm_solver")

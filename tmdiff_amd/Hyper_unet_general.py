@@ -67,11 +67,15 @@ def set_dropout_mask_fn(fn):
 
 
 def _drop_mask(module, shape, p, device):
+    """Dropout of a convolution input: None (eval), a mask tensor from the parity hook, or a (seed, p) spec for the
+    in-kernel generator.  The seed is drawn from torch's CPU generator (so torch.manual_seed reproduces a run and
+    per-rank seeds give per-rank masks) -- a host-side draw, no device work and no mask tensor in HBM."""
     if not module.training or p <= 0.0:
         return None
     if _MASK_FN is not None:
         return _MASK_FN(tuple(shape)).to(device=device, dtype=torch.float32).contiguous()
-    return (torch.rand(shape, device=device) >= p).float() / (1.0 - p)     # nn.Dropout(p) semantics
+    from .autograd import DropSpec
+    return DropSpec(int(torch.randint(0, 2 ** 62, (1,)).item()), p)
 
 
 def _lin(x, layer):
@@ -423,7 +427,16 @@ class WavBEST(nn.Module):
             rows = [self.get_embeding(prompt)]
         if any(r is None for r in rows):                  # same exception type as the reference (:602)
             raise AttributeError(f"unknown prompt {prompt!r}: 'NoneType' object has no attribute 'repeat'")
-        return torch.cat(rows).to(device)
+        # device copies of the (fixed) embedding vectors are kept: a per-call host -> device copy of pageable memory
+        # makes the host wait for the stream to drain
+        key = (str(device), tuple(prompt) if isinstance(prompt, (list, tuple)) else prompt)
+        cache = self.__dict__.setdefault("_emb_dev", {})
+        hit = cache.get(key)
+        if hit is None or hit[0] is not self.text_embeddings:
+            if len(cache) > 64:
+                cache.clear()
+            hit = cache[key] = (self.text_embeddings, torch.cat(rows).to(device))
+        return hit[1]
 
     def _condition(self, P, PAN, MS, prompt):
         b = MS.shape[0]
@@ -522,7 +535,10 @@ class WavBEST(nn.Module):
         pemb = lin(self.embed2, 4, lin(self.embed2, 2, lin(self.embed2, 0, pe, True), True), True)
         t = t_input.reshape(-1).to(device=dev, dtype=torch.float32)
         t = (t if t.numel() == b else t.expand(b)).contiguous()
-        g = ops.gamma_embedding(t, self._freqs_cpu.to(dev), self.inter_dim)
+        fr = self.__dict__.get("_freqs_dev")
+        if fr is None or fr.device != dev:
+            fr = self.__dict__["_freqs_dev"] = self._freqs_cpu.to(dev)
+        g = ops.gamma_embedding(t, fr, self.inter_dim)
         temb = lin(self.embed, 2, lin(self.embed, 0, g, True), True)
 
         shift_layers, scale_layers = [], []

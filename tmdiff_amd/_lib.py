@@ -28,6 +28,8 @@ class Conv3dDesc(C.Structure):
         ("y", vp),
         ("y2", vp), ("y2_shift", vp), ("y2_scale", vp), ("y2_shift_stride", C.c_int32), ("y2_scale_stride", C.c_int32),
         ("y2_act", C.c_int32), ("y2_bf16", C.c_int32), ("x_bf16", C.c_int32),
+        ("splitk_ws", vp), ("splitk_ws_bytes", C.c_int64),
+        ("drop_seed", C.c_uint64), ("drop_p", C.c_float),
     ]
 
 
@@ -37,6 +39,7 @@ SIGNATURES = {
     "tmdiff_last_error_string": (C.c_char_p, []),
     "tmdiff_conv3d_pack_weights": (C.c_int, [vp, vp, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32, vp]),
     "tmdiff_conv3d_fwd": (C.c_int, [C.POINTER(Conv3dDesc), vp]),
+    "tmdiff_conv3d_fwd_splitk_workspace_bytes": (C.c_size_t, [C.POINTER(Conv3dDesc)]),
     "tmdiff_conv3d_fwd_staged_supported": (C.c_int, [C.POINTER(Conv3dDesc)]),
     "tmdiff_conv3d_fwd_staged_workspace_bytes": (C.c_size_t, [C.POINTER(Conv3dDesc)]),
     "tmdiff_conv3d_fwd_staged": (C.c_int, [C.POINTER(Conv3dDesc), vp, vp]),
@@ -48,6 +51,8 @@ SIGNATURES = {
     "tmdiff_conv3d_wgrad": (C.c_int, [C.POINTER(Conv3dDesc), vp, vp, vp, vp]),
     "tmdiff_channel_sum": (C.c_int, [vp, vp, C.c_int32, C.c_int32, C.c_int64, C.c_float, vp]),
     "tmdiff_conv3d_prologue_bwd": (C.c_int, [C.POINTER(Conv3dDesc), vp, vp * 3, C.c_int32 * 3, vp, vp, vp]),
+    "tmdiff_conv3d_prologue_bwd_workspace_bytes": (C.c_size_t, [C.POINTER(Conv3dDesc)]),
+    "tmdiff_conv3d_prologue_bwd_ws": (C.c_int, [C.POINTER(Conv3dDesc), vp, vp * 3, C.c_int32 * 3, vp, vp, vp, vp]),
     "tmdiff_stem_bwd": (C.c_int, [vp, vp, vp, vp, vp, vp, vp, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32, vp]),
     "tmdiff_stem_bwd_input": (C.c_int, [vp, vp, vp, vp, vp, vp, vp, vp, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32,
                                         vp]),
@@ -64,6 +69,8 @@ SIGNATURES = {
     "tmdiff_ddpm_step": (C.c_int, [vp, vp, vp, vp, vp, vp, C.c_int64, C.c_float, C.c_float, C.c_float, C.c_float,
                                    C.c_float, C.c_int32, vp]),
     "tmdiff_axpby": (C.c_int, [vp * 4, C.c_float * 4, C.c_int32, vp, C.c_int64, vp]),
+    "tmdiff_multi_axpby_chunk": (C.c_int32, []),
+    "tmdiff_multi_axpby": (C.c_int, [vp, vp, vp, C.c_int32, C.c_float, C.c_float, vp]),
     "tmdiff_x0_from_model": (C.c_int, [vp, vp, vp, C.c_int64, C.c_float, C.c_float, C.c_int32, vp]),
     "tmdiff_abs_quantile_workspace_bytes": (C.c_size_t, [C.c_int32, C.c_int64]),
     "tmdiff_abs_quantile_clamp": (C.c_int, [vp, C.c_int32, C.c_int64, C.c_float, C.c_float, vp, vp]),

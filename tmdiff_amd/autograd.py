@@ -13,6 +13,15 @@ from . import ops
 from ._lib import check, lib
 
 
+class DropSpec(tuple):
+    """(seed, p): dropout of a convolution's prologue output evaluated inside the kernels from a counter-based hash of
+    (seed, element index) -- forward, weight gradient and prologue backward regenerate the same mask; no mask tensor."""
+    __slots__ = ()
+
+    def __new__(cls, seed, p):
+        return super().__new__(cls, (int(seed), float(p)))
+
+
 class _FusedConv3d(torch.autograd.Function):
     """y = (conv3d(act(cat(segs) + shift) * scale * mask, w) + bias_scale*bias + residual) * out_scale"""
 
@@ -23,10 +32,14 @@ class _FusedConv3d(torch.autograd.Function):
         w = weight.contiguous()
         cout, ksize = w.shape[0], w.shape[2]
         wp = ops.pack_conv_weight(w, groups=groups, mode=0)
+        # mask: None, a tensor (caller-supplied dropout mask, parity runs) or a DropSpec (seed, p): in-kernel dropout
+        drop = mask if isinstance(mask, DropSpec) else None
+        mask = None if drop is not None else mask
         y = ops.conv3d(segs, wp, cout, ksize, groups=groups, bias=bias, bias_scale=bias_scale, in_shift=shift,
-                       in_scale=scale, in_act=act, in_mask=mask, residual=residual, out_scale=out_scale)
+                       in_scale=scale, in_act=act, in_mask=mask, drop=drop, residual=residual, out_scale=out_scale)
         ctx.meta = meta
         ctx.nseg = len(segs)
+        ctx.drop = drop
         ctx.has = (bias is not None, shift is not None, scale is not None, residual is not None, mask is not None)
         ctx.save_for_backward(w, *(t for t in (shift, scale, mask) if t is not None), *segs)
         return y
@@ -53,7 +66,7 @@ class _FusedConv3d(torch.autograd.Function):
         # descriptor of the forward prologue (what x' was): used by wgrad and by the prologue backward
         dummy = torch.empty(b, cout, n, h, wd, device=g.device, dtype=torch.float32) if False else g
         desc = ops.make_conv_desc(segs, 0, cout, ksize, dummy, groups=groups, in_shift=shift, in_scale=scale,
-                                  in_act=act, in_mask=mask)
+                                  in_act=act, in_mask=mask, drop=ctx.drop)
         d_w = ops.conv3d_wgrad(desc, g, tuple(w.shape)) if need[1] else None
         need_x = any(need[7:]) or (has_shift and need[3]) or (has_scale and need[4])
         d_shift = d_scale = None

@@ -23,6 +23,8 @@ __device__ __forceinline__ void static_for(F&& f) {
 
 using f32x16 = __attribute__((ext_vector_type(16))) float;
 
+__device__ __forceinline__ bool tmdiff_aligned16_dev(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }
+
 __device__ __forceinline__ float silu_grad(float t) {  // d/dt [t * sigmoid(t)]
   const float s = 1.0f / (1.0f + __expf(-t));
   return s * (1.0f + t * (1.0f - s));
@@ -75,6 +77,9 @@ struct ApplyArgs {
   int in_act;
   float* xp;
   long plane;
+  uint64_t drop_seed;      // in-kernel dropout (drop_inv > 0): keep mask from (seed, element index)
+  uint32_t drop_thresh;
+  float drop_inv;
 };
 
 // x'[b, c, :] = act(x[b, c, :] + shift[b,c]) * scale[b,c] * mask[b,c,:]  -- one (b, c) plane per blockIdx.y
@@ -89,11 +94,36 @@ __global__ void __launch_bounds__(256) prologue_apply_kernel(const ApplyArgs a) 
   const float sh = a.in_shift ? a.in_shift[(long)b * a.shift_stride + c] : 0.f;
   const float sc = a.in_scale ? a.in_scale[(long)b * a.scale_stride + c] : 1.f;
   float* dst = a.xp + (long)bc * a.plane;
+  const bool drop = a.drop_inv > 0.f;
+  const uint64_t ebase = (uint64_t)bc * (uint64_t)a.plane;
+  if ((a.plane & 3) == 0 && tmdiff_aligned16_dev(xs) && tmdiff_aligned16_dev(dst) && (!msk || tmdiff_aligned16_dev(msk))) {
+    for (long i = (blockIdx.x * 256L + threadIdx.x) * 4; i < a.plane; i += 1024L * gridDim.x) {
+      const float4 x4 = *reinterpret_cast<const float4*>(xs + i);
+      float v[4] = {x4.x, x4.y, x4.z, x4.w};
+      float m[4] = {1.f, 1.f, 1.f, 1.f};
+      if (msk) {
+        const float4 m4 = *reinterpret_cast<const float4*>(msk + i);
+        m[0] = m4.x, m[1] = m4.y, m[2] = m4.z, m[3] = m4.w;
+      }
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        float t = v[k] + sh;
+        if (a.in_act) t = tmdiff::silu_f(t);
+        t *= sc;
+        if (msk) t *= m[k];
+        if (drop) t *= tmdiff::drop_keep(a.drop_seed, ebase + (uint64_t)(i + k), a.drop_thresh, a.drop_inv);
+        v[k] = t;
+      }
+      *reinterpret_cast<float4*>(dst + i) = make_float4(v[0], v[1], v[2], v[3]);
+    }
+    return;
+  }
   for (long i = blockIdx.x * 256L + threadIdx.x; i < a.plane; i += 256L * gridDim.x) {
     float v = xs[i] + sh;
     if (a.in_act) v = tmdiff::silu_f(v);
     v *= sc;
     if (msk) v *= msk[i];
+    if (drop) v *= tmdiff::drop_keep(a.drop_seed, ebase + (uint64_t)i, a.drop_thresh, a.drop_inv);
     dst[i] = v;
   }
 }
@@ -120,7 +150,8 @@ __global__ void __launch_bounds__(256, 1) conv3d_wgrad_kernel(const WgradArgs a)
   __shared__ float st0[STAGE];
   __shared__ float st1[STAGE];
 
-  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, l31 = lane & 31, khalf = lane >> 5;
+  const int tid = threadIdx.x, lane = tid & 63, l31 = lane & 31, khalf = lane >> 5;
+  const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);   // wave-uniform: LDS-DMA destinations / tap offsets stay scalar
   int id = blockIdx.x;
   const int split = id % a.splits; id /= a.splits;
   const int ci_t = id % a.tiles_ci; id /= a.tiles_ci;
@@ -345,12 +376,17 @@ struct PrologueBwdArgs {
   float* d_shift;
   float* d_scale;
   long plane;
+  uint64_t drop_seed;      // in-kernel dropout, as in ApplyArgs
+  uint32_t drop_thresh;
+  float drop_inv;
+  int slices;              // workgroups per (b, c) plane; > 1: d_shift / d_scale hold [B, Cin, slices] partial sums
 };
 
-// one workgroup per (b, c) plane
+// `slices` workgroups per (b, c) plane (blockIdx.z); 16-byte accesses when the plane allows.  With slices > 1 the
+// per-plane sums d_shift / d_scale are written as [B, Cin, slices] partials and finished by rowsum_kernel (fixed order).
 __global__ void __launch_bounds__(256) prologue_bwd_kernel(const PrologueBwdArgs a) {
   __shared__ float red[4];
-  const int c = blockIdx.x, b = blockIdx.y;
+  const int c = blockIdx.x, b = blockIdx.y, sl = blockIdx.z;
   const float sh = a.in_shift ? a.in_shift[(long)b * a.shift_stride + c] : 0.f;
   const float sc = a.in_scale ? a.in_scale[(long)b * a.scale_stride + c] : 1.f;
   int cs = c, seg = 0;
@@ -363,25 +399,64 @@ __global__ void __launch_bounds__(256) prologue_bwd_kernel(const PrologueBwdArgs
   if (dxs) dxs += ((long)b * segc + cs) * a.plane;
   const float* gp = a.gp + ((long)b * a.Cin + c) * a.plane;
   const float* msk = a.in_mask ? a.in_mask + ((long)b * a.Cin + c) * a.plane : nullptr;
+  const bool drop = a.drop_inv > 0.f;
+  const uint64_t ebase = ((uint64_t)b * a.Cin + c) * (uint64_t)a.plane;
+  // this slice's element range (multiples of 4 when vectorised)
+  const bool vec = (a.plane & 3) == 0 && tmdiff_aligned16_dev(xs) && tmdiff_aligned16_dev(gp) &&
+                   (!dxs || tmdiff_aligned16_dev(dxs)) && (!msk || tmdiff_aligned16_dev(msk));
+  const long unit = vec ? 4 : 1;
+  const long units = a.plane / unit;
+  const long per = (units + a.slices - 1) / a.slices;
+  const long lo = sl * per * unit, hi = min((sl + 1) * per, units) * unit;
   float s_sh = 0.f, s_sc = 0.f;
-  for (long i = threadIdx.x; i < a.plane; i += 256) {
-    const float t = xs[i] + sh;
+  auto one = [&](float x, float g, float m, long i, float& out) {
+    const float t = x + sh;
     const float act = a.in_act ? tmdiff::silu_f(t) : t;
     const float dact = a.in_act ? silu_grad(t) : 1.f;
-    const float gm = msk ? gp[i] * msk[i] : gp[i];
+    float gm = msk ? g * m : g;
+    if (drop) gm *= tmdiff::drop_keep(a.drop_seed, ebase + (uint64_t)i, a.drop_thresh, a.drop_inv);
     s_sc += gm * act;
     const float dt = gm * sc * dact;
     s_sh += dt;
-    if (dxs) dxs[i] = accum ? dxs[i] + dt : dt;
+    out = dt;
+  };
+  if (vec) {
+    for (long i = lo + threadIdx.x * 4L; i < hi; i += 1024) {
+      const float4 x4 = *reinterpret_cast<const float4*>(xs + i), g4 = *reinterpret_cast<const float4*>(gp + i);
+      float4 m4 = make_float4(1.f, 1.f, 1.f, 1.f), d4 = make_float4(0.f, 0.f, 0.f, 0.f), o4;
+      if (msk) m4 = *reinterpret_cast<const float4*>(msk + i);
+      if (dxs && accum) d4 = *reinterpret_cast<const float4*>(dxs + i);
+      one(x4.x, g4.x, m4.x, i, o4.x);
+      one(x4.y, g4.y, m4.y, i + 1, o4.y);
+      one(x4.z, g4.z, m4.z, i + 2, o4.z);
+      one(x4.w, g4.w, m4.w, i + 3, o4.w);
+      if (dxs) *reinterpret_cast<float4*>(dxs + i) = make_float4(d4.x + o4.x, d4.y + o4.y, d4.z + o4.z, d4.w + o4.w);
+    }
+  } else {
+    for (long i = lo + threadIdx.x; i < hi; i += 256) {
+      float o;
+      one(xs[i], gp[i], msk ? msk[i] : 1.f, i, o);
+      if (dxs) dxs[i] = accum ? dxs[i] + o : o;
+    }
   }
+  const long oidx = ((long)b * a.Cin + c) * a.slices + sl;
   if (a.d_shift) {
     const float v = block_sum_256(s_sh, red);
-    if (threadIdx.x == 0) a.d_shift[(long)b * a.Cin + c] = v;
+    if (threadIdx.x == 0) a.d_shift[oidx] = v;
   }
   if (a.d_scale) {
     const float v = block_sum_256(s_sc, red);
-    if (threadIdx.x == 0) a.d_scale[(long)b * a.Cin + c] = v;
+    if (threadIdx.x == 0) a.d_scale[oidx] = v;
   }
+}
+
+// out[r] = sum_k in[r, k] (k ascending: deterministic); finishes the sliced prologue backward
+__global__ void __launch_bounds__(256) rowsum_kernel(const float* __restrict__ in, float* __restrict__ out, long rows, int k) {
+  const long r = blockIdx.x * 256L + threadIdx.x;
+  if (r >= rows) return;
+  float s = 0.f;
+  for (int j = 0; j < k; ++j) s += in[r * k + j];
+  out[r] = s;
 }
 
 // stem backward: one workgroup per (co, b): partial sums over the sample's positions
@@ -535,13 +610,24 @@ inline WgradPlan plan_wgrad(const tmdiff_conv3d_desc* d) {
   const int cout_g = d->Cout / d->groups, cin_g = d->Cin / d->groups;
   p.tiles_co = (cout_g + 31) / 32; p.tiles_ci = (cin_g + 31) / 32;
   const long tiles = (long)d->groups * p.tiles_co * p.tiles_ci;
-  long splits = (512 + tiles - 1) / tiles;  // two resident workgroups per CU
-  if (splits > p.total_boxes) splits = p.total_boxes;
-  if (splits < 1) splits = 1;
-  p.boxes_per_split = (int)((p.total_boxes + splits - 1) / splits);
+  // One workgroup is resident per CU (148 KB of LDS), so the launch runs in rounds of 256 workgroups.  Choose the number
+  // of K-splits that minimises  rounds x (boxes per workgroup + ~half a box of prologue / partial-sum stores);
+  // ties go to the smaller split count (less to reduce).  E.g. 64 tiles x 32 boxes: 4 splits = one round of 8 boxes,
+  // where the old "512 workgroups" rule gave 576 workgroups = three rounds of 4.
+  long best_s = 1;
+  double best_cost = 1e30;
+  const long smax = p.total_boxes < 512 ? p.total_boxes : 512;
+  for (long s = 1; s <= smax; ++s) {
+    const long bps = (p.total_boxes + s - 1) / s;
+    const long s_eff = (p.total_boxes + bps - 1) / bps;
+    const long rounds = (tiles * s_eff + 255) / 256;
+    const double cost = (double)rounds * ((double)bps + 0.5);
+    if (cost < best_cost - 1e-9) { best_cost = cost; best_s = s_eff; }
+  }
+  p.boxes_per_split = (int)((p.total_boxes + best_s - 1) / best_s);
   p.splits = (int)((p.total_boxes + p.boxes_per_split - 1) / p.boxes_per_split);
   p.slots = d->ksize == 3 ? p.splits : p.splits * 4;
-  p.needs_xp = d->nseg > 1 || d->in_shift || d->in_scale || d->in_mask || d->in_act;
+  p.needs_xp = d->nseg > 1 || d->in_shift || d->in_scale || d->in_mask || d->in_act || d->drop_p > 0.f;
   p.partial_floats = ((size_t)p.slots * d->Cout * cin_g * p.taps + 3) / 4 * 4;
   return p;
 }
@@ -555,6 +641,8 @@ int tmdiff::launch_prologue_apply(const tmdiff_conv3d_desc* d, float* xp, hipStr
   q.B = d->B; q.Cin = d->Cin; q.nseg = d->nseg;
   for (int i = 0; i < 3; ++i) { q.seg_c[i] = i < d->nseg ? d->seg_c[i] : 0; q.seg_x[i] = i < d->nseg ? d->seg_x[i] : nullptr; }
   q.in_shift = d->in_shift; q.in_scale = d->in_scale; q.in_mask = d->in_mask; q.in_act = d->in_act;
+  q.drop_seed = d->drop_seed; q.drop_thresh = drop_threshold(d->drop_p);
+  q.drop_inv = d->drop_p > 0.f ? 1.0f / (1.0f - d->drop_p) : 0.f;
   q.shift_stride = d->in_shift_stride > 0 ? d->in_shift_stride : (d->in_shift_stride < 0 ? 0 : d->Cin);
   q.scale_stride = d->in_scale_stride > 0 ? d->in_scale_stride : (d->in_scale_stride < 0 ? 0 : d->Cin);
   q.xp = xp;
@@ -588,6 +676,7 @@ extern "C" int tmdiff_conv3d_wgrad(const tmdiff_conv3d_desc* d, const float* g, 
   }
   TMDIFF_REQUIRE(csum == d->Cin, "conv3d_wgrad: segments hold %d channels, Cin=%d", csum, d->Cin);
   TMDIFF_REQUIRE(workspace != nullptr, "conv3d_wgrad: NULL workspace");
+  TMDIFF_REQUIRE(!(d->in_mask && d->drop_p > 0.f), "conv3d_wgrad: give either a mask tensor or drop_p, not both");
   const WgradPlan p = plan_wgrad(d);
   TMDIFF_REQUIRE(p.total_boxes < (1L << 31) && (long)d->N * d->H * d->W * 32 < (1L << 31),
                  "conv3d_wgrad: tensor too large for 32-bit box / offset arithmetic");
@@ -632,12 +721,30 @@ extern "C" int tmdiff_channel_sum(const float* x, float* out, int32_t B, int32_t
   return check_launch("channel_sum");
 }
 
-extern "C" int tmdiff_conv3d_prologue_bwd(const tmdiff_conv3d_desc* d, const float* gp, float* const dx_seg[3],
-                                          const int32_t accumulate[3], float* d_shift, float* d_scale,
-                                          tmdiff_stream_t stream) {
+namespace {
+// workgroups per (b, c) plane of the prologue backward: enough to fill the chip, at least 2048 elements each
+int prologue_bwd_slices(const tmdiff_conv3d_desc* d) {
+  const long planes = (long)d->B * d->Cin, plane = (long)d->N * d->H * d->W;
+  long s = (1024 + planes - 1) / planes;
+  if (s > plane / 2048) s = plane / 2048;
+  if (s > 64) s = 64;
+  return s < 1 ? 1 : (int)s;
+}
+}  // namespace
+
+extern "C" size_t tmdiff_conv3d_prologue_bwd_workspace_bytes(const tmdiff_conv3d_desc* d) {
+  if (!d || d->B <= 0 || d->Cin <= 0) return 0;
+  const int s = prologue_bwd_slices(d);
+  return s > 1 ? (size_t)2 * d->B * d->Cin * s * sizeof(float) : 0;
+}
+
+extern "C" int tmdiff_conv3d_prologue_bwd_ws(const tmdiff_conv3d_desc* d, const float* gp, float* const dx_seg[3],
+                                             const int32_t accumulate[3], float* d_shift, float* d_scale, void* workspace,
+                                             tmdiff_stream_t stream) {
   using namespace tmdiff;
   TMDIFF_REQUIRE(d && gp && dx_seg && accumulate, "prologue_bwd: NULL pointer");
   TMDIFF_REQUIRE(d->B > 0 && d->Cin > 0 && d->B <= 65535 && d->nseg >= 1 && d->nseg <= 3, "prologue_bwd: bad extents");
+  TMDIFF_REQUIRE(!(d->in_mask && d->drop_p > 0.f), "prologue_bwd: give either a mask tensor or drop_p, not both");
   PrologueBwdArgs a;
   a.B = d->B; a.Cin = d->Cin; a.nseg = d->nseg;
   int csum = 0;
@@ -655,10 +762,30 @@ extern "C" int tmdiff_conv3d_prologue_bwd(const tmdiff_conv3d_desc* d, const flo
   a.in_shift = d->in_shift; a.in_scale = d->in_scale; a.in_mask = d->in_mask; a.in_act = d->in_act;
   a.shift_stride = d->in_shift_stride > 0 ? d->in_shift_stride : (d->in_shift_stride < 0 ? 0 : d->Cin);
   a.scale_stride = d->in_scale_stride > 0 ? d->in_scale_stride : (d->in_scale_stride < 0 ? 0 : d->Cin);
+  a.drop_seed = d->drop_seed; a.drop_thresh = drop_threshold(d->drop_p);
+  a.drop_inv = d->drop_p > 0.f ? 1.0f / (1.0f - d->drop_p) : 0.f;
   a.gp = gp; a.d_shift = d_shift; a.d_scale = d_scale;
   a.plane = (long)d->N * d->H * d->W;
-  prologue_bwd_kernel<<<dim3(d->Cin, d->B), 256, 0, as_stream(stream)>>>(a);
-  return check_launch("conv3d_prologue_bwd");
+  a.slices = workspace ? prologue_bwd_slices(d) : 1;
+  hipStream_t st = as_stream(stream);
+  const long planes = (long)d->B * d->Cin;
+  if (a.slices > 1) {   // per-slice partial sums go to the workspace, rowsum_kernel finishes them
+    float* w = static_cast<float*>(workspace);
+    if (d_shift) a.d_shift = w;
+    if (d_scale) a.d_scale = w + planes * a.slices;
+  }
+  prologue_bwd_kernel<<<dim3(d->Cin, d->B, a.slices), 256, 0, st>>>(a);
+  int rc = check_launch("conv3d_prologue_bwd");
+  if (rc || a.slices == 1) return rc;
+  if (d_shift) rowsum_kernel<<<(unsigned)((planes + 255) / 256), 256, 0, st>>>(a.d_shift, d_shift, planes, a.slices);
+  if (d_scale) rowsum_kernel<<<(unsigned)((planes + 255) / 256), 256, 0, st>>>(a.d_scale, d_scale, planes, a.slices);
+  return check_launch("conv3d_prologue_bwd(rowsum)");
+}
+
+extern "C" int tmdiff_conv3d_prologue_bwd(const tmdiff_conv3d_desc* d, const float* gp, float* const dx_seg[3],
+                                          const int32_t accumulate[3], float* d_shift, float* d_scale,
+                                          tmdiff_stream_t stream) {
+  return tmdiff_conv3d_prologue_bwd_ws(d, gp, dx_seg, accumulate, d_shift, d_scale, nullptr, stream);
 }
 
 extern "C" int tmdiff_stem_bwd(const float* xin, const float* pan, const float* ms, const float* w, const float* bias,

@@ -163,7 +163,7 @@ int launch(K1Args& a, int in_act, hipStream_t st) {
 // 1x1x1 forward through the bandwidth kernel.  Returns TMDIFF_E_UNSUPPORTED (without touching the error string)
 // for shapes it does not take; tmdiff_conv3d_fwd then uses the generic kernel.  `d` has been validated by the caller.
 int tmdiff::conv1_fp32_try(const tmdiff_conv3d_desc* d, hipStream_t st) {
-  if (d->ksize != 1 || d->in_mask || d->y2 || !d->y) return TMDIFF_E_UNSUPPORTED;
+  if (d->ksize != 1 || d->in_mask || d->drop_p > 0.f || d->y2 || !d->y) return TMDIFF_E_UNSUPPORTED;
   const int cin_g = d->Cin / d->groups, cout_g = d->Cout / d->groups;
   if (cin_g % (2 * G) || cout_g % 32) return TMDIFF_E_UNSUPPORTED;
   for (int i = 0; i < d->nseg; ++i)

@@ -67,6 +67,11 @@ struct ConvArgs {
   int tiles_n, tiles_h, tiles_w, tiles_co;  // tiles_co per group
   int w_vec4;                               // cout_g % 4 == 0 -> 16-byte weight loads
   unsigned total_blocks;
+  uint64_t drop_seed;                       // in-kernel dropout (drop_inv > 0; MASK instantiations): common.h drop_keep
+  uint32_t drop_thresh;
+  float drop_inv;
+  int ksplit, split_ch;                     // split-K: ksplit ranges of split_ch input channels (1, cin_g = no split)
+  float* part;                              // split-K partial outputs [ksplit][B][Cout][plane] (NULL = no split)
 };
 
 // Tile geometry.  A workgroup = 4 waves; wave w owns NS position sub-tiles (32 positions each) x MSUB
@@ -122,8 +127,10 @@ __global__ void __launch_bounds__(256, 2) conv3d_mfma_kernel(const ConvArgs a) {
   const int tw_i = __builtin_amdgcn_readfirstlane(id % a.tiles_w); id /= a.tiles_w;
   const int th_i = __builtin_amdgcn_readfirstlane(id % a.tiles_h); id /= a.tiles_h;
   const int tn_i = __builtin_amdgcn_readfirstlane(id % a.tiles_n); id /= a.tiles_n;
-  const int g = __builtin_amdgcn_readfirstlane(id % a.groups);
-  const int b = __builtin_amdgcn_readfirstlane(id / a.groups);
+  const int g = __builtin_amdgcn_readfirstlane(id % a.groups); id /= a.groups;
+  const int b = __builtin_amdgcn_readfirstlane(id % a.B);
+  const int split = __builtin_amdgcn_readfirstlane(id / a.B);   // split-K range of this workgroup (outermost index)
+  const int c_begin = split * a.split_ch, c_end = c_begin + a.split_ch;
   const int n0 = tn_i * TN, h0 = th_i * TH, w0 = tw_i * TW;
   const int co0 = co_tile * CO;  // within group
   const long plane = (long)a.N * a.H * a.W;
@@ -271,8 +278,11 @@ __global__ void __launch_bounds__(256, 2) conv3d_mfma_kernel(const ConvArgs a) {
         float t = xr[ci][i] + sh;
         const float ta = tmdiff::silu_f(t);
         t = (a.in_act ? ta : t) * sc;
-        if constexpr (MASK)  // dropout mask (training only): read here, not prefetched
-          if (cval[ci]) t *= a.in_mask[((long)b * a.Cin + g * a.cin_g + cn + ci) * plane + goff[i]];
+        if constexpr (MASK)  // dropout (training only): a mask tensor read here (not prefetched), or the counter-based hash
+          if (cval[ci]) {
+            const long ei = ((long)b * a.Cin + g * a.cin_g + cn + ci) * plane + goff[i];
+            t *= a.in_mask ? a.in_mask[ei] : tmdiff::drop_keep(a.drop_seed, (uint64_t)ei, a.drop_thresh, a.drop_inv);
+          }
         xr[ci][i] = t;
       } else {
         // halo / out-of-range elements are exactly zero: the conv pads the ACTIVATED tensor.  Lanes past the end
@@ -288,14 +298,14 @@ __global__ void __launch_bounds__(256, 2) conv3d_mfma_kernel(const ConvArgs a) {
   };
 
   // prologue: chunk 0 -> stage 0
-  static_for<0, NL>([&](auto qc) __attribute__((always_inline)) { load_item(qc, 0); });
-  static_for<0, NP>([&](auto pcc) __attribute__((always_inline)) { stage_item(pcc, lds, 0); });
+  static_for<0, NL>([&](auto qc) __attribute__((always_inline)) { load_item(qc, c_begin); });
+  static_for<0, NP>([&](auto pcc) __attribute__((always_inline)) { stage_item(pcc, lds, c_begin); });
   __syncthreads();
 
   for (int it = 0;; ++it) {
-    const int cn = (it + 1) * KC;  // first channel of the chunk brought in during this iteration
-    const bool more = cn < a.cin_g;
-    const int cn_ld = more ? cn : 0;  // last chunk: re-load chunk 0 (valid addresses, result unused) -> no branches
+    const int cn = c_begin + (it + 1) * KC;  // first channel of the chunk brought in during this iteration
+    const bool more = cn < c_end;
+    const int cn_ld = more ? cn : c_begin;  // last chunk: re-load the first one (valid addresses, result unused) -> no branches
     const float* st = lds + (it & 1) * G::STAGE;
     float* st_next = lds + ((it + 1) & 1) * G::STAGE;
 
@@ -347,6 +357,23 @@ __global__ void __launch_bounds__(256, 2) conv3d_mfma_kernel(const ConvArgs a) {
     });
     if (!more) break;
     __syncthreads();
+  }
+
+  if (a.part) {  // split-K: raw partial sums; splitk_reduce_kernel adds them up and applies the epilogue
+#pragma unroll
+    for (int m = 0; m < MSUB; ++m)
+#pragma unroll
+      for (int s = 0; s < NS; ++s) {
+        const int p = (wv * NS + s) * 32 + l31;
+        const int n = n0 + p / (TW * TH), h = h0 + (p / TW) % TH, w = w0 + p % TW;
+        const bool pok = n < a.N && h < a.H && w < a.W;
+        const long sp = pok ? ((long)n * a.H + h) * a.W + w : 0;
+        float* dst = a.part + (((long)split * a.B + b) * a.Cout + g * a.cout_g + co0 + m * 32 + 4 * khalf) * plane + sp;
+#pragma unroll
+        for (int r = 0; r < 16; ++r)
+          if (pok) dst[((r & 3) + 8 * (r >> 2)) * plane] = acc[s][m][r];
+      }
+    return;
   }
 
   // ---- epilogue: bias, residual, scale; D layout: col = lane&31 (position), row = channel --------
@@ -434,6 +461,65 @@ __global__ void __launch_bounds__(256) pack_weights_kernel(const float* __restri
   }
 }
 
+// ---- split-K reduction: y = (sum_s part[s] + bias_scale*bias + residual) * out_scale, optional y2; V floats per thread ----
+template <int V>
+__global__ void __launch_bounds__(256) splitk_reduce_kernel(const tmdiff::SplitKReduceArgs r) {
+  const long per_row = (r.plane + V - 1) / V;
+  const long i = blockIdx.x * 256L + threadIdx.x;
+  const long row = i / per_row;                     // b * Cout + co
+  if (row >= (long)r.B * r.Cout) return;
+  const long p = (i % per_row) * V;
+  const int co = (int)(row % r.Cout), b = (int)(row / r.Cout);
+  const long off = row * r.plane + p;
+  const long sstride = (long)r.B * r.Cout * r.plane;
+  float v[V];
+  if constexpr (V == 4) {
+    const float4 t = *reinterpret_cast<const float4*>(r.part + off);
+    v[0] = t.x, v[1] = t.y, v[2] = t.z, v[3] = t.w;
+    for (int s = 1; s < r.ksplit; ++s) {             // fixed order: deterministic
+      const float4 u = *reinterpret_cast<const float4*>(r.part + s * sstride + off);
+      v[0] += u.x, v[1] += u.y, v[2] += u.z, v[3] += u.w;
+    }
+  } else {
+    v[0] = r.part[off];
+    for (int s = 1; s < r.ksplit; ++s) v[0] += r.part[s * sstride + off];
+  }
+  const float bias = r.bias ? r.bias[co] * r.bias_scale : 0.f;
+  float res[V];
+#pragma unroll
+  for (int k = 0; k < V; ++k) res[k] = 0.f;
+  if (r.residual) {
+    if constexpr (V == 4) {
+      const float4 t = *reinterpret_cast<const float4*>(r.residual + off);
+      res[0] = t.x, res[1] = t.y, res[2] = t.z, res[3] = t.w;
+    } else {
+      res[0] = r.residual[off];
+    }
+  }
+#pragma unroll
+  for (int k = 0; k < V; ++k) v[k] = (v[k] + bias + res[k]) * r.out_scale;   // same association as the in-kernel epilogue
+  if (r.y) {
+    if constexpr (V == 4)
+      *reinterpret_cast<float4*>(r.y + off) = make_float4(v[0], v[1], v[2], v[3]);
+    else
+      r.y[off] = v[0];
+  }
+  if (r.y2) {
+    const float sh = r.y2_shift ? r.y2_shift[(long)b * r.y2_shift_stride + co] : 0.f;
+    const float sc = r.y2_scale ? r.y2_scale[(long)b * r.y2_scale_stride + co] : 1.f;
+#pragma unroll
+    for (int k = 0; k < V; ++k) {
+      float t = v[k] + sh;
+      const float ta = tmdiff::silu_f(t);
+      v[k] = (r.y2_act ? ta : t) * sc;
+    }
+    if constexpr (V == 4)
+      *reinterpret_cast<float4*>(r.y2 + off) = make_float4(v[0], v[1], v[2], v[3]);
+    else
+      r.y2[off] = v[0];
+  }
+}
+
 template <int KS, int NS, int MSUB, int KC, int TN, int TH, int TW>
 int launch(ConvArgs& a, hipStream_t st) {
   constexpr int CO = 32 * MSUB;
@@ -441,13 +527,14 @@ int launch(ConvArgs& a, hipStream_t st) {
   a.tiles_h = (a.H + TH - 1) / TH;
   a.tiles_w = (a.W + TW - 1) / TW;
   a.tiles_co = (a.cout_g + CO - 1) / CO;
-  const long blocks = (long)a.B * a.groups * a.tiles_n * a.tiles_h * a.tiles_w * a.tiles_co;
+  const long blocks = (long)a.ksplit * a.B * a.groups * a.tiles_n * a.tiles_h * a.tiles_w * a.tiles_co;
   if (blocks <= 0 || blocks > 0x7fffffffL) return tmdiff::fail(TMDIFF_E_INVALID, "conv3d: grid of %ld blocks", blocks);
   a.total_blocks = (unsigned)blocks;
   const bool fast = a.cin_g % KC == 0 && a.cout_g % CO == 0 && a.w_vec4;
-  if (a.in_mask && fast)  // training (dropout) path
+  const bool masked = a.in_mask || a.drop_inv > 0.f;
+  if (masked && fast)  // training (dropout) path
     conv3d_mfma_kernel<KS, NS, MSUB, KC, TN, TH, TW, true, true><<<(unsigned)blocks, 256, 0, st>>>(a);
-  else if (a.in_mask)
+  else if (masked)
     conv3d_mfma_kernel<KS, NS, MSUB, KC, TN, TH, TW, false, true><<<(unsigned)blocks, 256, 0, st>>>(a);
   else if (fast)
     conv3d_mfma_kernel<KS, NS, MSUB, KC, TN, TH, TW, true, false><<<(unsigned)blocks, 256, 0, st>>>(a);
@@ -457,6 +544,75 @@ int launch(ConvArgs& a, hipStream_t st) {
 }
 
 }  // namespace
+
+namespace tmdiff {
+
+int launch_splitk_reduce(const SplitKReduceArgs& r, hipStream_t st) {
+  const bool vec = r.plane % 4 == 0 && aligned16(r.part) && aligned16(r.y) && aligned16(r.y2) && aligned16(r.residual);
+  const long per_row = vec ? r.plane / 4 : r.plane;
+  const long blocks = ((long)r.B * r.Cout * per_row + 255) / 256;
+  if (vec)
+    splitk_reduce_kernel<4><<<(unsigned)blocks, 256, 0, st>>>(r);
+  else
+    splitk_reduce_kernel<1><<<(unsigned)blocks, 256, 0, st>>>(r);
+  return check_launch("conv3d split-K reduce");
+}
+
+// Split target: once a launch has fewer workgroups than this, its input channels are divided until it has at least that
+// many (the chip holds 256 CUs x 2 workgroups of these kernels).  TMDIFF_SPLITK=<n> overrides (0 = never split).
+static long splitk_target() {
+  static const long t = [] {
+    const char* e = getenv("TMDIFF_SPLITK");
+    return e ? atol(e) : 384L;
+  }();
+  return t;
+}
+
+Conv3Plan plan_conv3(const tmdiff_conv3d_desc* d) {
+  Conv3Plan p{3, 0, 1};
+  const int cin_g = d->Cin / d->groups, cout_g = d->Cout / d->groups;
+  const long boxes48 = (long)d->B * d->groups * ((d->N + 3) / 4) * ((d->H + 7) / 8) * ((d->W + 7) / 8);
+  const bool c64 = cout_g % 64 == 0;
+  const long wg256 = boxes48 * ((cout_g + 63) / 64);
+  // Layers whose 256-position grid would leave CUs idle or badly quantised (the 8x8x8 level: 128-384 workgroups) use
+  // 128-position tiles; 32-channel tiles take 512 positions when that still gives every CU a workgroup.
+  if (c64 && wg256 < 2 * 256 && d->N > 2) {
+    p.tile = 0;
+    p.blocks = (long)d->B * d->groups * ((d->N + 1) / 2) * ((d->H + 7) / 8) * ((d->W + 7) / 8) * (cout_g / 64);
+  } else if (c64) {
+    p.tile = 1;
+    p.blocks = wg256;
+  } else {
+    const long wg512 = (long)d->B * d->groups * ((d->N + 3) / 4) * ((d->H + 7) / 8) * ((d->W + 15) / 16) * ((cout_g + 31) / 32);
+    if (d->W >= 16 && wg512 >= 256) {
+      p.tile = 2;
+      p.blocks = wg512;
+    } else {
+      p.tile = 3;
+      p.blocks = boxes48 * ((cout_g + 31) / 32);
+    }
+  }
+  // split-K: only exact shapes (whole chunks, whole channel tiles), only when the caller lent a workspace
+  const long target = splitk_target();
+  if (d->ksize != 3 || target <= 0 || p.blocks >= target || cin_g % 4 || cout_g % 32) return p;
+  const int nchunks = cin_g / 4;
+  int best = 1;
+  for (int s = 2; s <= nchunks / 2; ++s) {            // at least two chunks per range
+    if (nchunks % s) continue;
+    best = s;
+    if (p.blocks * s >= target) break;
+  }
+  p.ksplit = best;
+  return p;
+}
+
+}  // namespace tmdiff
+
+extern "C" size_t tmdiff_conv3d_fwd_splitk_workspace_bytes(const tmdiff_conv3d_desc* d) {
+  if (!d || d->ksize != 3 || d->B <= 0 || d->groups <= 0 || d->Cin % d->groups || d->Cout % d->groups) return 0;
+  const tmdiff::Conv3Plan p = tmdiff::plan_conv3(d);
+  return p.ksplit > 1 ? (size_t)p.ksplit * d->B * d->Cout * d->N * d->H * d->W * sizeof(float) : 0;
+}
 
 extern "C" int tmdiff_conv3d_pack_weights(const float* w, float* packed, int32_t Cout, int32_t Cin, int32_t ksize,
                                           int32_t groups, int32_t mode, tmdiff_stream_t stream) {
@@ -515,6 +671,10 @@ extern "C" int tmdiff_conv3d_fwd(const tmdiff_conv3d_desc* d, tmdiff_stream_t st
   }
   a.wp = d->w_packed; a.bias = d->bias; a.bias_scale = d->bias_scale;
   a.in_shift = d->in_shift; a.in_scale = d->in_scale; a.in_mask = d->in_mask; a.in_act = d->in_act;
+  TMDIFF_REQUIRE(!(d->in_mask && d->drop_p > 0.f), "conv3d_fwd: give either a mask tensor or drop_p, not both");
+  TMDIFF_REQUIRE(d->drop_p >= 0.f && d->drop_p < 1.f, "conv3d_fwd: drop_p=%g", (double)d->drop_p);
+  a.drop_seed = d->drop_seed; a.drop_thresh = drop_threshold(d->drop_p);
+  a.drop_inv = d->drop_p > 0.f ? 1.0f / (1.0f - d->drop_p) : 0.f;
   a.shift_stride = d->in_shift_stride > 0 ? d->in_shift_stride : (d->in_shift_stride < 0 ? 0 : d->Cin);
   a.scale_stride = d->in_scale_stride > 0 ? d->in_scale_stride : (d->in_scale_stride < 0 ? 0 : d->Cin);
   a.residual = d->residual; a.out_scale = d->out_scale; a.y = d->y;
@@ -524,21 +684,26 @@ extern "C" int tmdiff_conv3d_fwd(const tmdiff_conv3d_desc* d, tmdiff_stream_t st
   a.w_vec4 = (a.cout_g % 4 == 0) && aligned16(d->w_packed);
   hipStream_t st = as_stream(stream);
 
-  // Tile choice.  <NS, MSUB>: 2x2 = 256 positions x 64 channels when the channel count is a multiple of 64
-  // (the packed rows are then sub-tile interleaved, see packed_col); otherwise 32-channel tiles, 512 positions
-  // (4x1) on planes at least 16 wide, else 256 positions (2x1).  Layers whose 256-position grid would leave CUs
-  // idle or badly quantised (the 8x8x8 level: 128-384 workgroups) use 128-position tiles (1x2) instead.
-  const bool c64 = a.cout_g % 64 == 0;
-  const long wg256 = (long)d->B * d->groups * ((d->N + 3) / 4) * ((d->H + 7) / 8) * ((d->W + 7) / 8) * ((a.cout_g + 63) / 64);
-  const bool small_grid = c64 && wg256 < 2 * 256 && d->N > 2;
-  if (d->ksize == 3) {
-    if (small_grid) return launch<3, 1, 2, 4, 2, 8, 8>(a, st);
-    if (c64) return launch<3, 2, 2, 4, 4, 8, 8>(a, st);
-    // 32-channel tiles: 512 positions when that still gives every CU a workgroup, else 256 (small batches)
-    const long wg512 = (long)d->B * d->groups * ((d->N + 3) / 4) * ((d->H + 7) / 8) * ((d->W + 15) / 16) * ((a.cout_g + 31) / 32);
-    const bool wide = d->W >= 16 && wg512 >= 256;
-    return wide ? launch<3, 4, 1, 4, 4, 8, 16>(a, st) : launch<3, 2, 1, 4, 4, 8, 8>(a, st);
+  a.ksplit = 1; a.split_ch = a.cin_g; a.part = nullptr;
+  if (d->ksize == 3) {  // tile configuration and split-K factor: plan_conv3 (shared with the staged kernel)
+    Conv3Plan plan = plan_conv3(d);
+    const size_t need = (size_t)plan.ksplit * d->B * d->Cout * d->N * d->H * d->W * sizeof(float);
+    if (plan.ksplit > 1 && d->splitk_ws && (size_t)d->splitk_ws_bytes >= need && aligned16(d->splitk_ws)) {
+      a.ksplit = plan.ksplit; a.split_ch = a.cin_g / plan.ksplit; a.part = static_cast<float*>(d->splitk_ws);
+    }
+    int rc;
+    switch (plan.tile) {
+      case 0: rc = launch<3, 1, 2, 4, 2, 8, 8>(a, st); break;
+      case 1: rc = launch<3, 2, 2, 4, 4, 8, 8>(a, st); break;
+      case 2: rc = launch<3, 4, 1, 4, 4, 8, 16>(a, st); break;
+      default: rc = launch<3, 2, 1, 4, 4, 8, 8>(a, st); break;
+    }
+    if (rc || !a.part) return rc;
+    SplitKReduceArgs r{a.part, a.ksplit, d->B, d->Cout, (long)d->N * d->H * d->W, d->bias, d->bias_scale, d->residual,
+                       d->out_scale, d->y, d->y2, d->y2_shift, d->y2_scale, a.y2_shift_stride, a.y2_scale_stride, d->y2_act};
+    return launch_splitk_reduce(r, st);
   }
+  const bool c64 = a.cout_g % 64 == 0;
   if (c64) return launch<1, 2, 2, 8, 4, 8, 8>(a, st);
   return d->W >= 16 ? launch<1, 4, 1, 8, 4, 8, 16>(a, st) : launch<1, 2, 1, 8, 4, 8, 8>(a, st);
 }

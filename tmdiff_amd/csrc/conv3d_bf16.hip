@@ -753,7 +753,7 @@ extern "C" int tmdiff_conv3d_fwd_bf16(const tmdiff_conv3d_desc* d, void* workspa
                  "conv3d_fwd_bf16: Cin=%d Cout=%d groups=%d", d->Cin, d->Cout, d->groups);
   TMDIFF_REQUIRE(d->nseg >= 1 && d->nseg <= 3, "conv3d_fwd_bf16: nseg=%d", d->nseg);
   TMDIFF_REQUIRE(d->ksize == 1 || d->ksize == 3, "conv3d_fwd_bf16: ksize=%d (1 or 3)", d->ksize);
-  if (d->in_mask) return fail(TMDIFF_E_UNSUPPORTED, "conv3d_fwd_bf16: input masks (training) are fp32 only");
+  if (d->in_mask || d->drop_p > 0.f) return fail(TMDIFF_E_UNSUPPORTED, "conv3d_fwd_bf16: dropout (training) is fp32 only");
   const int cin_g = d->Cin / d->groups, cout_g = d->Cout / d->groups;
   if (cin_g % (d->ksize == 3 ? 8 : 16) || cout_g % 32)
     return fail(TMDIFF_E_UNSUPPORTED, "conv3d_fwd_bf16: Cin/g=%d (multiple of %d) Cout/g=%d (multiple of 32)", cin_g,

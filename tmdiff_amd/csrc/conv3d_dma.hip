@@ -45,6 +45,8 @@ struct DmaArgs {
   int y2_shift_stride, y2_scale_stride, y2_act;
   int tiles_n, tiles_h, tiles_w, tiles_co;
   unsigned total_blocks;
+  int ksplit, split_chunks;  // split-K: ksplit ranges of split_chunks chunks each (1, cin_g / KC = no split)
+  float* part;               // split-K partial outputs [ksplit][B][Cout][plane] (NULL = no split)
 };
 
 __device__ const float4 kZero4 = {0.f, 0.f, 0.f, 0.f};  // source of zero padding / filler lanes
@@ -89,7 +91,7 @@ __global__ void __launch_bounds__(256, 2) conv3d_dma_kernel(const DmaArgs a) {
   __shared__ __attribute__((aligned(16))) float st1[G::STAGE];
 
   const int tid = threadIdx.x;
-  const int lane = tid & 63, wv = tid >> 6;
+  const int lane = tid & 63, wv = __builtin_amdgcn_readfirstlane(tid >> 6);   // wave-uniform: DMA destinations stay scalar
   const int l31 = lane & 31, khalf = lane >> 5;
 
   unsigned id = xcd_remap(blockIdx.x, a.total_blocks);
@@ -97,12 +99,13 @@ __global__ void __launch_bounds__(256, 2) conv3d_dma_kernel(const DmaArgs a) {
   const int tw_i = __builtin_amdgcn_readfirstlane(id % a.tiles_w); id /= a.tiles_w;
   const int th_i = __builtin_amdgcn_readfirstlane(id % a.tiles_h); id /= a.tiles_h;
   const int tn_i = __builtin_amdgcn_readfirstlane(id % a.tiles_n); id /= a.tiles_n;
-  const int g = __builtin_amdgcn_readfirstlane(id % a.groups);
-  const int b = __builtin_amdgcn_readfirstlane(id / a.groups);
+  const int g = __builtin_amdgcn_readfirstlane(id % a.groups); id /= a.groups;
+  const int b = __builtin_amdgcn_readfirstlane(id % a.B);
+  const int split = __builtin_amdgcn_readfirstlane(id / a.B);   // split-K range of this workgroup (outermost index)
   const int n0 = tn_i * TN, h0 = th_i * TH, w0 = tw_i * TW;
   const int co0 = co_tile * CO;
   const long plane = (long)a.N * a.H * a.W;
-  const int nchunks = a.cin_g / KC;
+  const int nchunks = a.split_chunks;                           // chunks of this workgroup: [split * nchunks, +nchunks)
 
   // ---- DMA sources of this lane (the same for every chunk) -----------------------------------------------------
   // x piece q = wv + 4k covers stage floats q*64 + lane = element (channel kc, box position e) of [KC][TILE_ELEMS]
@@ -123,8 +126,9 @@ __global__ void __launch_bounds__(256, 2) conv3d_dma_kernel(const DmaArgs a) {
     const int u = (wv + 4 * k) * 64 + lane;
     wsrc[k] = u < G::W_UNITS ? (u / (CO / 4)) * a.cout_g + (u % (CO / 4)) * 4 : -1;
   }
-  const float* xg = a.xq + ((long)b * a.Cin + (long)g * a.cin_g) * plane;
-  const float* wg = a.wp + (long)g * a.cin_g * G::TAPS * a.cout_g + co0;
+  const long c_first = (long)split * nchunks * KC;              // first input channel (within the group) of the range
+  const float* xg = a.xq + ((long)b * a.Cin + (long)g * a.cin_g + c_first) * plane;
+  const float* wg = a.wp + ((long)g * a.cin_g + c_first) * G::TAPS * a.cout_g + co0;
   const float* zero = reinterpret_cast<const float*>(&kZero4);
 
   // piece i of this wave for chunk c: i < XK = input pieces (dwords), then the weight pieces (16 bytes)
@@ -231,6 +235,23 @@ __global__ void __launch_bounds__(256, 2) conv3d_dma_kernel(const DmaArgs a) {
     }
   }
 
+  if (a.part) {  // split-K: raw partial sums; splitk_reduce_kernel (conv3d.hip) adds them up and applies the epilogue
+#pragma unroll
+    for (int m = 0; m < MSUB; ++m)
+#pragma unroll
+      for (int s = 0; s < NS; ++s) {
+        const int p = (wv * NS + s) * 32 + l31;
+        const int n = n0 + p / (TW * TH), h = h0 + (p / TW) % TH, w = w0 + p % TW;
+        const bool pok = n < a.N && h < a.H && w < a.W;
+        const long sp = pok ? ((long)n * a.H + h) * a.W + w : 0;
+        float* dst = a.part + (((long)split * a.B + b) * a.Cout + g * a.cout_g + co0 + m * 32 + 4 * khalf) * plane + sp;
+#pragma unroll
+        for (int r = 0; r < 16; ++r)
+          if (pok) dst[((r & 3) + 8 * (r >> 2)) * plane] = acc[s][m][r];
+      }
+    return;
+  }
+
   // ---- epilogue: bias, residual, scale; D layout: col = lane&31 (position), row = channel ----------------------
 #pragma unroll
   for (int m = 0; m < MSUB; ++m) {
@@ -287,7 +308,7 @@ int launch(DmaArgs& a, hipStream_t st) {
   a.tiles_h = (a.H + TH - 1) / TH;
   a.tiles_w = (a.W + TW - 1) / TW;
   a.tiles_co = a.cout_g / CO;
-  const long blocks = (long)a.B * a.groups * a.tiles_n * a.tiles_h * a.tiles_w * a.tiles_co;
+  const long blocks = (long)a.ksplit * a.B * a.groups * a.tiles_n * a.tiles_h * a.tiles_w * a.tiles_co;
   if (blocks <= 0 || blocks > 0x7fffffffL) return tmdiff::fail(TMDIFF_E_INVALID, "conv3d_fwd_staged: grid of %ld blocks", blocks);
   a.total_blocks = (unsigned)blocks;
   conv3d_dma_kernel<KS, NS, MSUB, KC, TN, TH, TW><<<(unsigned)blocks, 256, 0, st>>>(a);
@@ -295,7 +316,7 @@ int launch(DmaArgs& a, hipStream_t st) {
 }
 
 bool needs_apply(const tmdiff_conv3d_desc* d) {
-  return d->nseg > 1 || d->in_shift || d->in_scale || d->in_mask || d->in_act;
+  return d->nseg > 1 || d->in_shift || d->in_scale || d->in_mask || d->in_act || d->drop_p > 0.f;
 }
 
 // shapes the staged kernel takes (every production layer); others stay on the fused kernel
@@ -330,6 +351,8 @@ extern "C" int tmdiff_conv3d_fwd_staged(const tmdiff_conv3d_desc* d, void* works
   TMDIFF_REQUIRE(csum == d->Cin, "conv3d_fwd_staged: segments hold %d channels, Cin=%d", csum, d->Cin);
   TMDIFF_REQUIRE(d->w_packed && (d->y || d->y2) && aligned16(d->w_packed), "conv3d_fwd_staged: NULL / unaligned weights or output");
   TMDIFF_REQUIRE(!d->y2 || !d->y2_bf16, "conv3d_fwd_staged: a bf16-packed second output needs tmdiff_conv3d_fwd_bf16");
+  TMDIFF_REQUIRE(!(d->in_mask && d->drop_p > 0.f) && d->drop_p >= 0.f && d->drop_p < 1.f,
+                 "conv3d_fwd_staged: give either a mask tensor or 0 <= drop_p < 1");
   TMDIFF_REQUIRE((long)d->N * d->H * d->W * 8 < (1L << 31), "conv3d_fwd_staged: plane too large");
   hipStream_t st = as_stream(stream);
 
@@ -351,14 +374,22 @@ extern "C" int tmdiff_conv3d_fwd_staged(const tmdiff_conv3d_desc* d, void* works
   a.y2_shift_stride = d->y2_shift_stride > 0 ? d->y2_shift_stride : (d->y2_shift_stride < 0 ? 0 : d->Cout);
   a.y2_scale_stride = d->y2_scale_stride > 0 ? d->y2_scale_stride : (d->y2_scale_stride < 0 ? 0 : d->Cout);
 
-  // tile choice: as tmdiff_conv3d_fwd
-  const bool c64 = a.cout_g % 64 == 0;
-  const long wg256 = (long)d->B * d->groups * ((d->N + 3) / 4) * ((d->H + 7) / 8) * ((d->W + 7) / 8) * ((a.cout_g + 63) / 64);
-  const bool small_grid = c64 && wg256 < 2 * 256 && d->N > 2;
-  if (small_grid) return launch<3, 1, 2, 4, 2, 8, 8>(a, st);
-  if (c64) return launch<3, 2, 2, 4, 4, 8, 8>(a, st);
-  // 32-channel tiles: 512 positions when that still gives every CU a workgroup, else 256 (small batches)
-  const long wg512 = (long)d->B * d->groups * ((d->N + 3) / 4) * ((d->H + 7) / 8) * ((d->W + 15) / 16) * ((a.cout_g + 31) / 32);
-  const bool wide = d->W >= 16 && wg512 >= 256;
-  return wide ? launch<3, 4, 1, 4, 4, 8, 16>(a, st) : launch<3, 2, 1, 4, 4, 8, 8>(a, st);
+  // tile configuration and split-K factor: plan_conv3 (conv3d.hip), the same rule as tmdiff_conv3d_fwd
+  Conv3Plan plan = plan_conv3(d);
+  a.ksplit = 1; a.split_chunks = a.cin_g / 4; a.part = nullptr;
+  const size_t need = (size_t)plan.ksplit * d->B * d->Cout * d->N * d->H * d->W * sizeof(float);
+  if (plan.ksplit > 1 && d->splitk_ws && (size_t)d->splitk_ws_bytes >= need && aligned16(d->splitk_ws)) {
+    a.ksplit = plan.ksplit; a.split_chunks = a.cin_g / 4 / plan.ksplit; a.part = static_cast<float*>(d->splitk_ws);
+  }
+  int rc;
+  switch (plan.tile) {
+    case 0: rc = launch<3, 1, 2, 4, 2, 8, 8>(a, st); break;
+    case 1: rc = launch<3, 2, 2, 4, 4, 8, 8>(a, st); break;
+    case 2: rc = launch<3, 4, 1, 4, 4, 8, 16>(a, st); break;
+    default: rc = launch<3, 2, 1, 4, 4, 8, 8>(a, st); break;
+  }
+  if (rc || !a.part) return rc;
+  SplitKReduceArgs r{a.part, a.ksplit, d->B, d->Cout, (long)d->N * d->H * d->W, d->bias, d->bias_scale, d->residual,
+                     d->out_scale, d->y, d->y2, d->y2_shift, d->y2_scale, a.y2_shift_stride, a.y2_scale_stride, d->y2_act};
+  return launch_splitk_reduce(r, st);
 }

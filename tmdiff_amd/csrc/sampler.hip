@@ -85,6 +85,31 @@ __global__ void __launch_bounds__(256) axpby_kernel(AxpbyArgs a, float* __restri
   }
 }
 
+// Multi-tensor out_t = ca * a_t + cb * b_t over a list of tensors in ONE launch (the EMA update of 272 parameter
+// tensors, utils/EmaUpdater.py:23-38; one launch per tensor cost the host 272 calls per step).  Block = one chunk of at
+// most MT_CHUNK elements of one tensor; chunk -> (tensor, offset) through two small device tables.
+constexpr int MT_CHUNK = 16384;
+__global__ void __launch_bounds__(256) multi_axpby_kernel(const tmdiff_mt_entry* __restrict__ tensors,
+                                                          const int32_t* __restrict__ chunk_tensor,
+                                                          const int32_t* __restrict__ chunk_index, float ca, float cb) {
+  const tmdiff_mt_entry e = tensors[chunk_tensor[blockIdx.x]];
+  const long lo = (long)chunk_index[blockIdx.x] * MT_CHUNK;
+  const long hi = min(lo + MT_CHUNK, (long)e.n);
+  const bool vec = ((reinterpret_cast<uintptr_t>(e.out) | reinterpret_cast<uintptr_t>(e.a) | reinterpret_cast<uintptr_t>(e.b)) & 15u) == 0;
+  if (vec) {
+    const long hi4 = lo + ((hi - lo) & ~3L);
+    for (long i = lo + threadIdx.x * 4L; i < hi4; i += 1024) {
+      const float4 x = *reinterpret_cast<const float4*>(e.a + i), y = *reinterpret_cast<const float4*>(e.b + i);
+      *reinterpret_cast<float4*>(e.out + i) =
+          make_float4(__fadd_rn(__fmul_rn(ca, x.x), __fmul_rn(cb, y.x)), __fadd_rn(__fmul_rn(ca, x.y), __fmul_rn(cb, y.y)),
+                      __fadd_rn(__fmul_rn(ca, x.z), __fmul_rn(cb, y.z)), __fadd_rn(__fmul_rn(ca, x.w), __fmul_rn(cb, y.w)));
+    }
+    for (long i = hi4 + threadIdx.x; i < hi; i += 256) e.out[i] = __fadd_rn(__fmul_rn(ca, e.a[i]), __fmul_rn(cb, e.b[i]));
+  } else {
+    for (long i = lo + threadIdx.x; i < hi; i += 256) e.out[i] = __fadd_rn(__fmul_rn(ca, e.a[i]), __fmul_rn(cb, e.b[i]));
+  }
+}
+
 template <int V>
 __global__ void __launch_bounds__(256) x0_kernel(const float* __restrict__ x, const float* __restrict__ m,
                                                  float* __restrict__ x0, long nvec, float alpha, float sigma,
@@ -343,6 +368,18 @@ extern "C" int tmdiff_axpby(const float* const in[4], const float coef[4], int32
   else
     axpby_kernel<1><<<grid_for(n), 256, 0, as_stream(stream)>>>(a, out, n);
   return check_launch("axpby");
+}
+
+extern "C" int32_t tmdiff_multi_axpby_chunk(void) { return MT_CHUNK; }
+
+extern "C" int tmdiff_multi_axpby(const tmdiff_mt_entry* tensors_dev, const int32_t* chunk_tensor_dev,
+                                  const int32_t* chunk_index_dev, int32_t n_chunks, float ca, float cb,
+                                  tmdiff_stream_t stream) {
+  using namespace tmdiff;
+  TMDIFF_REQUIRE(tensors_dev && chunk_tensor_dev && chunk_index_dev && n_chunks >= 0, "multi_axpby: bad arguments");
+  if (n_chunks == 0) return TMDIFF_OK;
+  multi_axpby_kernel<<<(unsigned)n_chunks, 256, 0, as_stream(stream)>>>(tensors_dev, chunk_tensor_dev, chunk_index_dev, ca, cb);
+  return check_launch("multi_axpby");
 }
 
 extern "C" int tmdiff_x0_from_model(const float* x, const float* model_out, float* x0, int64_t n, float alpha,

@@ -148,17 +148,22 @@ class EmaUpdater:
     def __init__(self, model, ema_model, decay=0.9999, start_iter=0):
         self.model, self.ema_model = model, ema_model
         self.decay, self.start_iter, self.iteration = decay, start_iter, start_iter
+        self._mt = None          # ops.MultiAxpby over all parameter pairs (built on the first update)
 
     @torch.no_grad()
     def update(self, iteration):
         self.iteration = iteration
-        pairs = zip(self.model.netG.denoise_fn.parameters(), self.ema_model.netG.denoise_fn.parameters())
+        pairs = list(zip(self.model.netG.denoise_fn.parameters(), self.ema_model.netG.denoise_fn.parameters()))
         if iteration > self.start_iter:
+            gpu = [(p, pe) for p, pe in pairs if p.is_cuda]
+            if gpu:       # ONE multi-tensor launch: p_ema = decay * p_ema + (1 - decay) * p for every tensor
+                from . import ops
+                triples = [(pe.data, pe.data, p.data) for p, pe in gpu]
+                if self._mt is None or self._mt.stale(triples):
+                    self._mt = ops.MultiAxpby(triples)
+                self._mt.run(self.decay, 1.0 - self.decay)
             for p, p_ema in pairs:
-                if p.is_cuda:
-                    from . import ops
-                    ops.axpby([p_ema.data, p.data], [self.decay, 1.0 - self.decay], out=p_ema.data)
-                else:
+                if not p.is_cuda:
                     p_ema.data.mul_(self.decay).add_(p.data, alpha=1.0 - self.decay)
         else:
             for p, p_ema in pairs:

@@ -13,7 +13,14 @@ from . import _lib
 from ._lib import Conv3dDesc, check, lib
 
 
+_raw_stream = getattr(torch._C, "_cuda_getCurrentRawStream", None)
+
+
 def stream_ptr():
+    """hipStream_t of torch's current stream on the current device (the raw getter: torch.cuda.current_stream() builds
+    a Stream object per call, ~15 us -- 4 ms per training step at ~300 kernel launches)."""
+    if _raw_stream is not None:
+        return _raw_stream(torch.cuda.current_device())
     return torch.cuda.current_stream().cuda_stream
 
 
@@ -60,13 +67,17 @@ def pack_conv_weight_bf16(w, groups=1):
 def make_conv_desc(segs, w_packed, cout, ksize, y, groups=1, bias=None, bias_scale=1.0, in_shift=None, in_scale=None,
                    shift_stride=0, scale_stride=0, in_act=False, in_mask=None, residual=None, out_scale=1.0,
                    y2=None, y2_shift=None, y2_scale=None, y2_shift_stride=0, y2_scale_stride=0, y2_act=False,
-                   x_bf16_shape=None):
+                   x_bf16_shape=None, drop=None):
     """Fill a tmdiff_conv3d_desc.  `segs` = list of 1..3 tensors [B, c_i, N, H, W] (concat-free input).
     in_shift / in_scale may be tensors or raw (ptr) ints into a projection bank.  y may be None when only the second
     output y2 = act2(y + y2_shift) * y2_scale (the consumer's prologue, same pointer conventions) is wanted.
     A y2 of dtype int16 is written as bf16 units [B, Cout/8, N*H*W, 8]; x_bf16_shape = (N, H, W) says that segs[0] is
-    such a tensor (bf16 entry point only)."""
+    such a tensor (bf16 entry point only).  drop = (seed, p): in-kernel dropout of the prologue output (no mask tensor)."""
     d = Conv3dDesc()
+    if drop is not None:
+        if in_mask is not None:
+            raise ValueError("conv3d: give either in_mask (a mask tensor) or drop=(seed, p)")
+        d.drop_seed, d.drop_p = int(drop[0]) & 0xFFFFFFFFFFFFFFFF, float(drop[1])
     if x_bf16_shape is not None:
         xp = segs[0]
         if len(segs) != 1 or xp.dtype != torch.int16 or xp.dim() != 4 or xp.shape[3] != 8 or not xp.is_contiguous():
@@ -148,8 +159,8 @@ _FP32_STAGED = os.environ.get("TMDIFF_FP32_STAGED", "auto")   # experiments: "0"
 _BF16_PACK = os.environ.get("TMDIFF_BF16_PACK", "auto")       # experiments: "0" = fused kernel, "1"/"auto" = packed input
 
 
-def _workspace(device, nbytes):
-    key = (device.index, stream_ptr())
+def _workspace(device, nbytes, tag="x"):
+    key = (device.index, stream_ptr(), tag)
     ws = _WS.get(key)
     if ws is None or ws.numel() < nbytes:
         ws = _WS[key] = torch.empty(nbytes, device=device, dtype=torch.uint8)
@@ -194,6 +205,10 @@ def conv3d(segs, w_packed, cout, ksize, out=None, math="fp32", pack_input=None, 
     elif math == "fp32":
         if not isinstance(w_packed, int) and w_packed.dtype != torch.float32:
             raise TypeError("conv3d(math='fp32') needs weights from pack_conv_weight")
+        if ksize == 3:      # lend the split-K workspace (small grids only: B = 1, the 8x8 / 16x16 levels at small batches)
+            nsk = lib.tmdiff_conv3d_fwd_splitk_workspace_bytes(C.byref(d))
+            if nsk:
+                d.splitk_ws, d.splitk_ws_bytes = _workspace(dev, nsk, "splitk").data_ptr(), nsk
         if staged is None:
             # measured (tools/bench_conv.py, B=32): the staged kernel itself is 3-6 % faster than the fused one, but its
             # prologue pass costs 8 B per input element -- a net win when the input needs no pass (one plain tensor:
@@ -202,8 +217,10 @@ def conv3d(segs, w_packed, cout, ksize, out=None, math="fp32", pack_input=None, 
             # bandwidth kernel behind tmdiff_conv3d_fwd.
             plain = len(segs) == 1 and not (kw.get("in_act") or kw.get("in_shift") is not None or
                                             kw.get("in_scale") is not None or kw.get("in_mask") is not None)
+            plain = plain and kw.get("drop") is None
             staged = {"0": False, "1": True}.get(_FP32_STAGED, ksize == 3 and (
-                plain or cout // d.groups >= 128 or d.Cin // d.groups >= 384 or kw.get("in_mask") is not None))
+                plain or cout // d.groups >= 128 or d.Cin // d.groups >= 384 or kw.get("in_mask") is not None
+                or kw.get("drop") is not None))
         if staged and lib.tmdiff_conv3d_fwd_staged_supported(C.byref(d)):
             nb = lib.tmdiff_conv3d_fwd_staged_workspace_bytes(C.byref(d))
             ws32 = _workspace(dev, nb).data_ptr() if nb else None
@@ -311,6 +328,40 @@ def axpby(tensors, coefs, out=None):
     return y
 
 
+class MultiAxpby:
+    """out_t = ca * a_t + cb * b_t over a fixed list of (out, a, b) tensor triples in ONE launch (tmdiff_multi_axpby).
+    The device tables are built once from the tensors' addresses; ``stale()`` says whether they moved."""
+
+    def __init__(self, triples):
+        triples = [(o, a, b) for o, a, b in triples if o.numel() > 0]
+        for o, a, b in triples:
+            for t in (o, a, b):
+                _chk(t, "multi_axpby tensor")
+            if not (o.numel() == a.numel() == b.numel()):
+                raise ValueError("multi_axpby: out / a / b sizes differ")
+        dev = triples[0][0].device
+        self.key = tuple(t.data_ptr() for tr in triples for t in tr)
+        chunk = lib.tmdiff_multi_axpby_chunk()
+        ent, ct, ci = [], [], []
+        for k, (o, a, b) in enumerate(triples):
+            ent += [o.data_ptr(), a.data_ptr(), b.data_ptr(), o.numel()]
+            nck = (o.numel() + chunk - 1) // chunk
+            ct += [k] * nck
+            ci += list(range(nck))
+        self.entries = torch.tensor(ent, dtype=torch.int64).to(dev)           # tmdiff_mt_entry[]: 3 pointers + int64
+        self.chunk_tensor = torch.tensor(ct, dtype=torch.int32).to(dev)
+        self.chunk_index = torch.tensor(ci, dtype=torch.int32).to(dev)
+        self.n_chunks = len(ct)
+        self._keep = triples
+
+    def stale(self, triples):
+        return self.key != tuple(t.data_ptr() for tr in triples for t in tr if tr[0].numel() > 0)
+
+    def run(self, ca, cb):
+        check(lib.tmdiff_multi_axpby(self.entries.data_ptr(), self.chunk_tensor.data_ptr(), self.chunk_index.data_ptr(),
+                                     self.n_chunks, float(ca), float(cb), stream_ptr()), "multi_axpby")
+
+
 def x0_from_model(x, model_out, alpha, sigma, model_is_x_start=True, out=None):
     y = out if out is not None else torch.empty_like(x)
     check(lib.tmdiff_x0_from_model(_chk(x, "x"), _chk(model_out, "model_out"), _chk(y, "x0"), x.numel(), alpha, sigma,
@@ -368,8 +419,10 @@ def conv3d_prologue_bwd(desc, gp, dx_segs, accumulate, want_shift, want_scale):
     d_scale = torch.empty(b, cin, device=gp.device, dtype=torch.float32) if want_scale else None
     dxp = (C.c_void_p * 3)(*[_chk(t, "dx") for t in dx_segs], *([None] * (3 - len(dx_segs))))
     acc = (C.c_int32 * 3)(*[1 if a else 0 for a in accumulate], *([0] * (3 - len(accumulate))))
-    check(lib.tmdiff_conv3d_prologue_bwd(C.byref(desc), _chk(gp, "gp"), dxp, acc, _chk(d_shift, "d_shift"),
-                                         _chk(d_scale, "d_scale"), stream_ptr()), "conv3d_prologue_bwd")
+    nws = lib.tmdiff_conv3d_prologue_bwd_workspace_bytes(C.byref(desc))
+    ws = _workspace(gp.device, nws, "prologue_bwd").data_ptr() if nws else None
+    check(lib.tmdiff_conv3d_prologue_bwd_ws(C.byref(desc), _chk(gp, "gp"), dxp, acc, _chk(d_shift, "d_shift"),
+                                            _chk(d_scale, "d_scale"), ws, stream_ptr()), "conv3d_prologue_bwd")
     return d_shift, d_scale
 
 
