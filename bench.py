@@ -50,7 +50,7 @@ def launch_ranks(args):
     """Parent of a launcher-less multi-GPU run: start one worker per GPU and wait.  Nothing here touches the GPU
     (torch.cuda.device_count() does not initialise HIP on this image; it is only read to fail early and loudly)."""
     n = args.gpus
-    if not args.rehearse:
+    if not args.rehearse and os.environ.get("TMDIFF_BENCH_BACKEND", "nccl") == "nccl":   # (gloo: ranks may share a GPU)
         import torch
         ndev = torch.cuda.device_count()
         if ndev < n:
@@ -260,7 +260,7 @@ def train_leg(dev, world, rank, dist, steps, warmup):
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         dt, alone, dt_noex = (float(v) for v in tt)
         out["seconds"] = dt
-        out["allreduce"] = {"buckets": len(red.buckets), "launched_from_backward_hooks": red.launched,
+        out["allreduce"] = {"buckets": len(red.buckets), "launched_from_backward_hooks": red.launched_last,
                             "payload_mb": round(nbytes / 1e6, 1), "standalone_ms": round(alone * 1e3, 3),
                             "bus_gb_s": round(2 * (world - 1) / world * nbytes / alone / 1e9, 1),
                             "step_ms_without_exchange": round(dt_noex / steps * 1e3, 3),

@@ -51,8 +51,10 @@ __device__ __forceinline__ float block_sum_256(float v, float* red) {
 // (odd row strides: conflict-free column reads) by global_load_lds -- no registers, no ds_write -- into one of two
 // stages while the MFMAs of the previous box run out of the other (a box is 64 K-steps x 7 taps = 448 MFMAs per
 // wave; one barrier per box; all LDS operand reads have compile-time offsets).
-// KS=3: wave w accumulates taps w, w+4, ... (7 accumulators, the g operand is shared by all of them); KS=1: the
-// four waves split the positions of the box and their partials are separate splits.
+// Eight waves (two per SIMD: while one waits on its operand reads or issues DMA pieces, the other's MFMAs keep the matrix
+// pipe busy -- with one wave per SIMD the pipe idled a quarter of the time).  KS=3: wave w accumulates taps w%4, w%4+4, ...
+// (7 accumulators, the g operand is shared by all of them) over band w/4 of the box (the box has two band planes);
+// KS=1: the eight waves split the positions of the box.  Each wave's partial is a separate slot of the reduction.
 // Partials go to workspace[split][g][tap][co][ci]; wgrad_reduce_kernel sums the splits into PyTorch layout.
 // ---------------------------------------------------------------------------------------------------
 struct WgradArgs {
@@ -136,8 +138,10 @@ __device__ __forceinline__ void dma_word(const float* src, float* dst) {
 #endif
 }
 
+constexpr int WG_WAVES = 8;
+
 template <int KS>
-__global__ void __launch_bounds__(256, 1) conv3d_wgrad_kernel(const WgradArgs a) {
+__global__ void __launch_bounds__(64 * WG_WAVES, 1) conv3d_wgrad_kernel(const WgradArgs a) {
   constexpr int TAPS = KS * KS * KS, HALO = KS / 2;
   constexpr int BN = 2, BH = 8, BW = 8, POSB = BN * BH * BW;            // 128 positions per box
   constexpr int HN = BN + 2 * HALO, HH = BH + 2 * HALO, HW = BW + 2 * HALO;
@@ -146,7 +150,8 @@ __global__ void __launch_bounds__(256, 1) conv3d_wgrad_kernel(const WgradArgs a)
   constexpr int GS = GJ * 64 + 1, XS = XJ * 64 + 1;                     // odd LDS row strides holding whole pieces
   constexpr int NT = KS == 3 ? 7 : 1;                                   // accumulators per wave
   constexpr int STAGE = 32 * GS + 32 * XS;                              // g box [32][GS], then x' box [32][XS]
-  constexpr int NPIECE = 8 * (GJ + XJ);                                 // pieces per wave per box (8 channel rows)
+  constexpr int ROWS = 32 / WG_WAVES;                                   // channel rows a wave stages
+  constexpr int NPIECE = ROWS * (GJ + XJ);                              // pieces per wave per box
   __shared__ float st0[STAGE];
   __shared__ float st1[STAGE];
 
@@ -166,7 +171,8 @@ __global__ void __launch_bounds__(256, 1) conv3d_wgrad_kernel(const WgradArgs a)
 #pragma unroll
     for (int r = 0; r < 16; ++r) acc[j][r] = 0.f;
 
-  // ---- staging by LDS-DMA: wave w brings in channel rows 8w .. 8w+7 of both boxes, one 64-element piece per
+  const int wt = wv & 3, kh = wv >> 2;   // tap group / K half (band plane of the box) of this wave
+  // ---- staging by LDS-DMA: wave w brings in channel rows ROWS*w .. ROWS*w+ROWS-1 of both boxes, one 64-element piece per
   //      instruction (the channel base is wave-uniform; the per-lane position offset is shared by the 8 rows).
   //      Out-of-image positions, layout filler and out-of-range channels read a zero word.
   int goff[GJ], xoff[XJ];  // position offset inside a channel plane, or -1
@@ -200,7 +206,7 @@ __global__ void __launch_bounds__(256, 1) conv3d_wgrad_kernel(const WgradArgs a)
     constexpr int i = decltype(ic)::value;
     if constexpr (i < NPIECE) {
       constexpr int c = i / (GJ + XJ), j = i % (GJ + XJ);
-      const int ch = wv * 8 + c;  // wave-uniform
+      const int ch = wv * ROWS + c;  // wave-uniform
       if constexpr (j < GJ) {
         const bool ok = (goff[j] >= 0) & (co0 + ch < a.cout_g);
         dma_word(ok ? gbase + (long)ch * plane + goff[j] : &kZeroWord, st + ch * GS + j * 64);
@@ -212,28 +218,30 @@ __global__ void __launch_bounds__(256, 1) conv3d_wgrad_kernel(const WgradArgs a)
     }
   };
 
-  const int ga_off = l31 * GS + khalf;              // A operand of K-step ks: st[ga_off + 2*ks]
+  // KS=3: this wave's K-steps are the 32 position pairs of band plane kh of the box (BH*BW = 64 positions per plane)
+  const int ga_off = l31 * GS + khalf + (KS == 3 ? kh * (BH * BW) : 0);   // A operand of K-step ks: st[ga_off + 2*ks]
   int xj_off[NT];                                   // B operand base with the (wave-uniform) tap offset folded in
 #pragma unroll
   for (int j = 0; j < NT; ++j) {
-    const int tap = KS == 3 ? min(wv + 4 * j, TAPS - 1) : 0;
-    xj_off[j] = 32 * GS + l31 * XS + khalf + ((tap / (KS * KS)) * HH + (tap / KS) % KS) * HW + tap % KS;
+    const int tap = KS == 3 ? min(wt + 4 * j, TAPS - 1) : 0;
+    xj_off[j] = 32 * GS + l31 * XS + khalf + ((tap / (KS * KS)) * HH + (tap / KS) % KS) * HW + tap % KS +
+                (KS == 3 ? kh * (HH * HW) : 0);
   }
   // MFMAs of the box in `st`; the pieces of the next box go into `st_next`, spread evenly between the K-steps
   // (a burst of 72 DMA issues would keep the wave off the matrix pipe for a quarter of the box).
   auto mfma_box = [&](const float* st, float* st_next) __attribute__((always_inline)) {
-    constexpr int KSTEPS = POSB / 2, PER_WAVE = KS == 3 ? KSTEPS : KSTEPS / 4;
+    constexpr int KSTEPS = POSB / 2, PER_WAVE = KS == 3 ? KSTEPS / 2 : KSTEPS / WG_WAVES;
     float av[2], bv[2][NT];
     // operands of K-step k (one workgroup per CU = one wave per SIMD: nobody else hides the LDS latency, so the
     // reads of step k+1 are requested behind the first MFMA of step k)
     auto fetch = [&](auto kc) __attribute__((always_inline)) {
       constexpr int k0 = decltype(kc)::value;
       if constexpr (KS == 3) {
-        constexpr int p = 2 * k0;
-        constexpr int pn = p / (BH * BW), ph = (p / BW) % BH, pw = p % BW;
+        constexpr int p = 2 * k0;                    // position inside the wave's band plane
+        constexpr int ph = p / BW, pw = p % BW;
         av[k0 & 1] = st[ga_off + p];
 #pragma unroll
-        for (int j = 0; j < NT; ++j) bv[k0 & 1][j] = st[xj_off[j] + (pn * HH + ph) * HW + pw];
+        for (int j = 0; j < NT; ++j) bv[k0 & 1][j] = st[xj_off[j] + ph * HW + pw];
       } else {
         const int p = 2 * (wv * PER_WAVE + k0);
         av[k0 & 1] = st[ga_off + p];
@@ -245,7 +253,7 @@ __global__ void __launch_bounds__(256, 1) conv3d_wgrad_kernel(const WgradArgs a)
       constexpr int k0 = decltype(kc)::value;
       static_for<0, NT>([&](auto jc) __attribute__((always_inline)) {
         constexpr int j = decltype(jc)::value;
-        // (wave 3 has no 7th tap: it repeats tap 26 into an accumulator that is never stored)
+        // (tap group 3 has no 7th tap: it repeats tap 26 into an accumulator that is never stored)
         acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[k0 & 1], bv[k0 & 1][j], acc[j], 0, 0, 0);
         if constexpr (j == 0) {
           __builtin_amdgcn_sched_barrier(0);
@@ -282,10 +290,10 @@ __global__ void __launch_bounds__(256, 1) conv3d_wgrad_kernel(const WgradArgs a)
     }
   }
   // ---- partial sums -> workspace[slot][g][tap][co][ci]; D layout: col = l31 (ci), row = co ----------------------
-  const int slot = KS == 3 ? split : split * 4 + wv;
+  const int slot = KS == 3 ? split * 2 + kh : split * WG_WAVES + wv;
 #pragma unroll
   for (int j = 0; j < NT; ++j) {
-    const int tap = KS == 3 ? wv + 4 * j : 0;
+    const int tap = KS == 3 ? wt + 4 * j : 0;
     if (tap >= TAPS) continue;
     float* dst = a.ws + (((long)slot * a.groups + g) * TAPS + tap) * a.cout_g * a.cin_g;
 #pragma unroll
@@ -626,7 +634,7 @@ inline WgradPlan plan_wgrad(const tmdiff_conv3d_desc* d) {
   }
   p.boxes_per_split = (int)((p.total_boxes + best_s - 1) / best_s);
   p.splits = (int)((p.total_boxes + p.boxes_per_split - 1) / p.boxes_per_split);
-  p.slots = d->ksize == 3 ? p.splits : p.splits * 4;
+  p.slots = d->ksize == 3 ? p.splits * 2 : p.splits * WG_WAVES;
   p.needs_xp = d->nseg > 1 || d->in_shift || d->in_scale || d->in_mask || d->in_act || d->drop_p > 0.f;
   p.partial_floats = ((size_t)p.slots * d->Cout * cin_g * p.taps + 3) / 4 * 4;
   return p;
@@ -696,9 +704,9 @@ extern "C" int tmdiff_conv3d_wgrad(const tmdiff_conv3d_desc* d, const float* g, 
   a.splits = p.splits; a.boxes_per_split = p.boxes_per_split; a.total_boxes = p.total_boxes;
   const long blocks = (long)d->groups * p.tiles_co * p.tiles_ci * p.splits;
   if (d->ksize == 3)
-    conv3d_wgrad_kernel<3><<<(unsigned)blocks, 256, 0, st>>>(a);
+    conv3d_wgrad_kernel<3><<<(unsigned)blocks, 64 * WG_WAVES, 0, st>>>(a);
   else
-    conv3d_wgrad_kernel<1><<<(unsigned)blocks, 256, 0, st>>>(a);
+    conv3d_wgrad_kernel<1><<<(unsigned)blocks, 64 * WG_WAVES, 0, st>>>(a);
   int rc = check_launch("conv3d_wgrad");
   if (rc) return rc;
   const long total = (long)d->Cout * a.cin_g * p.taps;

@@ -107,7 +107,8 @@ class GradReducer:
         self.world = dist.get_world_size(group) if self.active else 1
         self.buckets = None          # list of dicts {flat, params, pending}
         self._order, self._bucket_of, self._handles = [], {}, []
-        self.launched = 0            # all-reduces started from hooks during the last backward
+        self.launched = 0            # all-reduces started from hooks during the current backward
+        self.launched_last = 0       # ... during the last finished step (kept across zero_grad, for reports)
         self._hooks = []
         if self.active:
             for p in module.parameters():
@@ -189,7 +190,7 @@ class GradReducer:
         return n
 
     def zero_grad(self):
-        self.launched = 0
+        self.launched_last, self.launched = self.launched, 0
         if self.buckets is None:
             self.module.zero_grad(set_to_none=True)
             self._order = []

@@ -1,0 +1,19 @@
+#!/bin/bash
+# collect_profiles.sh [TAG]: everything profiles/ holds for a round, in one GPU call (~4 min).  Outputs land in
+# gpurun_out/${TAG}_final/ (scratch); copy the summaries into profiles/ afterwards (tools/README.md).
+R=$PWD; TAG=${1:-r02}; O=$R/gpurun_out/${TAG}_final; mkdir -p $O
+python3 bench.py --steps 20 --warmup 3 > $O/bench_line.json 2> $O/bench.err; echo "bench rc=$?"
+python3 bench.py --mode train --steps 10 --warmup 3 > $O/bench_train_line.json 2>> $O/bench.err; echo "train rc=$?"
+bash tools/bench_traffic.sh $TAG > $O/traffic.log 2>&1; echo "traffic rc=$?"
+python3 tools/bench_configs.py c1 c3 c4 2>&1 | grep config > $O/configs.txt
+python3 tools/bench_attention.py 2>&1 | grep -v amdgpu > $O/attention.txt
+python3 tools/bench_hbm_kernels.py 2>&1 | grep -v amdgpu > $O/hbm_kernels.txt
+python3 tools/bench_wgrad.py 8 3 2>&1 | grep -v amdgpu > $O/wgrad_b8.txt
+python3 tools/bench_conv.py 32 3 fp32 2>&1 | grep -v amdgpu > $O/conv_layers_fp32.txt
+python3 tools/bench_conv.py 32 3 bf16 2>&1 | grep -v amdgpu > $O/conv_layers_bf16.txt
+bash tools/run_pmc.sh ${TAG}_final/pmc_wgrad "bench_wgrad.py 8 1"
+bash tools/run_pmc.sh ${TAG}_final/pmc_attention "bench_attention.py"
+bash tools/run_pmc.sh ${TAG}_final/pmc_conv_fp32 fp32
+cd /tmp && export TMPDIR=/tmp
+rocprofv3 --kernel-trace --stats -d $O/prof_train -o p --output-format csv -- python3 $R/bench.py --mode train --steps 6 --warmup 2 > /dev/null 2>&1; echo "train prof rc=$?"
+TMDIFF_BENCH_BACKEND=gloo timeout -k 10 300 python3 $R/bench.py --gpus 2 --mode train --steps 4 --warmup 2 > $O/train_2rank_gloo.json 2> /dev/null; echo "2-rank rc=$?"
