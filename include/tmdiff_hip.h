@@ -109,6 +109,19 @@ typedef struct tmdiff_conv3d_desc {
  * packed must hold Cout*Cin/groups*k^3 floats. */
 int tmdiff_conv3d_pack_weights(const float* w, float* packed, int32_t Cout, int32_t Cin, int32_t ksize,
                                int32_t groups, int32_t mode, tmdiff_stream_t stream);
+/* The same for a whole list of weight tensors in ONE launch, both packings at once (a training step re-packs every weight
+ * for its forward and its data-gradient convolution after each optimizer update).  `entries_dev` is a DEVICE array; chunk k
+ * (one workgroup) covers source elements [chunk_index_dev[k] * chunk, ...) of entry chunk_tensor_dev[k], chunk =
+ * tmdiff_conv3d_pack_weights_multi_chunk().  Either destination may be NULL. */
+typedef struct tmdiff_pack_entry {
+  const float* w;       /* [Cout, Cin/groups, k, k, k] */
+  float* packed_fwd;    /* mode 0 */
+  float* packed_dgrad;  /* mode 1 */
+  int32_t Cout, Cin, ksize, groups;
+} tmdiff_pack_entry;
+int32_t tmdiff_conv3d_pack_weights_multi_chunk(void);
+int tmdiff_conv3d_pack_weights_multi(const tmdiff_pack_entry* entries_dev, const int32_t* chunk_tensor_dev,
+                                     const int32_t* chunk_index_dev, int32_t n_chunks, tmdiff_stream_t stream);
 int tmdiff_conv3d_fwd(const tmdiff_conv3d_desc* d, tmdiff_stream_t stream);
 /* bytes of d->splitk_ws this convolution would use (0: its grid fills the chip, or the shape is not split) */
 size_t tmdiff_conv3d_fwd_splitk_workspace_bytes(const tmdiff_conv3d_desc* d);

@@ -530,6 +530,14 @@ class WavBEST(nn.Module):
         if dev.type != "cuda":
             raise RuntimeError("tmdiff_amd.WavBEST runs on the HIP kernels only: move the module to a GPU (.cuda())")
         b = x_t.shape[0]
+        # every convolution weight, forward and data-gradient packing, in one launch per step (re-done when a weight's
+        # version changed, i.e. after the optimizer step)
+        pk = self.__dict__.get("_train_pack")
+        if pk is None or pk.convs[0][0].device != dev:
+            pk = self.__dict__["_train_pack"] = ops.PackedWeights(
+                [(m.weight, m.groups) for m in self.modules()
+                 if isinstance(m, nn.Conv3d) and m.in_channels > 1 and m.out_channels > 1])
+        ops.PACKED = pk.refresh()
         lin = lambda seq, i, x, act: A.linear(x, seq[i].weight, seq[i].bias, act=act)
         pe = self._prompt_rows(prompt, b, dev)
         pemb = lin(self.embed2, 4, lin(self.embed2, 2, lin(self.embed2, 0, pe, True), True), True)

@@ -31,28 +31,41 @@ class _FusedConv3d(torch.autograd.Function):
         segs = [s.contiguous() for s in segs]
         w = weight.contiguous()
         cout, ksize = w.shape[0], w.shape[2]
-        wp = ops.pack_conv_weight(w, groups=groups, mode=0)
+        pre = ops.PACKED.lookup(w) if ops.PACKED is not None else None     # packed once per step for the whole network
+        wp = pre[0] if pre is not None else ops.pack_conv_weight(w, groups=groups, mode=0)
+        ctx.wp_dgrad = pre[1] if pre is not None else None
         # mask: None, a tensor (caller-supplied dropout mask, parity runs) or a DropSpec (seed, p): in-kernel dropout
         drop = mask if isinstance(mask, DropSpec) else None
         mask = None if drop is not None else mask
+        # a 3x3x3 convolution with dropout runs as prologue pass + staged kernel anyway: let the pass write x' into a
+        # tensor of its own and keep it -- the weight gradient then needs no prologue pass of its own
+        xp = None
+        if ksize == 3 and (drop is not None or mask is not None) and weight.requires_grad:
+            b, _, n, h, wd = segs[0].shape
+            cin = sum(s.shape[1] for s in segs)
+            if cin % groups == 0 and (cin // groups) % 4 == 0 and (cout // groups) % 32 == 0:   # shapes the staged kernel takes
+                xp = torch.empty(b, cin, n, h, wd, device=segs[0].device, dtype=torch.float32)
         y = ops.conv3d(segs, wp, cout, ksize, groups=groups, bias=bias, bias_scale=bias_scale, in_shift=shift,
-                       in_scale=scale, in_act=act, in_mask=mask, drop=drop, residual=residual, out_scale=out_scale)
+                       in_scale=scale, in_act=act, in_mask=mask, drop=drop, residual=residual, out_scale=out_scale,
+                       xp_out=xp)
         ctx.meta = meta
         ctx.nseg = len(segs)
         ctx.drop = drop
-        ctx.has = (bias is not None, shift is not None, scale is not None, residual is not None, mask is not None)
-        ctx.save_for_backward(w, *(t for t in (shift, scale, mask) if t is not None), *segs)
+        ctx.has = (bias is not None, shift is not None, scale is not None, residual is not None, mask is not None,
+                   xp is not None)
+        ctx.save_for_backward(w, *(t for t in (shift, scale, mask, xp) if t is not None), *segs)
         return y
 
     @staticmethod
     def backward(ctx, gy):
         act, groups, bias_scale, out_scale = ctx.meta
-        has_bias, has_shift, has_scale, has_res, has_mask = ctx.has
+        has_bias, has_shift, has_scale, has_res, has_mask, has_xp = ctx.has
         saved = list(ctx.saved_tensors)
         w = saved.pop(0)
         shift = saved.pop(0) if has_shift else None
         scale = saved.pop(0) if has_scale else None
         mask = saved.pop(0) if has_mask else None
+        xp = saved.pop(0) if has_xp else None
         segs = saved
         need = ctx.needs_input_grad  # (meta, weight, bias, shift, scale, residual, mask, *segs)
         g = gy.contiguous()
@@ -67,12 +80,16 @@ class _FusedConv3d(torch.autograd.Function):
         dummy = torch.empty(b, cout, n, h, wd, device=g.device, dtype=torch.float32) if False else g
         desc = ops.make_conv_desc(segs, 0, cout, ksize, dummy, groups=groups, in_shift=shift, in_scale=scale,
                                   in_act=act, in_mask=mask, drop=ctx.drop)
-        d_w = ops.conv3d_wgrad(desc, g, tuple(w.shape)) if need[1] else None
+        if need[1]:   # x' kept by the forward: a plain single-tensor input, no prologue pass inside the weight gradient
+            desc_w = ops.make_conv_desc([xp], 0, cout, ksize, dummy, groups=groups) if xp is not None else desc
+            d_w = ops.conv3d_wgrad(desc_w, g, tuple(w.shape))
+        else:
+            d_w = None
         need_x = any(need[7:]) or (has_shift and need[3]) or (has_scale and need[4])
         d_shift = d_scale = None
         d_segs = [None] * len(segs)
         if need_x:
-            wp_t = ops.pack_conv_weight(w, groups=groups, mode=1)
+            wp_t = ctx.wp_dgrad if ctx.wp_dgrad is not None else ops.pack_conv_weight(w, groups=groups, mode=1)
             gp = ops.conv3d([g], wp_t, cin, ksize, groups=groups)          # dL/dx'
             outs = [torch.empty_like(s) if need[7 + i] else None for i, s in enumerate(segs)]
             d_shift, d_scale = ops.conv3d_prologue_bwd(desc, gp, outs, [False] * len(segs),

@@ -520,6 +520,29 @@ __global__ void __launch_bounds__(256) splitk_reduce_kernel(const tmdiff::SplitK
   }
 }
 
+// Multi-tensor form: every convolution weight of a network, forward AND data-gradient packing, in ONE launch (a training
+// step re-packs all ~70 weights twice: 140 launches of 8 us became 1 ms of a 42 ms step).  Block = one chunk of
+// PACK_CHUNK source elements of one weight tensor.
+constexpr int PACK_CHUNK = 16384;
+__global__ void __launch_bounds__(256) pack_weights_multi_kernel(const tmdiff_pack_entry* __restrict__ entries,
+                                                                 const int32_t* __restrict__ chunk_tensor,
+                                                                 const int32_t* __restrict__ chunk_index) {
+  const tmdiff_pack_entry e = entries[chunk_tensor[blockIdx.x]];
+  const int taps = e.ksize * e.ksize * e.ksize, cout_g = e.Cout / e.groups, cin_g = e.Cin / e.groups;
+  const long total = (long)e.Cout * cin_g * taps;
+  const long lo = (long)chunk_index[blockIdx.x] * PACK_CHUNK, hi = min(lo + PACK_CHUNK, total);
+  for (long i = lo + threadIdx.x; i < hi; i += 256) {
+    const int tap = (int)(i % taps);
+    long r = i / taps;
+    const int ci = (int)(r % cin_g); r /= cin_g;
+    const int co = (int)(r % cout_g);
+    const int g = (int)(r / cout_g);
+    const float v = e.w[i];
+    if (e.packed_fwd) e.packed_fwd[(((long)g * cin_g + ci) * taps + tap) * cout_g + packed_col(co, cout_g)] = v;
+    if (e.packed_dgrad) e.packed_dgrad[(((long)g * cout_g + co) * taps + (taps - 1 - tap)) * cin_g + packed_col(ci, cin_g)] = v;
+  }
+}
+
 template <int KS, int NS, int MSUB, int KC, int TN, int TH, int TW>
 int launch(ConvArgs& a, hipStream_t st) {
   constexpr int CO = 32 * MSUB;
@@ -629,6 +652,17 @@ extern "C" int tmdiff_conv3d_pack_weights(const float* w, float* packed, int32_t
   pack_weights_kernel<<<(int)blocks, 256, 0, as_stream(stream)>>>(w, packed, Cout / groups, Cin / groups, taps, groups,
                                                                  mode, total);
   return check_launch("conv3d_pack_weights");
+}
+
+extern "C" int32_t tmdiff_conv3d_pack_weights_multi_chunk(void) { return PACK_CHUNK; }
+
+extern "C" int tmdiff_conv3d_pack_weights_multi(const tmdiff_pack_entry* entries_dev, const int32_t* chunk_tensor_dev,
+                                                const int32_t* chunk_index_dev, int32_t n_chunks, tmdiff_stream_t stream) {
+  using namespace tmdiff;
+  TMDIFF_REQUIRE(entries_dev && chunk_tensor_dev && chunk_index_dev && n_chunks >= 0, "pack_weights_multi: bad arguments");
+  if (n_chunks == 0) return TMDIFF_OK;
+  pack_weights_multi_kernel<<<(unsigned)n_chunks, 256, 0, as_stream(stream)>>>(entries_dev, chunk_tensor_dev, chunk_index_dev);
+  return check_launch("conv3d_pack_weights_multi");
 }
 
 extern "C" int tmdiff_conv3d_fwd(const tmdiff_conv3d_desc* d, tmdiff_stream_t stream) {

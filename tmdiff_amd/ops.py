@@ -42,6 +42,63 @@ def pack_conv_weight(w, groups=1, mode=0):
     return out
 
 
+class PackedWeights:
+    """Forward and data-gradient packings of a list of convolution weights, refreshed by ONE launch
+    (tmdiff_conv3d_pack_weights_multi).  ``refresh()`` re-packs when any weight changed (``_version``); ``lookup(w)``
+    returns (packed_fwd, packed_dgrad) for a weight whose current version is packed, else None."""
+
+    def __init__(self, convs):
+        """convs: list of (weight [Cout, Cin/g, k, k, k] on the GPU, groups)"""
+        self.convs = [(w, g) for w, g in convs]
+        dev = self.convs[0][0].device
+        chunk = lib.tmdiff_conv3d_pack_weights_multi_chunk()
+        self.fwd = [torch.empty(w.numel(), device=dev, dtype=torch.float32) for w, _ in self.convs]
+        self.dgrad = [torch.empty(w.numel(), device=dev, dtype=torch.float32) for w, _ in self.convs]
+        self._table_key, self.versions = None, None
+        self._chunk = chunk
+        self._index = {}
+
+    def _build_tables(self):
+        ent = bytearray()
+        ct, ci = [], []
+        import struct
+        for k, ((w, g), f, d) in enumerate(zip(self.convs, self.fwd, self.dgrad)):
+            _chk(w.detach(), "weight")
+            ent += struct.pack("<QQQiiii", w.data_ptr(), f.data_ptr(), d.data_ptr(), w.shape[0], w.shape[1] * g, w.shape[2], g)
+            nck = (w.numel() + self._chunk - 1) // self._chunk
+            ct += [k] * nck
+            ci += list(range(nck))
+        dev = self.convs[0][0].device
+        self.entries = torch.frombuffer(bytes(ent), dtype=torch.uint8).clone().to(dev)
+        self.chunk_tensor = torch.tensor(ct, dtype=torch.int32).to(dev)
+        self.chunk_index = torch.tensor(ci, dtype=torch.int32).to(dev)
+        self.n_chunks = len(ct)
+        self._table_key = tuple(w.data_ptr() for w, _ in self.convs)
+        self._index = {w.data_ptr(): k for k, (w, _) in enumerate(self.convs)}
+
+    def refresh(self):
+        ptrs = tuple(w.data_ptr() for w, _ in self.convs)
+        if ptrs != self._table_key:
+            self._build_tables()
+            self.versions = None
+        vers = tuple(w._version for w, _ in self.convs)
+        if vers != self.versions:
+            check(lib.tmdiff_conv3d_pack_weights_multi(self.entries.data_ptr(), self.chunk_tensor.data_ptr(),
+                                                       self.chunk_index.data_ptr(), self.n_chunks, stream_ptr()),
+                  "conv3d_pack_weights_multi")
+            self.versions = vers
+        return self
+
+    def lookup(self, w):
+        k = self._index.get(w.data_ptr())
+        if k is None or self.versions is None or self.versions[k] != w._version or self.convs[k][0].shape != w.shape:
+            return None
+        return self.fwd[k], self.dgrad[k]
+
+
+PACKED = None      # the PackedWeights of the network being trained (set by WavBEST.forward_train; autograd.py consults it)
+
+
 def bf16_conv_supported(cout, cin, ksize, groups=1, seg_channels=None):
     """Shapes tmdiff_conv3d_fwd_bf16 accepts (include/tmdiff_hip.h); other layers stay on the fp32 kernel."""
     if ksize not in (1, 3) or cin % groups or cout % groups or (cout // groups) % 32:
@@ -168,7 +225,7 @@ def _workspace(device, nbytes, tag="x"):
 
 
 def conv3d(segs, w_packed, cout, ksize, out=None, math="fp32", pack_input=None, staged=None, emit=None, keep_y=True,
-           x_bf16_shape=None, **kw):
+           x_bf16_shape=None, xp_out=None, **kw):
     """math="fp32": exact-fp32 MFMA kernel (w_packed from pack_conv_weight); "bf16": bf16 operands / fp32
     accumulation (w_packed from pack_conv_weight_bf16).  pack_input (bf16 only): True = pack the prologue output to
     bf16 once and run the staging-free kernel (default), False = one fused kernel.  staged (fp32 only): True = prologue
@@ -176,7 +233,9 @@ def conv3d(segs, w_packed, cout, ksize, out=None, math="fp32", pack_input=None, 
     emit = dict(act=, shift=, scale=, shift_stride=, scale_stride=): also produce y2 = act(y + shift) * scale, the
     consumer's prologue applied in this convolution's epilogue; returns (y, y2), or y2 alone with keep_y=False.  In the
     bf16 mode y2 is the packed bf16 tensor [B, Cout/8, N*H*W, 8] (int16 storage) that a following bf16 convolution takes
-    as its input with x_bf16_shape=(N, H, W), skipping its pack pass."""
+    as its input with x_bf16_shape=(N, H, W), skipping its pack pass.
+    xp_out (fp32, 3x3x3): a [B, Cin, N, H, W] tensor that receives the prologue output x' (forces the staged kernel, whose
+    prologue pass writes it there instead of the shared scratch) -- the training path keeps it for the weight gradient."""
     if x_bf16_shape is not None:
         b, (n, h, w) = segs[0].shape[0], x_bf16_shape
         kw = dict(kw, x_bf16_shape=x_bf16_shape)
@@ -221,9 +280,16 @@ def conv3d(segs, w_packed, cout, ksize, out=None, math="fp32", pack_input=None, 
             staged = {"0": False, "1": True}.get(_FP32_STAGED, ksize == 3 and (
                 plain or cout // d.groups >= 128 or d.Cin // d.groups >= 384 or kw.get("in_mask") is not None
                 or kw.get("drop") is not None))
+        if xp_out is not None:
+            staged = True
         if staged and lib.tmdiff_conv3d_fwd_staged_supported(C.byref(d)):
             nb = lib.tmdiff_conv3d_fwd_staged_workspace_bytes(C.byref(d))
-            ws32 = _workspace(dev, nb).data_ptr() if nb else None
+            if xp_out is not None and nb:
+                if xp_out.numel() * 4 != nb or not (xp_out.is_cuda and xp_out.is_contiguous()):
+                    raise ValueError("conv3d: xp_out must be a contiguous fp32 [B, Cin, N, H, W] tensor")
+                ws32 = xp_out.data_ptr()
+            else:
+                ws32 = _workspace(dev, nb).data_ptr() if nb else None
             fwd, what = (lambda dd, st: lib.tmdiff_conv3d_fwd_staged(dd, ws32, st)), "conv3d_fwd_staged"
         else:
             fwd, what = lib.tmdiff_conv3d_fwd, "conv3d_fwd"
