@@ -420,17 +420,7 @@ def main():
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         dt, dt_cached, dt_bf16, dt_instr = (float(v) for v in tt)
 
-    if not args.no_extras:
-        # ---- finetune step (BASELINE configs[3] share of this GPU), a short run beside `value` ---------------------
-        del net, diff
-        torch.cuda.empty_cache()
-        tsteps = max(3, min(args.steps, 8))
-        try:
-            train = train_object(train_leg(dev, world, rank, dist, tsteps, 2), world, tsteps)
-            log(f"train leg: {train['ms_per_step']} ms/step")
-        except Exception as e:       # the headline line must survive a failure of this side measurement
-            train = {"error": f"{type(e).__name__}: {e}"}
-
+    line = None
     if rank == 0:
         n3, ms3, fl3 = conv.get(3, (0, 0.0, 0.0))
         n1, ms1, fl1 = conv.get(1, (0, 0.0, 0.0))
@@ -478,11 +468,39 @@ def main():
                                     "note": "same full-forward steps with bf16 conv operands / fp32 accumulation "
                                             "(set_compute_dtype('bf16'), the config-3 mode; forward rel-L2 7e-3 vs fp32, "
                                             "tests/test_gpu_bf16.py) -- reduced precision, never `value`"}
-            line["train_step"] = train
         if world == 1 and not args.no_cpu_baseline and not args.no_extras:
             line["parity"] = parity_check(dev)
             log(f"parity: PSNR {line['parity']['psnr_db']} dB")
             line["cpu_baseline"] = cpu_baseline()
+
+    if not args.no_extras:
+        # ---- finetune step (BASELINE configs[3] share of this GPU), a short run beside `value`, LAST: at N > 1 it is the
+        # first code to push 123 MB gradient buckets through RCCL.  Everything measured so far is already in `line`; if
+        # this leg raises, or a collective never completes (watchdog), the line is still printed, with the reason. -------
+        del net, diff
+        torch.cuda.empty_cache()
+        tsteps = max(3, min(args.steps, 8))
+        import threading
+
+        def bail():
+            if rank == 0:
+                line["train_step"] = {"error": "finetune leg did not finish within 240 s (collective stuck?); "
+                                               "headline fields above were measured before it"}
+                print(json.dumps(line), flush=True)
+            os._exit(0)
+
+        dog = threading.Timer(240.0, bail)
+        dog.daemon = True
+        dog.start()
+        try:
+            train = train_object(train_leg(dev, world, rank, dist, tsteps, 2), world, tsteps)
+            log(f"train leg: {train['ms_per_step']} ms/step")
+        except Exception as e:       # the headline line must survive a failure of this side measurement
+            train = {"error": f"{type(e).__name__}: {e}"}
+        dog.cancel()
+        if rank == 0:
+            line["train_step"] = train
+    if rank == 0:
         print(json.dumps(line), flush=True)
     if dist is not None:
         dist.barrier()

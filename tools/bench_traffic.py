@@ -42,4 +42,5 @@ res = {"bytes_per_k3_launch": round(fetch + write), "fetch_bytes_per_launch": ro
                      "FETCH_SIZE x2 (gfx950), KiB -> bytes"}
 res["ratio_to_algorithmic"] = round(res["bytes_per_k3_launch"] / res["algorithmic_bytes_per_launch"], 3)
 json.dump(res, open(f"profiles/{tag}_bench_traffic.json", "w"), indent=1)
+json.dump(res, open(f"{out}.json", "w"), indent=1)        # gpurun_out/ copy: the only directory gpurun merges back
 print(json.dumps(res))

@@ -11,4 +11,5 @@ rocprofv3 --kernel-trace --pmc WRITE_SIZE -d $OUT/write -o p --output-format csv
 rocprofv3 --kernel-trace --stats -d $OUT/stats -o p --output-format csv -- $CMD > $OUT.stats.log 2>&1
 rc=$?
 cd $R && python3 tools/bench_traffic.py $OUT $TAG && cp $(ls $OUT/stats/*/*kernel_stats.csv $OUT/stats/*kernel_stats.csv 2>/dev/null | head -1) profiles/${TAG}_bench_kernel_stats.csv
+# (on a gpurun box only gpurun_out/ travels back: ${OUT}.json and $OUT/stats/p_kernel_stats.csv are the copies to commit under profiles/)
 exit $rc
