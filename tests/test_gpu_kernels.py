@@ -619,3 +619,38 @@ def test_conv3d_split_k(ops, case):
     xb = cu(torch.randn(32, 32, 8, 64, 64))
     db = ops.make_conv_desc([xb], ops.pack_conv_weight(cu(torch.randn(32, 32, 3, 3, 3))), 32, 3, torch.empty_like(xb))
     assert lib.tmdiff_conv3d_fwd_splitk_workspace_bytes(C.byref(db)) == 0
+
+
+def test_conv1_vectorised_equals_dword_kernel(ops, tmp_path):
+    """The 16-byte 1x1x1 kernel (a lane owns four consecutive positions; MFMA columns permuted accordingly) against fp64
+    and, bit for bit, against the dword kernel it replaces (run in a child process with TMDIFF_CONV1_DWORD=1)."""
+    import os, subprocess, sys
+    code = r'''
+import sys, torch
+sys.path.insert(0, sys.argv[1])
+from tmdiff_amd import ops
+outs = {}
+for tag, (b, cin, cout, shp, segs) in {"a": (2, 32, 64, (8, 16, 16), [32]), "b": (3, 48, 32, (4, 8, 16), [16, 32]),
+                                      "c": (1, 64, 128, (8, 32, 32), [64])}.items():
+    g = torch.Generator().manual_seed(len(tag) + cin)
+    xs = [torch.randn(b, c, *shp, generator=g).cuda() for c in segs]
+    w = (torch.randn(cout, cin, 1, 1, 1, generator=g) / cin ** 0.5).cuda()
+    kw = dict(bias=torch.randn(cout, generator=g).cuda(), residual=torch.randn(b, cout, *shp, generator=g).cuda(), out_scale=0.5,
+              in_shift=torch.randn(b, cin, generator=g).cuda(), in_scale=(torch.rand(b, cin, generator=g) + 0.5).cuda(), in_act=True)
+    outs[tag] = ops.conv3d(xs, ops.pack_conv_weight(w), cout, 1, **kw).cpu()
+    outs[tag + "_in"] = (torch.cat([x.cpu() for x in xs], 1), w.cpu(), {k: (v.cpu() if torch.is_tensor(v) else v) for k, v in kw.items()})
+torch.save(outs, sys.argv[2])
+'''
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    res = {}
+    for mode, env in (("vec", {}), ("dword", {"TMDIFF_CONV1_DWORD": "1"})):
+        path = str(tmp_path / f"{mode}.pt")
+        subprocess.run([sys.executable, "-c", code, root, path], check=True, env=dict(os.environ, **env), timeout=300)
+        res[mode] = torch.load(path)
+    for tag in ("a", "b", "c"):
+        assert torch.equal(res["vec"][tag], res["dword"][tag]), tag
+        x, w, kw = res["vec"][tag + "_in"]
+        xd = x.double() + kw["in_shift"].double()[:, :, None, None, None]
+        xd = xd * torch.sigmoid(xd) * kw["in_scale"].double()[:, :, None, None, None]
+        ref = (F.conv3d(xd, w.double(), kw["bias"].double()) + kw["residual"].double()) * 0.5
+        assert_close(res["vec"][tag], ref.float(), 2e-5, 2e-6, f"1x1x1 {tag} vs fp64")

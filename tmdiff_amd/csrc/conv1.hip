@@ -9,6 +9,8 @@
 //   [ci][co], tmdiff_conv3d_pack_weights) is one 4/8-byte load per lane from L2.
 // A workgroup = 4 waves x (NS x 32 positions) x (MSUB x 32 channels); 16 input channels (8 K-steps) are in flight
 // in registers while the previous 16 are multiplied.  Same accumulation order as the generic kernel.
+#include <cstdlib>
+
 #include "common.h"
 
 namespace {
@@ -147,6 +149,132 @@ __global__ void __launch_bounds__(256, 2) conv1_fp32_kernel(const K1Args a) {
   }
 }
 
+// 16-byte variant (plane % 4 == 0, 16-byte aligned tensors: every production layer).  A lane owns FOUR consecutive
+// positions: one dwordx4 load per channel, and MFMA sub-tile s takes element s of every lane, i.e. its 32 columns are the
+// positions {4*lane + s} -- a column permutation the epilogue undoes for free (a lane's four sub-tile results of a row are
+// again 4 consecutive positions = one dwordx4 store).  Four times fewer memory instructions than the dword kernel above,
+// whose issue rate, not HBM, capped it at ~3.4 TB/s.  Same accumulation order, so the same bits.
+constexpr int GV = 4;  // K-steps per register group (8 input channels)
+
+template <int MSUB, bool ACT>
+__global__ void __launch_bounds__(256, 2) conv1_fp32_vec_kernel(const K1Args a) {
+  constexpr int CO = 32 * MSUB, NS = 4;
+  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+  const int l31 = lane & 31, khalf = lane >> 5;
+  unsigned id = blockIdx.x;
+  const int co_tile = __builtin_amdgcn_readfirstlane(id % a.tiles_co); id /= a.tiles_co;
+  const int ptile = __builtin_amdgcn_readfirstlane(id % a.ptiles); id /= a.ptiles;
+  const int g = __builtin_amdgcn_readfirstlane(id % a.groups);
+  const int b = __builtin_amdgcn_readfirstlane(id / a.groups);
+  const int co0 = co_tile * CO;
+  const long plane = a.plane;
+  const int ngroups = a.cin_g / (2 * GV);
+
+  const long p0l = (long)ptile * 512 + wv * 128 + l31 * 4;      // first of this lane's four positions
+  const bool pok = p0l < plane;                                   // plane % 4 == 0: all four or none
+  const unsigned p0 = (unsigned)(pok ? p0l : plane - 4);          // clamped loads, no store
+  const unsigned chan_off = (unsigned)khalf * (unsigned)plane;
+  const float* wg = a.wp + (long)g * a.cin_g * a.cout_g + (long)khalf * a.cout_g + co0 + l31 * MSUB;
+
+  f32x16 acc[NS][MSUB];
+#pragma unroll
+  for (int s = 0; s < NS; ++s)
+#pragma unroll
+    for (int m = 0; m < MSUB; ++m)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[s][m][r] = 0.f;
+
+  float xr[2][GV][NS], wr[2][GV][MSUB], shr[2][GV], scr[2][GV];
+  auto load_group = [&](int q, int buf) __attribute__((always_inline)) {
+    const int cg = g * a.cin_g + q * 2 * GV;  // first of 8 channels; they lie in one input segment
+    const float* src;
+    int cl, segc;
+    if (cg < a.seg_c[0]) src = a.seg_x[0], cl = cg, segc = a.seg_c[0];
+    else if (cg < a.seg_c[0] + a.seg_c[1]) src = a.seg_x[1], cl = cg - a.seg_c[0], segc = a.seg_c[1];
+    else src = a.seg_x[2], cl = cg - a.seg_c[0] - a.seg_c[1], segc = a.seg_c[2];
+    const float* base = src + ((long)b * segc + cl) * plane;
+    const float* shp = a.in_shift ? a.in_shift + (long)b * a.shift_stride + cg : kZeros16;
+    const float* scp = a.in_scale ? a.in_scale + (long)b * a.scale_stride + cg : kOnes16;
+    const float* wq = wg + (long)q * 2 * GV * a.cout_g;
+#pragma unroll
+    for (int j = 0; j < GV; ++j) {
+      const float4 t = *reinterpret_cast<const float4*>(base + (unsigned)(2 * j) * (unsigned)plane + chan_off + p0);
+      xr[buf][j][0] = t.x, xr[buf][j][1] = t.y, xr[buf][j][2] = t.z, xr[buf][j][3] = t.w;
+      shr[buf][j] = shp[2 * j + khalf];
+      scr[buf][j] = scp[2 * j + khalf];
+      if constexpr (MSUB == 2) {
+        const float2 w2 = *reinterpret_cast<const float2*>(wq + (long)(2 * j) * a.cout_g);
+        wr[buf][j][0] = w2.x, wr[buf][j][1] = w2.y;
+      } else {
+        wr[buf][j][0] = wq[(long)(2 * j) * a.cout_g];
+      }
+    }
+  };
+  auto mfma_group = [&](int buf) __attribute__((always_inline)) {
+#pragma unroll
+    for (int j = 0; j < GV; ++j) {
+      float bv[NS];
+#pragma unroll
+      for (int s = 0; s < NS; ++s) {
+        float v = xr[buf][j][s] + shr[buf][j];
+        if constexpr (ACT) v = tmdiff::silu_f(v);
+        bv[s] = v * scr[buf][j];
+      }
+#pragma unroll
+      for (int s = 0; s < NS; ++s)
+#pragma unroll
+        for (int m = 0; m < MSUB; ++m)
+          acc[s][m] = __builtin_amdgcn_mfma_f32_32x32x2f32(wr[buf][j][m], bv[s], acc[s][m], 0, 0, 0);
+    }
+  };
+  load_group(0, 0);
+  for (int q = 0; q < ngroups; q += 2) {
+    if (q + 1 < ngroups) load_group(q + 1, 1);
+    mfma_group(0);
+    if (q + 1 < ngroups) {
+      if (q + 2 < ngroups) load_group(q + 2, 0);
+      mfma_group(1);
+    }
+  }
+
+  // epilogue: column l31 of sub-tile s = position p0 + s; row (r&3) + 8*(r>>2) + 4*khalf = channel
+#pragma unroll
+  for (int m = 0; m < MSUB; ++m) {
+    const int cbase = g * a.cout_g + co0 + m * 32 + 4 * khalf;
+    const long obase = ((long)b * a.Cout + cbase) * plane + p0;
+#pragma unroll
+    for (int half = 0; half < 2; ++half) {     // eight rows at a time: bounded register use
+      float4 res[8];
+      float bs[8];
+#pragma unroll
+      for (int k = 0; k < 8; ++k) {
+        const int r = half * 8 + k, row = (r & 3) + 8 * (r >> 2);
+        res[k] = a.residual ? *reinterpret_cast<const float4*>(a.residual + obase + row * plane) : make_float4(0.f, 0.f, 0.f, 0.f);
+        bs[k] = a.bias ? a.bias[cbase + row] * a.bias_scale : 0.f;
+      }
+#pragma unroll
+      for (int k = 0; k < 8; ++k) {
+        const int r = half * 8 + k, row = (r & 3) + 8 * (r >> 2);
+        if (pok)
+          *reinterpret_cast<float4*>(a.y + obase + row * plane) =
+              make_float4((acc[0][m][r] + bs[k] + res[k].x) * a.out_scale, (acc[1][m][r] + bs[k] + res[k].y) * a.out_scale,
+                          (acc[2][m][r] + bs[k] + res[k].z) * a.out_scale, (acc[3][m][r] + bs[k] + res[k].w) * a.out_scale);
+      }
+    }
+  }
+}
+
+template <int MSUB>
+int launch_vec(K1Args& a, int in_act, hipStream_t st) {
+  a.ptiles = (int)((a.plane + 511) / 512);
+  a.tiles_co = a.cout_g / (32 * MSUB);
+  const long blocks = (long)a.B * a.groups * a.ptiles * a.tiles_co;
+  if (blocks <= 0 || blocks > 0x7fffffffL) return tmdiff::fail(TMDIFF_E_INVALID, "conv1: grid of %ld blocks", blocks);
+  if (in_act) conv1_fp32_vec_kernel<MSUB, true><<<(unsigned)blocks, 256, 0, st>>>(a);
+  else conv1_fp32_vec_kernel<MSUB, false><<<(unsigned)blocks, 256, 0, st>>>(a);
+  return tmdiff::check_launch("conv3d_fwd (1x1x1 bandwidth kernel, 16-byte)");
+}
+
 template <int NS, int MSUB>
 int launch(K1Args& a, int in_act, hipStream_t st) {
   a.ptiles = (int)((a.plane + 4 * NS * 32 - 1) / (4 * NS * 32));
@@ -183,6 +311,12 @@ int tmdiff::conv1_fp32_try(const tmdiff_conv3d_desc* d, hipStream_t st) {
   a.residual = d->residual; a.out_scale = d->out_scale; a.y = d->y;
   a.plane = plane;
   // channel tiles follow the weight packing: 64-channel interleaved rows when cout_g % 64 == 0
+  // (its 512-position tiles must still fill the chip: the 8x8x8 level keeps the dword kernel's 256-position tiles)
+  const long blocks_vec = (long)d->B * d->groups * ((plane + 511) / 512) * (cout_g % 64 == 0 ? cout_g / 64 : cout_g / 32);
+  bool vec = plane % 4 == 0 && blocks_vec >= 512 && aligned16(d->y) && aligned16(d->residual);
+  for (int i = 0; i < d->nseg; ++i) vec = vec && aligned16(d->seg_x[i]);
+  static const bool no_vec = getenv("TMDIFF_CONV1_DWORD") != nullptr;      // experiments: the dword kernel everywhere
+  if (vec && !no_vec) return cout_g % 64 == 0 ? launch_vec<2>(a, d->in_act, st) : launch_vec<1>(a, d->in_act, st);
   if (cout_g % 64 == 0) return launch<2, 2>(a, d->in_act, st);
   return launch<2, 1>(a, d->in_act, st);
 }
