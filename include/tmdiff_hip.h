@@ -110,16 +110,18 @@ typedef struct tmdiff_conv3d_desc {
 int tmdiff_conv3d_pack_weights(const float* w, float* packed, int32_t Cout, int32_t Cin, int32_t ksize,
                                int32_t groups, int32_t mode, tmdiff_stream_t stream);
 /* The same for a whole list of weight tensors in ONE launch, both packings at once (a training step re-packs every weight
- * for its forward and its data-gradient convolution after each optimizer update).  `entries_dev` is a DEVICE array; chunk k
- * (one workgroup) covers source elements [chunk_index_dev[k] * chunk, ...) of entry chunk_tensor_dev[k], chunk =
- * tmdiff_conv3d_pack_weights_multi_chunk().  Either destination may be NULL. */
+ * for its forward and its data-gradient convolution after each optimizer update).  `entries_dev` is a DEVICE array; workgroup
+ * k works on entry chunk_tensor_dev[k]; chunk_index_dev[k] = tile number within that entry, with bit 30 set for the tiles of
+ * the data-gradient packing: an entry needs tmdiff_conv3d_pack_weights_multi_chunks(...) workgroups, the first *n_type_a of
+ * them forward-packing tiles (numbered 0..), the rest data-gradient tiles (numbered 0.. | 1<<30).  ksize 1 or 3.  Either
+ * destination may be NULL. */
 typedef struct tmdiff_pack_entry {
   const float* w;       /* [Cout, Cin/groups, k, k, k] */
   float* packed_fwd;    /* mode 0 */
   float* packed_dgrad;  /* mode 1 */
   int32_t Cout, Cin, ksize, groups;
 } tmdiff_pack_entry;
-int32_t tmdiff_conv3d_pack_weights_multi_chunk(void);
+int32_t tmdiff_conv3d_pack_weights_multi_chunks(int32_t Cout, int32_t Cin, int32_t groups, int32_t* n_type_a);
 int tmdiff_conv3d_pack_weights_multi(const tmdiff_pack_entry* entries_dev, const int32_t* chunk_tensor_dev,
                                      const int32_t* chunk_index_dev, int32_t n_chunks, tmdiff_stream_t stream);
 int tmdiff_conv3d_fwd(const tmdiff_conv3d_desc* d, tmdiff_stream_t stream);

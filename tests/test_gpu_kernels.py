@@ -623,7 +623,8 @@ def test_conv3d_split_k(ops, case):
 
 def test_conv1_vectorised_equals_dword_kernel(ops, tmp_path):
     """The 16-byte 1x1x1 kernel (a lane owns four consecutive positions; MFMA columns permuted accordingly) against fp64
-    and, bit for bit, against the dword kernel it replaces (run in a child process with TMDIFF_CONV1_DWORD=1)."""
+    and, bit for bit, against the dword kernel it replaces on large grids (child processes with TMDIFF_CONV1_VEC=1 /
+    TMDIFF_CONV1_DWORD=1 force either kernel at these small sizes)."""
     import os, subprocess, sys
     code = r'''
 import sys, torch
@@ -643,7 +644,7 @@ torch.save(outs, sys.argv[2])
 '''
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     res = {}
-    for mode, env in (("vec", {}), ("dword", {"TMDIFF_CONV1_DWORD": "1"})):
+    for mode, env in (("vec", {"TMDIFF_CONV1_VEC": "1"}), ("dword", {"TMDIFF_CONV1_DWORD": "1"})):
         path = str(tmp_path / f"{mode}.pt")
         subprocess.run([sys.executable, "-c", code, root, path], check=True, env=dict(os.environ, **env), timeout=300)
         res[mode] = torch.load(path)
@@ -654,3 +655,22 @@ torch.save(outs, sys.argv[2])
         xd = xd * torch.sigmoid(xd) * kw["in_scale"].double()[:, :, None, None, None]
         ref = (F.conv3d(xd, w.double(), kw["bias"].double()) + kw["residual"].double()) * 0.5
         assert_close(res["vec"][tag], ref.float(), 2e-5, 2e-6, f"1x1x1 {tag} vs fp64")
+
+
+def test_multi_tensor_weight_packing_equals_single(ops):
+    """tmdiff_conv3d_pack_weights_multi (every weight of a network, forward + data-gradient packing, one launch, LDS-tiled
+    transposes) against tmdiff_conv3d_pack_weights tensor by tensor: identical buffers; refresh() re-packs on a version bump."""
+    torch.manual_seed(41)
+    shapes = [(32, 32, 3, 1), (64, 32, 3, 1), (32, 96, 3, 1), (128, 64, 1, 1), (96, 48, 3, 3), (24, 20, 3, 1), (8, 4, 1, 1),
+              (256, 768, 3, 1)]
+    ws = [(torch.nn.Parameter(cu(torch.randn(co, ci // g, k, k, k))), g) for co, ci, k, g in shapes]
+    pk = ops.PackedWeights(ws).refresh()
+    for w, g in ws:
+        f, d = pk.lookup(w)
+        assert torch.equal(f, ops.pack_conv_weight(w, groups=g, mode=0)), tuple(w.shape)
+        assert torch.equal(d, ops.pack_conv_weight(w, groups=g, mode=1)), tuple(w.shape)
+    with torch.no_grad():
+        ws[2][0].mul_(2.0)                       # an optimizer step bumps the version
+    assert pk.lookup(ws[2][0]) is None and pk.lookup(ws[1][0]) is not None
+    pk.refresh()
+    assert torch.equal(pk.lookup(ws[2][0])[0], ops.pack_conv_weight(ws[2][0], groups=1, mode=0))

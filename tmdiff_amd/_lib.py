@@ -38,7 +38,7 @@ SIGNATURES = {
     "tmdiff_version": (C.c_int, []),
     "tmdiff_last_error_string": (C.c_char_p, []),
     "tmdiff_conv3d_pack_weights": (C.c_int, [vp, vp, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32, vp]),
-    "tmdiff_conv3d_pack_weights_multi_chunk": (C.c_int32, []),
+    "tmdiff_conv3d_pack_weights_multi_chunks": (C.c_int32, [C.c_int32, C.c_int32, C.c_int32, C.POINTER(C.c_int32)]),
     "tmdiff_conv3d_pack_weights_multi": (C.c_int, [vp, vp, vp, C.c_int32, vp]),
     "tmdiff_conv3d_fwd": (C.c_int, [C.POINTER(Conv3dDesc), vp]),
     "tmdiff_conv3d_fwd_splitk_workspace_bytes": (C.c_size_t, [C.POINTER(Conv3dDesc)]),

@@ -54,7 +54,8 @@ __device__ __forceinline__ float block_sum_256(float v, float* red) {
 // Eight waves (two per SIMD: while one waits on its operand reads or issues DMA pieces, the other's MFMAs keep the matrix
 // pipe busy -- with one wave per SIMD the pipe idled a quarter of the time).  KS=3: wave w accumulates taps w%4, w%4+4, ...
 // (7 accumulators, the g operand is shared by all of them) over band w/4 of the box (the box has two band planes);
-// KS=1: the eight waves split the positions of the box.  Each wave's partial is a separate slot of the reduction.
+// KS=1: the eight waves split the positions of the box.  Waves that share a tap add their accumulators through LDS at the
+// end (fixed order), so a workgroup contributes one slot to the reduction.
 // Partials go to workspace[split][g][tap][co][ci]; wgrad_reduce_kernel sums the splits into PyTorch layout.
 // ---------------------------------------------------------------------------------------------------
 struct WgradArgs {
@@ -152,8 +153,9 @@ __global__ void __launch_bounds__(64 * WG_WAVES, 1) conv3d_wgrad_kernel(const Wg
   constexpr int STAGE = 32 * GS + 32 * XS;                              // g box [32][GS], then x' box [32][XS]
   constexpr int ROWS = 32 / WG_WAVES;                                   // channel rows a wave stages
   constexpr int NPIECE = ROWS * (GJ + XJ);                              // pieces per wave per box
-  __shared__ float st0[STAGE];
-  __shared__ float st1[STAGE];
+  __shared__ float stages[2 * STAGE];   // (one array: the final reduction of the waves' partials reuses all of it)
+  float* const st0 = stages;
+  float* const st1 = stages + STAGE;
 
   const int tid = threadIdx.x, lane = tid & 63, l31 = lane & 31, khalf = lane >> 5;
   const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);   // wave-uniform: LDS-DMA destinations / tap offsets stay scalar
@@ -289,8 +291,40 @@ __global__ void __launch_bounds__(64 * WG_WAVES, 1) conv3d_wgrad_kernel(const Wg
       __syncthreads();
     }
   }
-  // ---- partial sums -> workspace[slot][g][tap][co][ci]; D layout: col = l31 (ci), row = co ----------------------
-  const int slot = KS == 3 ? split * 2 + kh : split * WG_WAVES + wv;
+  // ---- the waves that shared a tap (KS=3: the two band planes; KS=1: all eight) add their accumulators through LDS in a
+  //      fixed order, so that the workgroup writes ONE partial per (tap, co, ci) -------------------------------------
+  static_assert(2 * STAGE >= (KS == 3 ? 4 : 7) * NT * 16 * 64, "stage buffers hold the partials being combined");
+  __syncthreads();   // (the last box's LDS reads are done)
+  if constexpr (KS == 3) {
+    float* xch = stages + (wt * NT) * 16 * 64 + lane;
+    if (kh == 1) {
+#pragma unroll
+      for (int j = 0; j < NT; ++j)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) xch[(j * 16 + r) * 64] = acc[j][r];
+    }
+    __syncthreads();
+    if (kh == 0) {
+#pragma unroll
+      for (int j = 0; j < NT; ++j)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[j][r] += xch[(j * 16 + r) * 64];
+    }
+  } else {
+    if (wv > 0) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) stages[((wv - 1) * 16 + r) * 64 + lane] = acc[0][r];
+    }
+    __syncthreads();
+    if (wv == 0) {
+      for (int w = 0; w < WG_WAVES - 1; ++w)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[0][r] += stages[(w * 16 + r) * 64 + lane];
+    }
+  }
+  if (KS == 3 ? kh != 0 : wv != 0) return;
+  // ---- partial sums -> workspace[split][g][tap][co][ci]; D layout: col = l31 (ci), row = co ----------------------
+  const int slot = split;
 #pragma unroll
   for (int j = 0; j < NT; ++j) {
     const int tap = KS == 3 ? wt + 4 * j : 0;
@@ -634,7 +668,7 @@ inline WgradPlan plan_wgrad(const tmdiff_conv3d_desc* d) {
   }
   p.boxes_per_split = (int)((p.total_boxes + best_s - 1) / best_s);
   p.splits = (int)((p.total_boxes + p.boxes_per_split - 1) / p.boxes_per_split);
-  p.slots = d->ksize == 3 ? p.splits * 2 : p.splits * WG_WAVES;
+  p.slots = p.splits;          // the waves of a workgroup combine their partials in LDS
   p.needs_xp = d->nseg > 1 || d->in_shift || d->in_scale || d->in_mask || d->in_act || d->drop_p > 0.f;
   p.partial_floats = ((size_t)p.slots * d->Cout * cin_g * p.taps + 3) / 4 * 4;
   return p;

@@ -313,7 +313,8 @@ int tmdiff::conv1_fp32_try(const tmdiff_conv3d_desc* d, hipStream_t st) {
   // channel tiles follow the weight packing: 64-channel interleaved rows when cout_g % 64 == 0
   // (its 512-position tiles must still fill the chip: the 8x8x8 level keeps the dword kernel's 256-position tiles)
   const long blocks_vec = (long)d->B * d->groups * ((plane + 511) / 512) * (cout_g % 64 == 0 ? cout_g / 64 : cout_g / 32);
-  bool vec = plane % 4 == 0 && blocks_vec >= 512 && aligned16(d->y) && aligned16(d->residual);
+  static const bool force_vec = getenv("TMDIFF_CONV1_VEC") != nullptr;     // experiments / tests: wherever it is legal
+  bool vec = plane % 4 == 0 && (blocks_vec >= 512 || force_vec) && aligned16(d->y) && aligned16(d->residual);
   for (int i = 0; i < d->nseg; ++i) vec = vec && aligned16(d->seg_x[i]);
   static const bool no_vec = getenv("TMDIFF_CONV1_DWORD") != nullptr;      // experiments: the dword kernel everywhere
   if (vec && !no_vec) return cout_g % 64 == 0 ? launch_vec<2>(a, d->in_act, st) : launch_vec<1>(a, d->in_act, st);

@@ -521,25 +521,62 @@ __global__ void __launch_bounds__(256) splitk_reduce_kernel(const tmdiff::SplitK
 }
 
 // Multi-tensor form: every convolution weight of a network, forward AND data-gradient packing, in ONE launch (a training
-// step re-packs all ~70 weights twice: 140 launches of 8 us became 1 ms of a 42 ms step).  Block = one chunk of
-// PACK_CHUNK source elements of one weight tensor.
-constexpr int PACK_CHUNK = 16384;
+// step re-packs all ~70 weights twice: 140 launches of 8 us were 1.1 ms of a 42 ms step).  Both packings are transposes of
+// the source [co][ci][tap], so each goes through an LDS tile shaped for ITS destination's contiguous axis:
+//   type A (forward packing  [ci][tap][co]):        tile = 32 co x 8 ci  x taps, written as 128-byte runs over co;
+//   type B (data-gradient    [co][taps-1-tap][ci]): tile = 8 co  x 64 ci x taps, written as 256-byte runs over ci.
+// (A single pass with scattered 4-byte writes took 0.72 ms for the 31 M weights of the ch 32-256 network.)
+constexpr int PK_A_CO = 32, PK_A_CI = 8, PK_B_CO = 8, PK_B_CI = 64, PK_MAXTAPS = 27;
 __global__ void __launch_bounds__(256) pack_weights_multi_kernel(const tmdiff_pack_entry* __restrict__ entries,
                                                                  const int32_t* __restrict__ chunk_tensor,
                                                                  const int32_t* __restrict__ chunk_index) {
+  __shared__ float tile[PK_B_CO * (PK_B_CI * PK_MAXTAPS + 1)];   // also holds a type-A tile: 32 x (8*27 + 1)
   const tmdiff_pack_entry e = entries[chunk_tensor[blockIdx.x]];
   const int taps = e.ksize * e.ksize * e.ksize, cout_g = e.Cout / e.groups, cin_g = e.Cin / e.groups;
-  const long total = (long)e.Cout * cin_g * taps;
-  const long lo = (long)chunk_index[blockIdx.x] * PACK_CHUNK, hi = min(lo + PACK_CHUNK, total);
-  for (long i = lo + threadIdx.x; i < hi; i += 256) {
-    const int tap = (int)(i % taps);
-    long r = i / taps;
-    const int ci = (int)(r % cin_g); r /= cin_g;
-    const int co = (int)(r % cout_g);
-    const int g = (int)(r / cout_g);
-    const float v = e.w[i];
-    if (e.packed_fwd) e.packed_fwd[(((long)g * cin_g + ci) * taps + tap) * cout_g + packed_col(co, cout_g)] = v;
-    if (e.packed_dgrad) e.packed_dgrad[(((long)g * cout_g + co) * taps + (taps - 1 - tap)) * cin_g + packed_col(ci, cin_g)] = v;
+  const int raw = chunk_index[blockIdx.x];
+  const bool type_b = (raw >> 30) & 1;
+  int id = raw & 0x3FFFFFFF;
+  const int tid = threadIdx.x;
+  if (!type_b) {
+    const int nci = (cin_g + PK_A_CI - 1) / PK_A_CI, nco = (cout_g + PK_A_CO - 1) / PK_A_CO;
+    const int cib = id % nci; id /= nci;
+    const int cob = id % nco;
+    const int g = id / nco;
+    const int ci0 = cib * PK_A_CI, co0 = cob * PK_A_CO;
+    const int ncil = min(PK_A_CI, cin_g - ci0), run = ncil * taps, LS = PK_A_CI * PK_MAXTAPS + 1;
+    for (int i = tid; i < PK_A_CO * run; i += 256) {      // source: per co a contiguous run of ncil*taps floats
+      const int co = i / run, k = i % run;
+      if (co0 + co < cout_g) tile[co * LS + k] = e.w[(((long)g * cout_g + co0 + co) * cin_g + ci0) * taps + k];
+    }
+    __syncthreads();
+    if (e.packed_fwd) {
+      const int co = tid % PK_A_CO;
+      if (co0 + co < cout_g)
+        for (int k = tid / PK_A_CO; k < run; k += 256 / PK_A_CO)     // k = ci_local * taps + tap
+          e.packed_fwd[(((long)g * cin_g + ci0) * taps + k) * cout_g + packed_col(co0 + co, cout_g)] = tile[co * LS + k];
+    }
+  } else {
+    const int nci = (cin_g + PK_B_CI - 1) / PK_B_CI, nco = (cout_g + PK_B_CO - 1) / PK_B_CO;
+    const int cib = id % nci; id /= nci;
+    const int cob = id % nco;
+    const int g = id / nco;
+    const int ci0 = cib * PK_B_CI, co0 = cob * PK_B_CO;
+    const int ncil = min(PK_B_CI, cin_g - ci0), run = ncil * taps, LS = PK_B_CI * PK_MAXTAPS + 1;
+    for (int i = tid; i < PK_B_CO * run; i += 256) {
+      const int co = i / run, k = i % run;
+      if (co0 + co < cout_g) tile[co * LS + k] = e.w[(((long)g * cout_g + co0 + co) * cin_g + ci0) * taps + k];
+    }
+    __syncthreads();
+    if (e.packed_dgrad) {
+      const int ci = tid % PK_B_CI;
+      if (ci < ncil)
+        for (int q = tid / PK_B_CI; q < PK_B_CO * taps; q += 256 / PK_B_CI) {   // q = co_local * taps + tap
+          const int co = q / taps, tap = q % taps;
+          if (co0 + co < cout_g)
+            e.packed_dgrad[(((long)g * cout_g + co0 + co) * taps + (taps - 1 - tap)) * cin_g + packed_col(ci0 + ci, cin_g)] =
+                tile[co * LS + ci * taps + tap];
+        }
+    }
   }
 }
 
@@ -654,7 +691,15 @@ extern "C" int tmdiff_conv3d_pack_weights(const float* w, float* packed, int32_t
   return check_launch("conv3d_pack_weights");
 }
 
-extern "C" int32_t tmdiff_conv3d_pack_weights_multi_chunk(void) { return PACK_CHUNK; }
+// number of workgroups (chunks) a weight of this shape needs: type-A tiles first, then type-B tiles
+extern "C" int32_t tmdiff_conv3d_pack_weights_multi_chunks(int32_t Cout, int32_t Cin, int32_t groups, int32_t* n_type_a) {
+  if (groups <= 0 || Cout % groups || Cin % groups) return 0;
+  const int cout_g = Cout / groups, cin_g = Cin / groups;
+  const int na = groups * ((cout_g + PK_A_CO - 1) / PK_A_CO) * ((cin_g + PK_A_CI - 1) / PK_A_CI);
+  const int nb = groups * ((cout_g + PK_B_CO - 1) / PK_B_CO) * ((cin_g + PK_B_CI - 1) / PK_B_CI);
+  if (n_type_a) *n_type_a = na;
+  return na + nb;
+}
 
 extern "C" int tmdiff_conv3d_pack_weights_multi(const tmdiff_pack_entry* entries_dev, const int32_t* chunk_tensor_dev,
                                                 const int32_t* chunk_index_dev, int32_t n_chunks, tmdiff_stream_t stream) {

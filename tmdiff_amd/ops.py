@@ -51,11 +51,9 @@ class PackedWeights:
         """convs: list of (weight [Cout, Cin/g, k, k, k] on the GPU, groups)"""
         self.convs = [(w, g) for w, g in convs]
         dev = self.convs[0][0].device
-        chunk = lib.tmdiff_conv3d_pack_weights_multi_chunk()
         self.fwd = [torch.empty(w.numel(), device=dev, dtype=torch.float32) for w, _ in self.convs]
         self.dgrad = [torch.empty(w.numel(), device=dev, dtype=torch.float32) for w, _ in self.convs]
         self._table_key, self.versions = None, None
-        self._chunk = chunk
         self._index = {}
 
     def _build_tables(self):
@@ -65,9 +63,12 @@ class PackedWeights:
         for k, ((w, g), f, d) in enumerate(zip(self.convs, self.fwd, self.dgrad)):
             _chk(w.detach(), "weight")
             ent += struct.pack("<QQQiiii", w.data_ptr(), f.data_ptr(), d.data_ptr(), w.shape[0], w.shape[1] * g, w.shape[2], g)
-            nck = (w.numel() + self._chunk - 1) // self._chunk
+            if w.shape[2] not in (1, 3):
+                raise ValueError("PackedWeights: kernel size 1 or 3")
+            na = C.c_int32(0)
+            nck = lib.tmdiff_conv3d_pack_weights_multi_chunks(w.shape[0], w.shape[1] * g, g, C.byref(na))
             ct += [k] * nck
-            ci += list(range(nck))
+            ci += list(range(na.value)) + [(1 << 30) | t for t in range(nck - na.value)]
         dev = self.convs[0][0].device
         self.entries = torch.frombuffer(bytes(ent), dtype=torch.uint8).clone().to(dev)
         self.chunk_tensor = torch.tensor(ct, dtype=torch.int32).to(dev)
