@@ -174,6 +174,10 @@ int tmdiff_conv3d_fwd_bf16(const tmdiff_conv3d_desc* d, void* workspace, tmdiff_
 size_t tmdiff_conv3d_wgrad_workspace_bytes(const tmdiff_conv3d_desc* d);
 int tmdiff_conv3d_wgrad(const tmdiff_conv3d_desc* d, const float* g, float* dw, void* workspace,
                         tmdiff_stream_t stream);
+/* The same, and dbias[Cout] = d->bias_scale * sum_{b,pos} g[b,co,pos] on the side (the kernel reads every g element anyway;
+ * this replaces a tmdiff_channel_sum pass over g).  dbias NULL = tmdiff_conv3d_wgrad. */
+int tmdiff_conv3d_wgrad_bias(const tmdiff_conv3d_desc* d, const float* g, float* dw, float* dbias, void* workspace,
+                             tmdiff_stream_t stream);
 
 /* out[c] = scale * sum_{b, p} x[b, c, p]   (x is [B, C, P]); bias gradients. */
 int tmdiff_channel_sum(const float* x, float* out, int32_t B, int32_t C, int64_t P, float scale,

@@ -348,3 +348,21 @@ def test_in_kernel_dropout_matches_explicit_mask():
         outs.append([y.detach()] + [t.grad for t in (x, w, bias, shift, scale, res)])
     for name, a_, b_ in zip(("y", "dx", "dw", "dbias", "dshift", "dscale", "dres"), *outs):
         assert_close(a_, b_, 1e-6, 1e-6, f"in-kernel dropout {name}")
+
+
+@pytest.mark.parametrize("shape", [(2, 32, 64, 3, 1), (1, 24, 40, 3, 1), (2, 48, 96, 3, 3), (2, 32, 32, 1, 1)])
+def test_wgrad_with_bias_gradient_on_the_side(shape):
+    """tmdiff_conv3d_wgrad_bias: dw as tmdiff_conv3d_wgrad (bit for bit) and dbias = bias_scale * sum g against the
+    channel-sum kernel / fp64."""
+    from tmdiff_amd import ops
+    b, cin, cout, k, groups = shape
+    x, g = cu(randn(1, b, cin, 4, 8, 16)), cu(randn(2, b, cout, 4, 8, 16))
+    sc = cu(torch.rand(b, cin) + 0.5)
+    d = ops.make_conv_desc([x], 0, cout, k, g, groups=groups, in_scale=sc, in_act=True, bias_scale=2.0)
+    wshape = (cout, cin // groups, k, k, k)
+    dw0 = ops.conv3d_wgrad(d, g, wshape)
+    dw1, db = ops.conv3d_wgrad(d, g, wshape, want_bias=True)
+    assert torch.equal(dw0, dw1)
+    want = 2.0 * g.double().sum(dim=(0, 2, 3, 4))
+    assert_close(db.cpu(), want.float().cpu(), 1e-5, 1e-5, "dbias inside wgrad")
+    assert_close(ops.channel_sum(g, 2.0).cpu(), want.float().cpu(), 1e-5, 1e-5, "channel_sum")

@@ -564,11 +564,8 @@ class WavBEST(nn.Module):
 
         def bank(x, layers):     # one launch for all projections of x; autograd splits the gradient back
             out = A.linear(x, torch.cat([l.weight for _, l in layers]), torch.cat([l.bias for _, l in layers]))
-            res, off = {}, 0
-            for n_, l in layers:
-                res[n_] = out[:, off:off + l.out_features]
-                off += l.out_features
-            return res
+            parts = A.split_cols(out, [l.out_features for _, l in layers])
+            return {n_: p for (n_, _), p in zip(layers, parts)}
 
         shifts, scales = bank(temb, shift_layers), bank(pemb, scale_layers)
         sh = lambda name: shifts.get(name)          # flag=True blocks have no shift entry (and ignore it)

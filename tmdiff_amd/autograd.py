@@ -13,6 +13,13 @@ from . import ops
 from ._lib import check, lib
 
 
+import os as _os
+# "1": the bias gradient is accumulated inside the weight-gradient kernel (tmdiff_conv3d_wgrad_bias) instead of a
+# tmdiff_channel_sum pass over g.  Measured on one box, same process pair: 43.4 vs 43.2 ms per finetune step -- the saved
+# pass (0.6 ms of launches) is paid back inside the MFMA stream -- so the separate pass stays the default.
+_WGRAD_BIAS = _os.environ.get("TMDIFF_WGRAD_BIAS", "0") == "1"
+
+
 class DropSpec(tuple):
     """(seed, p): dropout of a convolution's prologue output evaluated inside the kernels from a counter-based hash of
     (seed, element index) -- forward, weight gradient and prologue backward regenerate the same mask; no mask tensor."""
@@ -74,7 +81,7 @@ class _FusedConv3d(torch.autograd.Function):
         cout, cin_g, ksize = w.shape[0], w.shape[1], w.shape[2]
         cin = cin_g * groups
         b, _, n, h, wd = segs[0].shape
-        d_bias = ops.channel_sum(g, bias_scale) if (has_bias and need[2]) else None
+        d_bias = None
         d_res = g if (has_res and need[5]) else None
         # descriptor of the forward prologue (what x' was): used by wgrad and by the prologue backward
         dummy = torch.empty(b, cout, n, h, wd, device=g.device, dtype=torch.float32) if False else g
@@ -82,9 +89,15 @@ class _FusedConv3d(torch.autograd.Function):
                                   in_act=act, in_mask=mask, drop=ctx.drop)
         if need[1]:   # x' kept by the forward: a plain single-tensor input, no prologue pass inside the weight gradient
             desc_w = ops.make_conv_desc([xp], 0, cout, ksize, dummy, groups=groups) if xp is not None else desc
-            d_w = ops.conv3d_wgrad(desc_w, g, tuple(w.shape))
+            if has_bias and need[2] and _WGRAD_BIAS:      # the bias gradient rides along in the weight-gradient kernel
+                desc_w.bias_scale = bias_scale
+                d_w, d_bias = ops.conv3d_wgrad(desc_w, g, tuple(w.shape), want_bias=True)
+            else:
+                d_w = ops.conv3d_wgrad(desc_w, g, tuple(w.shape))
         else:
             d_w = None
+        if has_bias and need[2] and d_bias is None:
+            d_bias = ops.channel_sum(g, bias_scale)
         need_x = any(need[7:]) or (has_shift and need[3]) or (has_scale and need[4])
         d_shift = d_scale = None
         d_segs = [None] * len(segs)
@@ -226,3 +239,22 @@ class _Linear(torch.autograd.Function):
 
 def linear(x, weight, bias=None, act=False):
     return _Linear.apply(x, weight, bias, act)
+
+
+class _SplitCols(torch.autograd.Function):
+    """[B, sum(sizes)] -> contiguous [B, size_k] blocks.  Plain slicing would do, but its backward builds a zero-filled
+    full-width tensor per slice and adds them up (three tiny kernels per Dense() projection, ~180 launches per training
+    step for the two projection banks); here the backward is one concatenation."""
+
+    @staticmethod
+    def forward(ctx, out, sizes):
+        ctx.sizes = sizes
+        return tuple(t.contiguous() for t in torch.split(out, sizes, dim=1))
+
+    @staticmethod
+    def backward(ctx, *grads):
+        return torch.cat([g.contiguous() for g in grads], dim=1), None      # (materialised: unused blocks arrive as zeros)
+
+
+def split_cols(out, sizes):
+    return _SplitCols.apply(out, tuple(int(s) for s in sizes))

@@ -63,6 +63,7 @@ struct WgradArgs {
   const float* xp;  // x' [B, Cin, N, H, W]
   const float* g;
   float* ws;
+  float* bias_ws;          // [slot][Cout] partial sums of g over positions (bias gradient), or NULL
   int nbn, nbh, nbw;       // boxes per sample along n, h, w
   int tiles_co, tiles_ci;  // per group
   int splits, boxes_per_split;
@@ -172,6 +173,10 @@ __global__ void __launch_bounds__(64 * WG_WAVES, 1) conv3d_wgrad_kernel(const Wg
   for (int j = 0; j < NT; ++j)
 #pragma unroll
     for (int r = 0; r < 16; ++r) acc[j][r] = 0.f;
+  // Bias gradient on the side: the A operand of every K-step IS g[co = l31][position], so the waves of the first ci tile
+  // that load each g element exactly once (KS=3: tap group 0 of either band plane; KS=1: all eight) sum it up as they go.
+  const bool do_bias = a.bias_ws != nullptr && ci_t == 0 && (KS == 1 || (wv & 3) == 0);
+  float bsum = 0.f;
 
   const int wt = wv & 3, kh = wv >> 2;   // tap group / K half (band plane of the box) of this wave
   // ---- staging by LDS-DMA: wave w brings in channel rows ROWS*w .. ROWS*w+ROWS-1 of both boxes, one 64-element piece per
@@ -249,6 +254,7 @@ __global__ void __launch_bounds__(64 * WG_WAVES, 1) conv3d_wgrad_kernel(const Wg
         av[k0 & 1] = st[ga_off + p];
         bv[k0 & 1][0] = st[xj_off[0] + p];
       }
+      if (do_bias) bsum += av[k0 & 1];
     };
     fetch(std::integral_constant<int, 0>{});
     static_for<0, PER_WAVE>([&](auto kc) __attribute__((always_inline)) {
@@ -294,7 +300,16 @@ __global__ void __launch_bounds__(64 * WG_WAVES, 1) conv3d_wgrad_kernel(const Wg
   // ---- the waves that shared a tap (KS=3: the two band planes; KS=1: all eight) add their accumulators through LDS in a
   //      fixed order, so that the workgroup writes ONE partial per (tap, co, ci) -------------------------------------
   static_assert(2 * STAGE >= (KS == 3 ? 4 : 7) * NT * 16 * 64, "stage buffers hold the partials being combined");
+  __shared__ float bred[WG_WAVES][32];
+  bsum += __shfl_xor(bsum, 32, 64);           // even + odd positions of the pair
+  if (lane < 32) bred[wv][lane] = do_bias ? bsum : 0.f;
   __syncthreads();   // (the last box's LDS reads are done)
+  if (a.bias_ws != nullptr && ci_t == 0 && wv == 0 && lane < 32 && co0 + lane < a.cout_g) {
+    float t = 0.f;
+#pragma unroll
+    for (int w = 0; w < WG_WAVES; ++w) t += bred[w][lane];      // fixed order
+    a.bias_ws[((long)split * a.groups + g) * a.cout_g + co0 + lane] = t;
+  }
   if constexpr (KS == 3) {
     float* xch = stages + (wt * NT) * 16 * 64 + lane;
     if (kh == 1) {
@@ -343,8 +358,17 @@ __global__ void __launch_bounds__(64 * WG_WAVES, 1) conv3d_wgrad_kernel(const Wg
 // then the rows are combined through LDS in a fixed order (deterministic).
 __global__ void __launch_bounds__(256) wgrad_reduce_kernel(const float* __restrict__ ws, float* __restrict__ dw,
                                                            int slots, int groups, int taps, int cout_g, int cin_g,
-                                                           long total) {
+                                                           long total, const float* __restrict__ bias_ws,
+                                                           float* __restrict__ dbias, float bias_scale) {
   __shared__ float part[4][64];
+  if (dbias && blockIdx.x == gridDim.x - 1) {   // bias gradient: sum of the per-workgroup partials, slot order
+    const int cout = groups * cout_g;
+    for (int c = threadIdx.x; c < cout; c += 256) {
+      float t = 0.f;
+      for (int k = 0; k < slots; ++k) t += bias_ws[(long)k * cout + c];
+      dbias[c] = bias_scale * t;
+    }
+  }
   const long per_slot = (long)groups * taps * cout_g * cin_g;
   const int col = threadIdx.x & 63, row = threadIdx.x >> 6;
   for (long base = blockIdx.x * 64L; base < total; base += 64L * gridDim.x) {
@@ -641,7 +665,7 @@ struct WgradPlan {
   int taps, nbn, nbh, nbw, tiles_co, tiles_ci, splits, boxes_per_split, slots;
   long total_boxes;
   bool needs_xp;        // the prologue output (or the concatenation of the segments) is materialised in the workspace
-  size_t partial_floats;
+  size_t partial_floats, bias_floats;
 };
 
 inline WgradPlan plan_wgrad(const tmdiff_conv3d_desc* d) {
@@ -671,6 +695,7 @@ inline WgradPlan plan_wgrad(const tmdiff_conv3d_desc* d) {
   p.slots = p.splits;          // the waves of a workgroup combine their partials in LDS
   p.needs_xp = d->nseg > 1 || d->in_shift || d->in_scale || d->in_mask || d->in_act || d->drop_p > 0.f;
   p.partial_floats = ((size_t)p.slots * d->Cout * cin_g * p.taps + 3) / 4 * 4;
+  p.bias_floats = ((size_t)p.slots * d->Cout + 3) / 4 * 4;
   return p;
 }
 
@@ -699,11 +724,16 @@ extern "C" size_t tmdiff_conv3d_wgrad_workspace_bytes(const tmdiff_conv3d_desc* 
   if (!d || d->B <= 0 || d->groups <= 0 || (d->ksize != 1 && d->ksize != 3)) return 0;
   const WgradPlan p = plan_wgrad(d);
   const size_t xp = p.needs_xp ? (size_t)d->B * d->Cin * d->N * d->H * d->W : 0;
-  return (p.partial_floats + xp) * sizeof(float);
+  return (p.partial_floats + p.bias_floats + xp) * sizeof(float);
 }
 
 extern "C" int tmdiff_conv3d_wgrad(const tmdiff_conv3d_desc* d, const float* g, float* dw, void* workspace,
                                    tmdiff_stream_t stream) {
+  return tmdiff_conv3d_wgrad_bias(d, g, dw, nullptr, workspace, stream);
+}
+
+extern "C" int tmdiff_conv3d_wgrad_bias(const tmdiff_conv3d_desc* d, const float* g, float* dw, float* dbias,
+                                        void* workspace, tmdiff_stream_t stream) {
   using namespace tmdiff;
   TMDIFF_REQUIRE(d && g && dw, "conv3d_wgrad: NULL pointer");
   TMDIFF_REQUIRE(d->ksize == 1 || d->ksize == 3, "conv3d_wgrad: ksize=%d", d->ksize);
@@ -727,9 +757,10 @@ extern "C" int tmdiff_conv3d_wgrad(const tmdiff_conv3d_desc* d, const float* g, 
   a.B = d->B; a.N = d->N; a.H = d->H; a.W = d->W; a.Cin = d->Cin; a.Cout = d->Cout;
   a.groups = d->groups; a.cin_g = d->Cin / d->groups; a.cout_g = d->Cout / d->groups;
   a.g = g; a.ws = reinterpret_cast<float*>(workspace);
+  a.bias_ws = dbias ? a.ws + p.partial_floats : nullptr;
   a.xp = d->seg_x[0];
   if (p.needs_xp) {
-    float* xp = a.ws + p.partial_floats;
+    float* xp = a.ws + p.partial_floats + p.bias_floats;
     const int rc = launch_prologue_apply(d, xp, st);
     if (rc) return rc;
     a.xp = xp;
@@ -746,7 +777,8 @@ extern "C" int tmdiff_conv3d_wgrad(const tmdiff_conv3d_desc* d, const float* g, 
   const long total = (long)d->Cout * a.cin_g * p.taps;
   long rb = (total + 63) / 64;
   if (rb > 8192) rb = 8192;
-  wgrad_reduce_kernel<<<(unsigned)rb, 256, 0, st>>>(a.ws, dw, p.slots, d->groups, p.taps, a.cout_g, a.cin_g, total);
+  wgrad_reduce_kernel<<<(unsigned)rb, 256, 0, st>>>(a.ws, dw, p.slots, d->groups, p.taps, a.cout_g, a.cin_g, total,
+                                                    a.bias_ws, dbias, d->bias_scale);
   return check_launch("conv3d_wgrad(reduce)");
 }
 

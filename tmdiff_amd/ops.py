@@ -461,14 +461,20 @@ def q_sample(x0, noise, a, out=None):
 
 
 # ---- backward-side wrappers (finetune path) -----------------------------------------------------------
-def conv3d_wgrad(desc, g, weight_shape):
-    """dL/dw [Cout, Cin/g, k,k,k] for the convolution described by `desc` (a filled Conv3dDesc) given g = dL/dy."""
+def conv3d_wgrad(desc, g, weight_shape, want_bias=False):
+    """dL/dw [Cout, Cin/g, k,k,k] for the convolution described by `desc` (a filled Conv3dDesc) given g = dL/dy; with
+    want_bias also dL/dbias = desc.bias_scale * sum_{b,pos} g, accumulated inside the same kernel: returns (dw, dbias)."""
     dw = torch.empty(weight_shape, device=g.device, dtype=torch.float32)
     nbytes = lib.tmdiff_conv3d_wgrad_workspace_bytes(C.byref(desc))
-    ws = torch.empty(max(1, nbytes // 4), device=g.device, dtype=torch.float32)
-    check(lib.tmdiff_conv3d_wgrad(C.byref(desc), _chk(g, "g"), dw.data_ptr(), ws.data_ptr(), stream_ptr()),
-          "conv3d_wgrad")
-    return dw
+    ws = _workspace(g.device, max(4, nbytes), "wgrad")
+    if not want_bias:
+        check(lib.tmdiff_conv3d_wgrad(C.byref(desc), _chk(g, "g"), dw.data_ptr(), ws.data_ptr(), stream_ptr()),
+              "conv3d_wgrad")
+        return dw
+    db = torch.empty(weight_shape[0], device=g.device, dtype=torch.float32)
+    check(lib.tmdiff_conv3d_wgrad_bias(C.byref(desc), _chk(g, "g"), dw.data_ptr(), db.data_ptr(), ws.data_ptr(),
+                                       stream_ptr()), "conv3d_wgrad_bias")
+    return dw, db
 
 
 def channel_sum(x, scale=1.0):
