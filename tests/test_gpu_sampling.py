@@ -171,7 +171,11 @@ def test_adaptive_add_noise_inverse(golden):
         z = mk().inverse(data, steps=12, order=2, skip_type="time_uniform", method="multistep")
         assert_close(z.cpu(), g[f"gauss_{algo}_inverse"], 1e-4, 1e-4, f"inverse {algo}")
         back = mk().sample(z, steps=12, order=2, skip_type="time_uniform", method="multistep")
-        assert_close(back.cpu(), g[f"gauss_{algo}_inverse_back"], 1e-4, 1e-4, f"inverse round trip {algo}")
+        # (noise-parameterised "dpmsolver": the way back divides by alpha_T ~ 5e-3 -- the reference's own round trip moves by
+        #  1.8e-4 max-rel when the data is perturbed by 1e-7 relative (asserted on the oracle in tests/test_oracle_golden.py);
+        #  the data-parameterised "dpmsolver++" is stable at the 1e-6 level)
+        rt_tol = 1e-3 if algo == "dpmsolver" else 1e-4
+        assert_close(back.cpu(), g[f"gauss_{algo}_inverse_back"], rt_tol, rt_tol, f"inverse round trip {algo}")
     sol = DPM_Solver(model_wrapper(gm, ns, model_type="noise"), ns)
     xn = cu(randn(155, 2, 4, 8, 8))
     y1 = sol.add_noise(xn, torch.tensor([0.3]), noise=cu(randn(156, 1, 2, 4, 8, 8)))
