@@ -37,7 +37,9 @@ def test_primitives():
     a, gate = u.chunk(2, -1)
     assert_close(ops.geglu(cu(u)).cpu(), a * F.gelu(gate), 1e-6, 1e-6, "geglu")
     assert_close(ops.geglu(cu(u), gelu_only=True).cpu(), F.gelu(u), 1e-6, 1e-6, "gelu")
-    for b, h, nq, nk, d in ((2, 8, 256, 77, 16), (1, 4, 64, 64, 32), (2, 1, 200, 200, 64), (1, 2, 33, 5, 128)):
+    # (head dims 64 / 128 take the pipelined LDS-DMA kernel, the others the simple one: ragged Nq / Nk for both)
+    for b, h, nq, nk, d in ((2, 8, 256, 77, 16), (1, 4, 64, 64, 32), (2, 1, 200, 200, 64), (1, 2, 33, 5, 128), (2, 4, 300, 77, 64),
+                            (1, 1, 1024, 1024, 128), (3, 2, 129, 97, 64)):
         q, k, v = randn(12, b, nq, h * d), randn(13, b, nk, h * d), randn(14, b, nk, h * d)
         split = lambda t: t.reshape(t.shape[0], t.shape[1], h, d).permute(0, 2, 1, 3)
         want = F.scaled_dot_product_attention(split(q), split(k), split(v), scale=d ** -0.5)

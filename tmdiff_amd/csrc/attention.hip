@@ -12,6 +12,8 @@
 // in-lane reductions plus one exchange between the two half-waves, the rescale of the output accumulator
 // O^T[d, query] is a per-lane multiply, and P^T feeds the second product O^T += V^T P^T directly from the
 // accumulator registers: register r of half-wave h is key (r&3)+8(r>>2)+4h, exactly the K-pair of MFMA step r.
+#include <cstdlib>
+
 #include "common.h"
 
 namespace {
@@ -120,6 +122,134 @@ __global__ void __launch_bounds__(256) attn_fwd_kernel(const AttnArgs a) {
   for (int e = tid; e < 128 * DP; e += 256) {
     const int r = e / DP, c = e % DP;
     if (q0 + r < a.Nq && c < a.D) ob[(long)(q0 + r) * a.o_rs + c] = qs[r * KS + c];
+  }
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// Pipelined variant for head dims 64 and 128 (SpatialSelfAttention at c = 64 / 128, CrossAttention d_head 64): same
+// arithmetic and register layout as attn_fwd_kernel, but
+//   * K/V tiles go global -> LDS with global_load_lds (one 256-byte row piece per instruction, no registers), double
+//     buffered: tile i+1 lands while tile i is multiplied, one barrier per tile instead of a synchronous
+//     load - barrier - compute - barrier sequence;
+//   * the workgroup's (pre-scaled) query rows are held in registers, so S^T = K Q^T costs one LDS operand read per MFMA
+//     instead of two;
+//   * the Q staging buffer, the K/V stages and the O transpose buffer share the same LDS (33 / 66 KB: 2+ workgroups per CU).
+// ---------------------------------------------------------------------------------------------------------
+__device__ __attribute__((unused)) const float kZeroRow[128] = {};
+
+template <int DT>  // D == 32 * DT, DT = 2 or 4
+__global__ void __launch_bounds__(256, 2) attn_fwd_dma_kernel(const AttnArgs a) {
+  constexpr int D = DT * 32, KS = D + 1, TILE = 32 * KS, RP = D / 64;   // RP = 256-byte pieces per row
+  static_assert(DT == 2 || DT == 4, "head dim 64 or 128");
+  static_assert(4 * TILE == 128 * KS, "two double-buffered K/V stages alias the 128-row Q / O buffer");
+  __shared__ float lds[4 * TILE];
+  const int tid = threadIdx.x, lane = tid & 63, l31 = lane & 31, h = lane >> 5;
+  const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int bh = blockIdx.y, b = bh / a.H, hd = bh % a.H;
+  const int q0 = blockIdx.x * 128;
+  const float* qb = a.q + b * a.q_bs + hd * a.q_hs;
+  const float* kb = a.k + b * a.k_bs + hd * a.k_hs;
+  const float* vb = a.v + b * a.v_bs + hd * a.v_hs;
+
+  // queries: coalesced rows -> LDS -> this lane's row (query wv*32 + l31), elements 2j + h, into registers
+  for (int e = tid; e < 128 * D; e += 256) {
+    const int r = e / D, c = e % D;
+    lds[r * KS + c] = q0 + r < a.Nq ? qb[(long)(q0 + r) * a.q_rs + c] * a.scale : 0.f;
+  }
+  __syncthreads();
+  float qreg[D / 2];
+  {
+    const float* qrow = lds + (wv * 32 + l31) * KS + h;
+#pragma unroll
+    for (int j = 0; j < D / 2; ++j) qreg[j] = qrow[2 * j];
+  }
+  __syncthreads();   // everyone has its queries: the buffer becomes the K/V stages
+
+  // DMA of key tile starting at k0 into stage st: wave w brings rows w, w+4, ... of K and of V
+  auto issue = [&](int k0, float* st) __attribute__((always_inline)) {
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      const int r = wv + 4 * i;
+      const bool ok = k0 + r < a.Nk;
+#pragma unroll
+      for (int p = 0; p < RP; ++p) {
+#if defined(__HIP_DEVICE_COMPILE__)  // the builtin exists in the device pass only
+        const float* ksrc = ok ? kb + (long)(k0 + r) * a.k_rs + p * 64 + lane : kZeroRow + lane;
+        const float* vsrc = ok ? vb + (long)(k0 + r) * a.v_rs + p * 64 + lane : kZeroRow + lane;
+        __builtin_amdgcn_global_load_lds(ksrc, st + r * KS + p * 64, 4, 0, 0);
+        __builtin_amdgcn_global_load_lds(vsrc, st + TILE + r * KS + p * 64, 4, 0, 0);
+#else
+        (void)ok; (void)kb; (void)vb; (void)st;
+#endif
+      }
+    }
+  };
+
+  f32x16 oacc[DT];
+#pragma unroll
+  for (int t = 0; t < DT; ++t)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) oacc[t][r] = 0.f;
+  float m_run = -3.0e38f, l_run = 0.f;
+
+  issue(0, lds);
+  int it = 0;
+  for (int k0 = 0; k0 < a.Nk; k0 += 32, ++it) {
+    __syncthreads();   // tile `it` has landed (own pieces: vmcnt(0) in front of the barrier); tile it-1 is consumed by all
+    if (k0 + 32 < a.Nk) issue(k0 + 32, lds + ((it + 1) & 1) * 2 * TILE);
+    const float* ks = lds + (it & 1) * 2 * TILE;
+    const float* vs = ks + TILE;
+    f32x16 s;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) s[r] = 0.f;
+    const float* krow = ks + l31 * KS + h;
+#pragma unroll
+    for (int j = 0; j < D / 2; ++j) s = __builtin_amdgcn_mfma_f32_32x32x2f32(krow[2 * j], qreg[j], s, 0, 0, 0);
+    float mx = -3.0e38f;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int key = k0 + (r & 3) + 8 * (r >> 2) + 4 * h;
+      bool keep = key < a.Nk;
+      if (keep && a.mask) keep = a.mask[(long)b * a.Nk + key] != 0;
+      s[r] = keep ? s[r] : -3.4028234e38f;   // masked_fill(-finfo.max), ref :203-204
+      mx = fmaxf(mx, s[r]);
+    }
+    mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+    const float m_new = fmaxf(m_run, mx);
+    const float alpha = __expf(m_run - m_new);
+    float psum = 0.f;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      s[r] = __expf(s[r] - m_new);
+      psum += s[r];
+    }
+    psum += __shfl_xor(psum, 32, 64);
+    l_run = l_run * alpha + psum;
+    m_run = m_new;
+#pragma unroll
+    for (int t = 0; t < DT; ++t) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) oacc[t][r] *= alpha;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int key = (r & 3) + 8 * (r >> 2) + 4 * h;
+        oacc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(vs[key * KS + t * 32 + l31], s[r], oacc[t], 0, 0, 0);
+      }
+    }
+  }
+  // out[query, d] = O^T[d, query] / l; transpose through LDS for coalesced stores
+  __syncthreads();
+  const float inv = 1.f / l_run;
+  float* ot = lds + wv * 32 * KS;
+#pragma unroll
+  for (int t = 0; t < DT; ++t)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) ot[l31 * KS + t * 32 + (r & 3) + 8 * (r >> 2) + 4 * h] = oacc[t][r] * inv;
+  __syncthreads();
+  float* ob = a.o + b * a.o_bs + hd * a.o_hs;
+  for (int e = tid; e < 128 * D; e += 256) {
+    const int r = e / D, c = e % D;
+    if (q0 + r < a.Nq) ob[(long)(q0 + r) * a.o_rs + c] = lds[r * KS + c];
   }
 }
 
@@ -254,6 +384,12 @@ extern "C" int tmdiff_attn_fwd(const float* q, const float* k, const float* v, f
   a.H = H; a.Nq = Nq; a.Nk = Nk; a.D = D; a.scale = scale;
   dim3 grid((Nq + 127) / 128, B * H);
   hipStream_t st = as_stream(stream);
+  static const bool no_dma = getenv("TMDIFF_ATTN_SIMPLE") != nullptr;   // experiments: the un-pipelined kernel everywhere
+  if (!no_dma && (D == 64 || D == 128)) {
+    if (D == 64) attn_fwd_dma_kernel<2><<<grid, 256, 0, st>>>(a);
+    else attn_fwd_dma_kernel<4><<<grid, 256, 0, st>>>(a);
+    return check_launch("attn_fwd");
+  }
   switch ((D + 31) / 32) {
     case 1: attn_fwd_kernel<1><<<grid, 256, 0, st>>>(a); break;
     case 2: attn_fwd_kernel<2><<<grid, 256, 0, st>>>(a); break;
