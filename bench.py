@@ -237,6 +237,7 @@ def train_leg(dev, world, rank, dist, steps, warmup):
     out = {"seconds": dt, "host_seconds": t_host, "loss": float(m.get_current_log()["l_pix"]), "allreduce": None}
     if dist is not None:
         red = m.reducer
+        hook_launches = red.launched_last      # of the last timed step (the exchange-free steps below reset it)
         nbytes = sum(bk["flat"].numel() * 4 for bk in red.buckets)
         # the same exchange un-overlapped (all buckets back to back, nothing else running), for the exposed share
         barrier()
@@ -260,7 +261,7 @@ def train_leg(dev, world, rank, dist, steps, warmup):
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         dt, alone, dt_noex = (float(v) for v in tt)
         out["seconds"] = dt
-        out["allreduce"] = {"buckets": len(red.buckets), "launched_from_backward_hooks": red.launched_last,
+        out["allreduce"] = {"buckets": len(red.buckets), "launched_from_backward_hooks": hook_launches,
                             "payload_mb": round(nbytes / 1e6, 1), "standalone_ms": round(alone * 1e3, 3),
                             "bus_gb_s": round(2 * (world - 1) / world * nbytes / alone / 1e9, 1),
                             "step_ms_without_exchange": round(dt_noex / steps * 1e3, 3),

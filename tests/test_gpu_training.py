@@ -260,3 +260,26 @@ def test_finetune_driver_end_to_end(tmp_path):
     cfg.write_text(json.dumps(opt))
     scores = train.main(["-c", str(cfg), "-p", "val", "--root", root])
     assert set(scores) >= {"ssim_WV3", "sam_WV3", "ssim_GF2", "sam_GF2"} and all(np.isfinite(v) for v in scores.values())
+
+
+def test_bench_train_two_ranks_share_the_gpu_over_gloo():
+    """`bench.py --gpus 2 --mode train` as its own launcher: two ranks (sharing the one GPU, gloo instead of RCCL) run the
+    finetune leg with the bucketed all-reduce started from backward hooks; every bucket must go out from a hook and the
+    exchange-free variant must run too.  (RCCL itself needs >= 2 GPUs: the driver's multi-GPU run is its first execution.)"""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT")}
+    env["TMDIFF_BENCH_BACKEND"] = "gloo"
+    p = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--mode", "train", "--steps", "2",
+                        "--warmup", "2"], capture_output=True, text=True, env=env, timeout=600)
+    assert p.returncode == 0, p.stderr[-3000:]
+    lines = [l for l in p.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1
+    line = json.loads(lines[0])
+    ar = line["train_step"]["allreduce"]
+    assert line["n_gpus"] == 2 and line["train_step"]["global_batch"] == 16
+    assert ar["buckets"] >= 3 and ar["launched_from_backward_hooks"] == ar["buckets"]
+    assert 100 < ar["payload_mb"] < 130                      # 216 gradient tensors of the ch 32-256 network, fp32
+    assert np.isfinite(line["train_step"]["loss"]) and line["train_step"]["ms_per_step"] > 0
