@@ -207,6 +207,11 @@ int tmdiff_conv3d_prologue_bwd_ws(const tmdiff_conv3d_desc* d, const float* gp, 
 int tmdiff_stem_fwd(const float* xin, const float* pan, const float* ms, const float* w, const float* bias, float* y,
                     int32_t B, int32_t Cout, int32_t N, int32_t H, int32_t W, int32_t apply_silu,
                     tmdiff_stream_t stream);
+/* The same with the consumer's per-(b, co) modulation folded in: y *= out_scale[b, co] (row stride as in_scale_stride) --
+ * conv21 of the stem block (Hyper_unet_general.py:171) then reads a plain tensor. */
+int tmdiff_stem_fwd_scaled(const float* xin, const float* pan, const float* ms, const float* w, const float* bias,
+                           const float* out_scale, int32_t out_scale_stride, float* y, int32_t B, int32_t Cout, int32_t N,
+                           int32_t H, int32_t W, int32_t apply_silu, tmdiff_stream_t stream);
 int tmdiff_head_fwd(const float* x, const float* w, const float* scale, int32_t scale_stride, float* y, int32_t B,
                     int32_t C, int64_t P, tmdiff_stream_t stream); /* scale_stride as in_scale_stride above */
 /* stem backward: with u = w[co]*x + bias[co], y = SiLU(u): dwb[b, co, 0] = sum_p gy*SiLU'(u)*x and
@@ -240,6 +245,23 @@ int tmdiff_head_bwd(const float* x, const float* w, const float* scale, const fl
  * The adjoint of dwt is idwt and vice versa (orthonormal transform), which is how the
  * backward passes are served.
  * ------------------------------------------------------------------------------------ */
+/* Producer-side prologue: the DWT's LL band / the IDWT's first reconstruction can be written with the CONSUMER convolution's
+ * prologue already applied,  out = act(out + shift[b, c]) * scale[b, c]  (plane = (b * C + c) * n_per_channel + n), so that the
+ * consumer (Conv_1 of a wavelet block, Hyper_unet_general.py:400-406) reads a plain tensor: same bits as applying the
+ * prologue on the consumer side.  Strides as tmdiff_conv3d_desc::in_shift_stride (0 dense = C, > 0 floats, -1 broadcast row). */
+typedef struct tmdiff_plane_prologue {
+  const float* shift; /* [B, C] or NULL */
+  const float* scale; /* [B, C] or NULL */
+  int32_t shift_stride, scale_stride;
+  int32_t C, n_per_channel;
+  int32_t act; /* 0 identity, 1 SiLU */
+} tmdiff_plane_prologue;
+int tmdiff_haar_dwt2d_pro(const float* x, float* ll, float* lh, float* hl, float* hh, int64_t planes, int32_t H, int32_t W,
+                          float ll_scale, float hi_scale, const tmdiff_plane_prologue* ll_prologue, tmdiff_stream_t stream);
+int tmdiff_haar_idwt2d_pro(const float* const ll[2], int32_t n_ll, const float* lh, const float* hl, const float* hh,
+                           int64_t hi_planes_per_batch, int64_t hi_batch_stride, float* const out[2], int64_t planes,
+                           int32_t h, int32_t w, float in_scale, const tmdiff_plane_prologue* out0_prologue,
+                           tmdiff_stream_t stream);
 int tmdiff_haar_dwt2d(const float* x, float* ll, float* lh, float* hl, float* hh, int64_t planes, int32_t H,
                       int32_t W, float ll_scale, float hi_scale, tmdiff_stream_t stream);
 int tmdiff_haar_idwt2d(const float* const ll[2], int32_t n_ll, const float* lh, const float* hl, const float* hh,

@@ -31,6 +31,7 @@ from . import ops
 
 PROMPTS = ("QB", "WV3", "GF2", "WV2", "WV4")
 _EPILOGUE_FUSE = os.environ.get("TMDIFF_EPILOGUE_FUSE", "1") != "0"   # experiments: "0" = consumers apply their own prologue
+_PRODUCER_FUSE = os.environ.get("TMDIFF_PRODUCER_FUSE", "1") != "0"   # experiments: "0" = only the conv20 -> conv21 exchange
 
 
 def synthetic_text_embeddings(seed=1234):
@@ -377,9 +378,25 @@ class WavBEST(nn.Module):
         ptr, stride = P["scale_bank"].slot(S["scale"], name)
         return {"in_scale": ptr, "scale_stride": stride}
 
-    def _resblock(self, P, S, name, segs, flag):
+    # Producer-side prologues (fp32 inference): wherever a tensor has ONE convolution as its consumer, the kernel that
+    # produces it also writes the consumer's prologue output act(y + shift) * scale (a second output of a convolution's
+    # epilogue, the LL band of a DWT, the first reconstruction of an IDWT, the stem), so the consumer is a plain-input
+    # convolution: it runs on the staged kernel (operands by LDS-DMA, matrix pipe busy 0.85-0.89 at 2.3 GHz against
+    # 0.74-0.83 at 2.1 GHz for the kernel that applies the prologue while staging) without a prologue pass.  Same bits
+    # as the consumer-side prologue.  `pre` = such a tensor for a block's first convolution; `emit` = the prologue spec
+    # of the block's consumer.  Multi-segment consumers (the up path's conv20) keep their own prologue pass.
+    def _spec(self, P, S, shift=None, scale=None, act=True):
+        d = {"act": act}
+        if shift is not None:
+            d["shift"], d["shift_stride"] = P["shift_bank"].slot(S["shift"], shift)
+        if scale is not None:
+            d["scale"], d["scale_stride"] = P["scale_bank"].slot(S["scale"], scale)
+        return d
+
+    def _resblock(self, P, S, name, segs, flag, pre=None, emit=None):
         """ResBlockModulateBEST (ref :237-249): conv20 with fused (shift,) SiLU; optional 1x1x1
-        res_conv; conv21 with fused SiLU + text modulation + residual add."""
+        res_conv; conv21 with fused SiLU + text modulation + residual add.  Returns (y, y2): y2 = `emit` applied to y
+        (None without emit)."""
         rb = self.get_submodule(name)
         sh = {} if flag else self._shift(P, S, name + ".dense1")
         res = self._conv(P, name + ".res_conv", segs) if isinstance(rb.res_conv, nn.Conv3d) else segs[0]
@@ -388,34 +405,55 @@ class WavBEST(nn.Module):
         # reads that directly -- a plain fp32 tensor for the staged kernel, or the packed bf16 units in the bf16 mode
         # (no prologue / pack pass in between; same bits either way)
         both16 = name + ".conv20" in P["bf16"] and name + ".conv21" in P["bf16"]
+        kw = {} if emit is None else {"emit": emit}
         if _EPILOGUE_FUSE and (both16 or (name + ".conv20" not in P["bf16"] and name + ".conv21" not in P["bf16"])):
-            t1p = self._conv(P, name + ".conv20", segs, in_act=True, keep_y=False,
-                             emit=dict(act=True, scale=sc["in_scale"], scale_stride=sc["scale_stride"]), **sh)
+            mid = dict(act=True, scale=sc["in_scale"], scale_stride=sc["scale_stride"])
+            if pre is not None:
+                t1p = self._conv(P, name + ".conv20", [pre], keep_y=False, emit=mid)
+            else:
+                t1p = self._conv(P, name + ".conv20", segs, in_act=True, keep_y=False, emit=mid, **sh)
             shape = tuple(res.shape[2:]) if both16 else None
-            return self._conv(P, name + ".conv21", [t1p], use_bias=False, residual=res, x_bf16_shape=shape)
-        t1 = self._conv(P, name + ".conv20", segs, in_act=True, **sh)
-        return self._conv(P, name + ".conv21", [t1], use_bias=False, in_act=True, residual=res, **sc)
+            out = self._conv(P, name + ".conv21", [t1p], use_bias=False, residual=res, x_bf16_shape=shape, **kw)
+        else:
+            assert pre is None
+            t1 = self._conv(P, name + ".conv20", segs, in_act=True, **sh)
+            out = self._conv(P, name + ".conv21", [t1], use_bias=False, in_act=True, residual=res, **sc, **kw)
+        return out if emit is not None else (out, None)
 
-    def _down(self, P, S, name, x, flag, want_high):
+    def _down(self, P, S, name, x, flag, want_high, pre=None, emit=None, fuse=False):
         """WaveletUPorDown(down=True) (ref :369-414); /2 folded into the DWT, LL-only when the
-        caller drops the high bands."""
-        hh = self._conv(P, name + ".Conv_0", [x], in_act=True)
+        caller drops the high bands.  Returns (out, out2, bands)."""
+        hh = self._conv(P, name + ".Conv_0", [pre]) if pre is not None else self._conv(P, name + ".Conv_0", [x], in_act=True)
         xx = self._conv(P, name + ".Conv_2", [x])
-        hll, lh, hl, hhh = ops.haar_dwt2d(hh, want_high=want_high, ll_scale=0.5)
         xll = ops.haar_dwt2d(xx, want_high=False, ll_scale=0.5)[0]
-        sh = {} if flag else self._shift(P, S, name + ".Dense_0")
-        out = self._conv(P, name + ".Conv_1", [hll], use_bias=False, in_act=True, residual=xll,
-                         **self._scale(P, S, name + ".dense1"), **sh)
-        return out, (lh, hl, hhh)
+        kw = {} if emit is None else {"emit": emit}
+        if fuse:   # Conv_1's prologue (shift, SiLU, text modulation) is applied to the LL band where the DWT writes it
+            pro = self._spec(P, S, shift=None if flag else name + ".Dense_0", scale=name + ".dense1")
+            hll, lh, hl, hhh = ops.haar_dwt2d(hh, want_high=want_high, ll_scale=0.5, ll_prologue=pro)
+            out = self._conv(P, name + ".Conv_1", [hll], use_bias=False, residual=xll, **kw)
+        else:
+            hll, lh, hl, hhh = ops.haar_dwt2d(hh, want_high=want_high, ll_scale=0.5)
+            sh = {} if flag else self._shift(P, S, name + ".Dense_0")
+            out = self._conv(P, name + ".Conv_1", [hll], use_bias=False, in_act=True, residual=xll,
+                             **self._scale(P, S, name + ".dense1"), **sh, **kw)
+        out, out2 = out if emit is not None else (out, None)
+        return out, out2, (lh, hl, hhh)
 
-    def _up(self, P, S, name, x, bands):
+    def _up(self, P, S, name, x, bands, pre=None, fuse=False):
         """WaveletUPorDown(up=True) (ref :379-386, :398-408); ``bands`` = convH_0 output
         [B, 3C, N, h, w], step-invariant and cached with the condition branch."""
-        hh = self._conv(P, name + ".Conv_0", [x], in_act=True)
+        hh = self._conv(P, name + ".Conv_0", [pre]) if pre is not None else self._conv(P, name + ".Conv_0", [x], in_act=True)
         xx = self._conv(P, name + ".Conv_2", [x])
+        if fuse:   # Conv_1's prologue applied to the h reconstruction where the IDWT writes it
+            pro = self._spec(P, S, shift=name + ".Dense_0", scale=name + ".dense1")
+            h_up, x_up = ops.haar_idwt2d([hh, xx], None, None, None, in_scale=2.0, stacked_bands=bands, out0_prologue=pro)
+            return self._conv(P, name + ".Conv_1", [h_up], use_bias=False, residual=x_up)
         h_up, x_up = ops.haar_idwt2d([hh, xx], None, None, None, in_scale=2.0, stacked_bands=bands)
         return self._conv(P, name + ".Conv_1", [h_up], use_bias=False, in_act=True, residual=x_up,
                           **self._shift(P, S, name + ".Dense_0"), **self._scale(P, S, name + ".dense1"))
+
+    def _producer_fuse(self):
+        return _PRODUCER_FUSE and self.compute_dtype == "fp32"
 
     # ---- condition branch (independent of x_t and t) -------------------------------------------------
     def _prompt_rows(self, prompt, batch, device):
@@ -445,13 +483,22 @@ class WavBEST(nn.Module):
         pemb = lin(4, lin(2, lin(0, pe)))                 # act(embed2(prompt)) -- one row per distinct prompt row
         S = {"scale": P["scale_bank"].run(pemb)}
         c0 = self.channels[0]
-        a0 = ops.stem(self.conv1.conv20.weight.detach().reshape(-1), self.conv1.conv20.bias.detach(), c0,
-                      pan=PAN.contiguous(), ms=MS.contiguous())
-        h = self._conv(P, "conv1.conv21", [a0], use_bias=False, **self._scale(P, S, "conv1.dense2"))
+        fuse = self._producer_fuse()
+        spec = lambda **k: self._spec(P, S, **k) if fuse else None
+        w0, b0 = self.conv1.conv20.weight.detach().reshape(-1), self.conv1.conv20.bias.detach()
+        if fuse:    # the stem writes conv21's modulated input; conv21's epilogue writes SiLU(h) for down1_1.conv20 (flag: no shift)
+            osc, oss = P["scale_bank"].slot(S["scale"], "conv1.dense2")
+            a0 = ops.stem(w0, b0, c0, pan=PAN.contiguous(), ms=MS.contiguous(), out_scale=osc, out_scale_stride=oss)
+            h, hp = self._conv(P, "conv1.conv21", [a0], use_bias=False, emit=spec())
+        else:
+            a0 = ops.stem(w0, b0, c0, pan=PAN.contiguous(), ms=MS.contiguous())
+            h, hp = self._conv(P, "conv1.conv21", [a0], use_bias=False, **self._scale(P, S, "conv1.dense2")), None
         cond = {"h0": h, "pan": PAN, "ms": MS, "prompt": prompt, "scale": S["scale"]}
         for lvl, (dn, upn) in enumerate((("down1_1", "up3"), ("down2_1", "up2"), ("down3_1", "up1")), start=1):
-            h = self._resblock(P, S, dn + ".conv20", [h], flag=True)
-            h, skip = self._down(P, S, dn + ".down", h, flag=True, want_high=True)
+            h, ha = self._resblock(P, S, dn + ".conv20", [h], flag=True, pre=hp, emit=spec())
+            # (the last level's output only feeds the up path's three-segment conv20: nothing to emit)
+            h, hp, skip = self._down(P, S, dn + ".down", h, flag=True, want_high=True, pre=ha,
+                                     emit=spec() if lvl < 3 else None, fuse=fuse)
             cond[f"h{lvl}"] = h
             # convH_0(cat(skipH)/2)*2 == grouped conv of the three bands + 2*bias (exact: powers of two)
             cond[f"bands{lvl}"] = self._conv(P, upn + ".up1.convH_0.0", list(skip), bias_scale=2.0)
@@ -503,21 +550,30 @@ class WavBEST(nn.Module):
         temb = ops.linear(e, self.embed[2].weight.detach(), self.embed[2].bias.detach(), act=True)
         S = {"shift": P["shift_bank"].run(temb), "scale": cond["scale"]}
 
-        a0 = ops.stem(self.conv2.conv20.weight.detach().reshape(-1), self.conv2.conv20.bias.detach(),
-                      self.channels[0], xin=x_t.contiguous())
-        h = self._conv(P, "conv2.conv21", [a0], use_bias=False, **self._scale(P, S, "conv2.dense2"))
+        fuse = self._producer_fuse()
+        spec = lambda **k: self._spec(P, S, **k) if fuse else None
+        w0, b0 = self.conv2.conv20.weight.detach().reshape(-1), self.conv2.conv20.bias.detach()
+        if fuse:
+            osc, oss = P["scale_bank"].slot(S["scale"], "conv2.dense2")
+            a0 = ops.stem(w0, b0, self.channels[0], xin=x_t.contiguous(), out_scale=osc, out_scale_stride=oss)
+            h, hp = self._conv(P, "conv2.conv21", [a0], use_bias=False, emit=spec(shift="down1.conv20.dense1"))
+        else:
+            a0 = ops.stem(w0, b0, self.channels[0], xin=x_t.contiguous())
+            h, hp = self._conv(P, "conv2.conv21", [a0], use_bias=False, **self._scale(P, S, "conv2.dense2")), None
         hs = [h]
-        for dn in ("down1", "down2", "down3"):
-            h = self._resblock(P, S, dn + ".conv20", [h], flag=False)
-            h, _ = self._down(P, S, dn + ".down", h, flag=False, want_high=False)
+        for dn, nxt in (("down1", "down2.conv20"), ("down2", "down3.conv20"), ("down3", "middle1")):
+            h, ha = self._resblock(P, S, dn + ".conv20", [h], flag=False, pre=hp, emit=spec())
+            h, hp, _ = self._down(P, S, dn + ".down", h, flag=False, want_high=False, pre=ha,
+                                  emit=spec(shift=nxt + ".dense1"), fuse=fuse)
             hs.append(h)
-        h = self._resblock(P, S, "middle1", [hs[3]], flag=False)
+        h, _ = self._resblock(P, S, "middle1", [hs[3]], flag=False, pre=hp)
         for lvl, upn in ((3, "up1"), (2, "up2"), (1, "up3")):
-            h = self._resblock(P, S, upn + ".conv20", [h, cond[f"h{lvl}"], hs[lvl]], flag=False)
-            h = self._up(P, S, upn + ".up1", h, cond[f"bands{lvl}"])
-        h = self._resblock(P, S, "final.conv20", [h, cond["h0"], hs[0]], flag=False)
+            h, ha = self._resblock(P, S, upn + ".conv20", [h, cond[f"h{lvl}"], hs[lvl]], flag=False, emit=spec())
+            h = self._up(P, S, upn + ".up1", h, cond[f"bands{lvl}"], pre=ha, fuse=fuse)
+        h, hp = self._resblock(P, S, "final.conv20", [h, cond["h0"], hs[0]], flag=False, emit=spec(shift="final.conv21.dense1"))
         for k in (1, 2, 3):
-            h = self._resblock(P, S, f"final.conv2{k}", [h], flag=False)
+            h, hp = self._resblock(P, S, f"final.conv2{k}", [h], flag=False, pre=hp,
+                                   emit=spec(shift=f"final.conv2{k + 1}.dense1") if k < 3 else None)
         sc = self._scale(P, S, "final.dense2")
         return ops.head(h, self.final.conv24.weight.detach().reshape(-1), sc["in_scale"], sc["scale_stride"])
 

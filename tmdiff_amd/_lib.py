@@ -102,6 +102,22 @@ SIGNATURES = {
 }
 
 
+class PlanePrologue(C.Structure):
+    """struct tmdiff_plane_prologue"""
+    _fields_ = [("shift", vp), ("scale", vp), ("shift_stride", C.c_int32), ("scale_stride", C.c_int32),
+                ("C", C.c_int32), ("n_per_channel", C.c_int32), ("act", C.c_int32)]
+
+
+SIGNATURES.update({
+    "tmdiff_haar_dwt2d_pro": (C.c_int, [vp, vp, vp, vp, vp, C.c_int64, C.c_int32, C.c_int32, C.c_float, C.c_float,
+                                        C.POINTER(PlanePrologue), vp]),
+    "tmdiff_haar_idwt2d_pro": (C.c_int, [vp * 2, C.c_int32, vp, vp, vp, C.c_int64, C.c_int64, vp * 2, C.c_int64,
+                                         C.c_int32, C.c_int32, C.c_float, C.POINTER(PlanePrologue), vp]),
+    "tmdiff_stem_fwd_scaled": (C.c_int, [vp, vp, vp, vp, vp, vp, C.c_int32, vp, C.c_int32, C.c_int32, C.c_int32, C.c_int32,
+                                         C.c_int32, C.c_int32, vp]),
+})
+
+
 class TmdiffError(RuntimeError):
     """Non-zero status from the C ABI (the reference surfaces errors as ordinary exceptions)."""
 

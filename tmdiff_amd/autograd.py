@@ -47,7 +47,7 @@ class _FusedConv3d(torch.autograd.Function):
         # a 3x3x3 convolution with dropout runs as prologue pass + staged kernel anyway: let the pass write x' into a
         # tensor of its own and keep it -- the weight gradient then needs no prologue pass of its own
         xp = None
-        if ksize == 3 and (drop is not None or mask is not None) and weight.requires_grad:
+        if ksize == 3 and (drop is not None or mask is not None) and ctx.needs_input_grad[1]:
             b, _, n, h, wd = segs[0].shape
             cin = sum(s.shape[1] for s in segs)
             if cin % groups == 0 and (cin // groups) % 4 == 0 and (cout // groups) % 32 == 0:   # shapes the staged kernel takes

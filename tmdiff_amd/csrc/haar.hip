@@ -47,11 +47,33 @@ __device__ __forceinline__ void inv_butterfly(float ll, float lh, float hl, floa
 }
 
 // One thread -> V adjacent output columns of one output row.  grid-stride over all outputs.
+// Optional consumer prologue on one output (the LL band of the DWT, the first reconstruction of the IDWT):
+//   out = act(out + shift[b, c]) * scale[b, c]   with plane = (b * C + c) * n_per_channel + band-plane index
+// -- the convolution that consumes that tensor then reads it as a plain input (no prologue pass, no hand-off).
+struct PlanePrologue {
+  const float* shift;
+  const float* scale;
+  int shift_stride, scale_stride;  // row strides in floats (0 = one row broadcast over the batch)
+  int C, n_per_channel, act, on;
+};
+
+__device__ __forceinline__ void prologue_coefs(const PlanePrologue& p, long plane, float& sh, float& sc) {
+  const long bc = plane / p.n_per_channel;
+  const int b = (int)(bc / p.C), c = (int)(bc % p.C);
+  sh = p.shift ? p.shift[(long)b * p.shift_stride + c] : 0.f;
+  sc = p.scale ? p.scale[(long)b * p.scale_stride + c] : 1.f;
+}
+__device__ __forceinline__ float apply_prologue(int act, float sh, float sc, float v) {   // as the conv kernels' prologue
+  float t = v + sh;
+  const float ta = tmdiff::silu_f(t);
+  return (act ? ta : t) * sc;
+}
+
 template <int V>
 __global__ void __launch_bounds__(256) dwt2d_kernel(const float* __restrict__ x, float* __restrict__ ll,
                                                     float* __restrict__ lh, float* __restrict__ hl,
                                                     float* __restrict__ hh, long total, int h, int w, float ll_scale,
-                                                    float hi_scale) {
+                                                    float hi_scale, const PlanePrologue pro) {
   const int wv = w / V;  // vector columns per output row
   const int W = 2 * w;
   for (long i = blockIdx.x * 256L + threadIdx.x; i < total; i += 256L * gridDim.x) {
@@ -78,11 +100,19 @@ __global__ void __launch_bounds__(256) dwt2d_kernel(const float* __restrict__ x,
     for (int band = 0; band < 4; ++band) {
       if (outs[band] == nullptr) continue;
       const float sc = band == 0 ? ll_scale : hi_scale;
+      float v[V];
+#pragma unroll
+      for (int k = 0; k < V; ++k) v[k] = sc * o[band][k];
+      if (band == 0 && pro.on) {
+        float sh, scl;
+        prologue_coefs(pro, plane, sh, scl);
+#pragma unroll
+        for (int k = 0; k < V; ++k) v[k] = apply_prologue(pro.act, sh, scl, v[k]);
+      }
       if constexpr (V == 4) {
-        *reinterpret_cast<float4*>(outs[band] + off) =
-            make_float4(sc * o[band][0], sc * o[band][1], sc * o[band][2], sc * o[band][3]);
+        *reinterpret_cast<float4*>(outs[band] + off) = make_float4(v[0], v[1], v[2], v[3]);
       } else {
-        outs[band][off] = sc * o[band][0];
+        outs[band][off] = v[0];
       }
     }
   }
@@ -93,7 +123,8 @@ __global__ void __launch_bounds__(256) idwt2d_kernel(const float* __restrict__ l
                                                      const float* __restrict__ lh, const float* __restrict__ hl,
                                                      const float* __restrict__ hh, float* __restrict__ out0,
                                                      float* __restrict__ out1, long total, int h, int w,
-                                                     float in_scale, long hi_ppb, long hi_bstride) {
+                                                     float in_scale, long hi_ppb, long hi_bstride,
+                                                     const PlanePrologue pro) {
   const int wv = w / V;
   const int W = 2 * w;
   for (long i = blockIdx.x * 256L + threadIdx.x; i < total; i += 256L * gridDim.x) {
@@ -128,6 +159,12 @@ __global__ void __launch_bounds__(256) idwt2d_kernel(const float* __restrict__ l
       }
 #pragma unroll
       for (int c = 0; c < V; ++c) inv_butterfly(in_scale * b0[c], b1[c], b2[c], b3[c], t[2 * c], t[2 * c + 1], bt[2 * c], bt[2 * c + 1]);
+      if (k == 0 && pro.on) {
+        float sh, scl;
+        prologue_coefs(pro, plane, sh, scl);
+#pragma unroll
+        for (int c = 0; c < 2 * V; ++c) t[c] = apply_prologue(pro.act, sh, scl, t[c]), bt[c] = apply_prologue(pro.act, sh, scl, bt[c]);
+      }
       float* top = outs[k] + (plane * 2 * h + 2 * r) * W + 2 * V * j;
       float* bot = top + W;
       if constexpr (V == 4) {
@@ -149,9 +186,30 @@ inline int grid_for(long total) {
 
 }  // namespace
 
+namespace {
+int make_prologue(const tmdiff_plane_prologue* p, int64_t planes, PlanePrologue& q) {
+  q = PlanePrologue{nullptr, nullptr, 0, 0, 1, 1, 0, 0};
+  if (!p) return TMDIFF_OK;
+  TMDIFF_REQUIRE(p->C > 0 && p->n_per_channel > 0 && planes % ((int64_t)p->C * p->n_per_channel) == 0,
+                 "haar prologue: planes=%ld is not B * C=%d * n=%d", (long)planes, p->C, p->n_per_channel);
+  q.shift = p->shift; q.scale = p->scale; q.C = p->C; q.n_per_channel = p->n_per_channel; q.act = p->act; q.on = 1;
+  q.shift_stride = p->shift_stride > 0 ? p->shift_stride : (p->shift_stride < 0 ? 0 : p->C);
+  q.scale_stride = p->scale_stride > 0 ? p->scale_stride : (p->scale_stride < 0 ? 0 : p->C);
+  return TMDIFF_OK;
+}
+}  // namespace
+
 extern "C" int tmdiff_haar_dwt2d(const float* x, float* ll, float* lh, float* hl, float* hh, int64_t planes, int32_t H,
                                  int32_t W, float ll_scale, float hi_scale, tmdiff_stream_t stream) {
+  return tmdiff_haar_dwt2d_pro(x, ll, lh, hl, hh, planes, H, W, ll_scale, hi_scale, nullptr, stream);
+}
+
+extern "C" int tmdiff_haar_dwt2d_pro(const float* x, float* ll, float* lh, float* hl, float* hh, int64_t planes, int32_t H,
+                                     int32_t W, float ll_scale, float hi_scale, const tmdiff_plane_prologue* ll_prologue,
+                                     tmdiff_stream_t stream) {
   using namespace tmdiff;
+  PlanePrologue pro;
+  if (int rc = make_prologue(ll_prologue, planes, pro)) return rc;
   TMDIFF_REQUIRE(x && ll, "haar_dwt2d: x and ll must not be NULL");
   TMDIFF_REQUIRE(planes >= 0 && H > 0 && W > 0 && H % 2 == 0 && W % 2 == 0, "haar_dwt2d: H=%d W=%d must be positive and even",
                  H, W);
@@ -160,10 +218,10 @@ extern "C" int tmdiff_haar_dwt2d(const float* x, float* ll, float* lh, float* hl
   const bool vec = (w % 4 == 0) && aligned16(x) && aligned16(ll) && aligned16(lh) && aligned16(hl) && aligned16(hh);
   if (vec) {
     const long total = planes * h * (w / 4);
-    dwt2d_kernel<4><<<grid_for(total), 256, 0, as_stream(stream)>>>(x, ll, lh, hl, hh, total, h, w, ll_scale, hi_scale);
+    dwt2d_kernel<4><<<grid_for(total), 256, 0, as_stream(stream)>>>(x, ll, lh, hl, hh, total, h, w, ll_scale, hi_scale, pro);
   } else {
     const long total = planes * h * w;
-    dwt2d_kernel<1><<<grid_for(total), 256, 0, as_stream(stream)>>>(x, ll, lh, hl, hh, total, h, w, ll_scale, hi_scale);
+    dwt2d_kernel<1><<<grid_for(total), 256, 0, as_stream(stream)>>>(x, ll, lh, hl, hh, total, h, w, ll_scale, hi_scale, pro);
   }
   return check_launch("haar_dwt2d");
 }
@@ -172,7 +230,17 @@ extern "C" int tmdiff_haar_idwt2d(const float* const ll[2], int32_t n_ll, const 
                                   const float* hh, int64_t hi_planes_per_batch, int64_t hi_batch_stride,
                                   float* const out[2], int64_t planes, int32_t h, int32_t w, float in_scale,
                                   tmdiff_stream_t stream) {
+  return tmdiff_haar_idwt2d_pro(ll, n_ll, lh, hl, hh, hi_planes_per_batch, hi_batch_stride, out, planes, h, w, in_scale,
+                                nullptr, stream);
+}
+
+extern "C" int tmdiff_haar_idwt2d_pro(const float* const ll[2], int32_t n_ll, const float* lh, const float* hl,
+                                      const float* hh, int64_t hi_planes_per_batch, int64_t hi_batch_stride,
+                                      float* const out[2], int64_t planes, int32_t h, int32_t w, float in_scale,
+                                      const tmdiff_plane_prologue* out0_prologue, tmdiff_stream_t stream) {
   using namespace tmdiff;
+  PlanePrologue pro;
+  if (int rc = make_prologue(out0_prologue, planes, pro)) return rc;
   TMDIFF_REQUIRE(n_ll == 1 || n_ll == 2, "haar_idwt2d: n_ll=%d must be 1 or 2", n_ll);
   TMDIFF_REQUIRE(ll && out && ll[0] && out[0], "haar_idwt2d: NULL band/output");
   TMDIFF_REQUIRE((lh && hl && hh) || (!lh && !hl && !hh), "haar_idwt2d: give all three high bands or none");
@@ -190,11 +258,11 @@ extern "C" int tmdiff_haar_idwt2d(const float* const ll[2], int32_t n_ll, const 
   if (vec) {
     const long total = planes * h * (w / 4);
     idwt2d_kernel<4><<<grid_for(total), 256, 0, as_stream(stream)>>>(ll[0], ll1, lh, hl, hh, out[0], out1, total, h, w, in_scale,
-                                                                     hi_planes_per_batch, hi_batch_stride);
+                                                                     hi_planes_per_batch, hi_batch_stride, pro);
   } else {
     const long total = planes * h * w;
     idwt2d_kernel<1><<<grid_for(total), 256, 0, as_stream(stream)>>>(ll[0], ll1, lh, hl, hh, out[0], out1, total, h, w, in_scale,
-                                                                     hi_planes_per_batch, hi_batch_stride);
+                                                                     hi_planes_per_batch, hi_batch_stride, pro);
   }
   return check_launch("haar_idwt2d");
 }

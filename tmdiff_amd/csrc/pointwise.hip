@@ -15,7 +15,8 @@ template <int V>
 __global__ void __launch_bounds__(256) stem_kernel(const float* __restrict__ xin, const float* __restrict__ pan,
                                                    const float* __restrict__ ms, const float* __restrict__ w,
                                                    const float* __restrict__ bias, float* __restrict__ y, int Cout,
-                                                   long P, long HW, int act) {
+                                                   long P, long HW, int act, const float* __restrict__ oscale,
+                                                   int oscale_stride) {
   const long pv = (blockIdx.x * 256L + threadIdx.x) * V;
   const int b = blockIdx.y;
   if (pv >= P) return;
@@ -44,6 +45,11 @@ __global__ void __launch_bounds__(256) stem_kernel(const float* __restrict__ xin
     for (int k = 0; k < V; ++k) {
       o[k] = __fadd_rn(__fmul_rn(wc, x[k]), bc);
       if (act) o[k] = tmdiff::silu_f(o[k]);
+    }
+    if (oscale) {  // the consumer's modulation (conv21 of the stem block) applied where the value is produced
+      const float sc = oscale[(long)b * oscale_stride + co];
+#pragma unroll
+      for (int k = 0; k < V; ++k) o[k] *= sc;
     }
     float* dst = y + ((long)b * Cout + co) * P + pv;
     if constexpr (V == 4)
@@ -137,7 +143,14 @@ __global__ void __launch_bounds__(256) gamma_kernel(const float* __restrict__ t,
 extern "C" int tmdiff_stem_fwd(const float* xin, const float* pan, const float* ms, const float* w, const float* bias,
                                float* y, int32_t B, int32_t Cout, int32_t N, int32_t H, int32_t W, int32_t apply_silu,
                                tmdiff_stream_t stream) {
+  return tmdiff_stem_fwd_scaled(xin, pan, ms, w, bias, nullptr, 0, y, B, Cout, N, H, W, apply_silu, stream);
+}
+
+extern "C" int tmdiff_stem_fwd_scaled(const float* xin, const float* pan, const float* ms, const float* w, const float* bias,
+                                      const float* out_scale, int32_t out_scale_stride, float* y, int32_t B, int32_t Cout,
+                                      int32_t N, int32_t H, int32_t W, int32_t apply_silu, tmdiff_stream_t stream) {
   using namespace tmdiff;
+  const int oss = out_scale_stride > 0 ? out_scale_stride : (out_scale_stride < 0 ? 0 : Cout);
   TMDIFF_REQUIRE(w && y, "stem_fwd: NULL weights/output");
   TMDIFF_REQUIRE((ms && pan) || (!ms && xin), "stem_fwd: give either (pan, ms) or xin");
   TMDIFF_REQUIRE(B >= 0 && Cout > 0 && N > 0 && H > 0 && W > 0 && B <= 65535, "stem_fwd: bad extents");
@@ -146,10 +159,10 @@ extern "C" int tmdiff_stem_fwd(const float* xin, const float* pan, const float* 
   const bool vec = HW % 4 == 0 && aligned16(xin) && aligned16(pan) && aligned16(ms) && aligned16(y);
   if (vec) {
     dim3 grid((unsigned)((P / 4 + 255) / 256), B);
-    stem_kernel<4><<<grid, 256, 0, as_stream(stream)>>>(xin, pan, ms, w, bias, y, Cout, P, HW, apply_silu);
+    stem_kernel<4><<<grid, 256, 0, as_stream(stream)>>>(xin, pan, ms, w, bias, y, Cout, P, HW, apply_silu, out_scale, oss);
   } else {
     dim3 grid((unsigned)((P + 255) / 256), B);
-    stem_kernel<1><<<grid, 256, 0, as_stream(stream)>>>(xin, pan, ms, w, bias, y, Cout, P, HW, apply_silu);
+    stem_kernel<1><<<grid, 256, 0, as_stream(stream)>>>(xin, pan, ms, w, bias, y, Cout, P, HW, apply_silu, out_scale, oss);
   }
   return check_launch("stem_fwd");
 }

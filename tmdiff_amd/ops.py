@@ -307,12 +307,16 @@ def conv3d(segs, w_packed, cout, ksize, out=None, math="fp32", pack_input=None, 
     return ret
 
 
-def stem(w, bias, out_channels, xin=None, pan=None, ms=None, silu=True, out=None):
+def stem(w, bias, out_channels, xin=None, pan=None, ms=None, silu=True, out=None, out_scale=None, out_scale_stride=0):
+    """out_scale (tensor [B, C0] or a raw pointer into a projection bank, row stride out_scale_stride): the consumer's
+    modulation folded into the stem's output."""
     ref = ms if ms is not None else xin
     b, n, h, wd = ref.shape
     y = out if out is not None else torch.empty(b, out_channels, n, h, wd, device=ref.device, dtype=torch.float32)
-    check(lib.tmdiff_stem_fwd(_chk(xin, "xin"), _chk(pan, "pan"), _chk(ms, "ms"), _chk(w, "w"), _chk(bias, "bias"),
-                              _chk(y, "y"), b, out_channels, n, h, wd, 1 if silu else 0, stream_ptr()), "stem_fwd")
+    osc = out_scale if isinstance(out_scale, int) else _chk(out_scale, "out_scale")
+    check(lib.tmdiff_stem_fwd_scaled(_chk(xin, "xin"), _chk(pan, "pan"), _chk(ms, "ms"), _chk(w, "w"), _chk(bias, "bias"),
+                                     osc, out_scale_stride, _chk(y, "y"), b, out_channels, n, h, wd, 1 if silu else 0,
+                                     stream_ptr()), "stem_fwd")
     return y
 
 
@@ -324,22 +328,39 @@ def head(x, w, scale, scale_stride=0, out=None):
     return y
 
 
-def haar_dwt2d(x, want_high=True, ll_scale=1.0, hi_scale=1.0, outs=None):
-    """x [..., H, W] -> (ll, lh, hl, hh); the high bands are None when want_high is False."""
+def _plane_prologue(pro, channels, n_per_channel):
+    """pro = dict(act=, shift=, scale=, shift_stride=, scale_stride=) (tensors or raw bank pointers) -> ctypes struct"""
+    if pro is None:
+        return None
+    q = _lib.PlanePrologue()
+    q.shift = pro.get("shift") if isinstance(pro.get("shift"), int) else _chk(pro.get("shift"), "prologue shift")
+    q.scale = pro.get("scale") if isinstance(pro.get("scale"), int) else _chk(pro.get("scale"), "prologue scale")
+    q.shift_stride, q.scale_stride = pro.get("shift_stride", 0), pro.get("scale_stride", 0)
+    q.C, q.n_per_channel, q.act = channels, n_per_channel, 1 if pro.get("act") else 0
+    return C.byref(q)
+
+
+def haar_dwt2d(x, want_high=True, ll_scale=1.0, hi_scale=1.0, outs=None, ll_prologue=None):
+    """x [..., H, W] -> (ll, lh, hl, hh); the high bands are None when want_high is False.
+    ll_prologue (x must then be [B, C, N, H, W]): the consumer convolution's prologue applied to the LL band as it is
+    written -- dict(act=, shift=, scale=, shift_stride=, scale_stride=), per (b, c)."""
     hh_, ww = x.shape[-2:]
     planes = x.numel() // (hh_ * ww)
     shape = (*x.shape[:-2], hh_ // 2, ww // 2)
     if outs is None:
         outs = [torch.empty(shape, device=x.device, dtype=torch.float32) for _ in range(4 if want_high else 1)]
     ptrs = [_chk(o, "band") for o in outs] + [None] * (4 - len(outs))
-    check(lib.tmdiff_haar_dwt2d(_chk(x, "x"), *ptrs, planes, hh_, ww, ll_scale, hi_scale, stream_ptr()), "haar_dwt2d")
+    pro = _plane_prologue(ll_prologue, x.shape[1], x.shape[2]) if ll_prologue is not None else None
+    check(lib.tmdiff_haar_dwt2d_pro(_chk(x, "x"), *ptrs, planes, hh_, ww, ll_scale, hi_scale, pro, stream_ptr()),
+          "haar_dwt2d")
     return tuple(outs) + (None,) * (4 - len(outs))
 
 
-def haar_idwt2d(lls, lh, hl, hh, in_scale=1.0, outs=None, stacked_bands=None):
+def haar_idwt2d(lls, lh, hl, hh, in_scale=1.0, outs=None, stacked_bands=None, out0_prologue=None):
     """lls: list of 1 or 2 low bands sharing the high bands; returns a list of reconstructions.
     ``stacked_bands`` [B, 3C, N, h, w] (the convH_0 output) supplies lh/hl/hh as channel slices
-    without copying them out."""
+    without copying them out.  out0_prologue (lls[0] must then be [B, C, N, h, w]): the consumer convolution's prologue
+    applied to the first reconstruction as it is written (see haar_dwt2d)."""
     ll0 = lls[0]
     h, w = ll0.shape[-2:]
     planes = ll0.numel() // (h * w)
@@ -357,7 +378,8 @@ def haar_idwt2d(lls, lh, hl, hh, in_scale=1.0, outs=None, stacked_bands=None):
         hp = (base, base + step, base + 2 * step, ppb, 3 * ppb * h * w)
     else:
         hp = (_chk(lh, "lh"), _chk(hl, "hl"), _chk(hh, "hh"), 0, 0)
-    check(lib.tmdiff_haar_idwt2d(llp, len(lls), *hp, outp, planes, h, w, in_scale, stream_ptr()), "haar_idwt2d")
+    pro = _plane_prologue(out0_prologue, ll0.shape[1], ll0.shape[2]) if out0_prologue is not None else None
+    check(lib.tmdiff_haar_idwt2d_pro(llp, len(lls), *hp, outp, planes, h, w, in_scale, pro, stream_ptr()), "haar_idwt2d")
     return outs
 
 
