@@ -408,8 +408,9 @@ class WavBEST(nn.Module):
         kw = {} if emit is None else {"emit": emit}
         if _EPILOGUE_FUSE and (both16 or (name + ".conv20" not in P["bf16"] and name + ".conv21" not in P["bf16"])):
             mid = dict(act=True, scale=sc["in_scale"], scale_stride=sc["scale_stride"])
-            if pre is not None:
-                t1p = self._conv(P, name + ".conv20", [pre], keep_y=False, emit=mid)
+            if pre is not None:     # (bf16 mode: `pre` is the packed bf16 form a bf16 producer wrote)
+                t1p = self._conv(P, name + ".conv20", [pre], keep_y=False, emit=mid,
+                                 x_bf16_shape=tuple(res.shape[2:]) if pre.dtype == torch.int16 else None)
             else:
                 t1p = self._conv(P, name + ".conv20", segs, in_act=True, keep_y=False, emit=mid, **sh)
             shape = tuple(res.shape[2:]) if both16 else None
@@ -420,10 +421,16 @@ class WavBEST(nn.Module):
             out = self._conv(P, name + ".conv21", [t1], use_bias=False, in_act=True, residual=res, **sc, **kw)
         return out if emit is not None else (out, None)
 
+    def _conv0(self, P, name, x, pre):
+        """Conv_0 of a wavelet block on SiLU(x): from the producer's second output when there is one."""
+        if pre is None:
+            return self._conv(P, name + ".Conv_0", [x], in_act=True)
+        return self._conv(P, name + ".Conv_0", [pre], x_bf16_shape=tuple(x.shape[2:]) if pre.dtype == torch.int16 else None)
+
     def _down(self, P, S, name, x, flag, want_high, pre=None, emit=None, fuse=False):
         """WaveletUPorDown(down=True) (ref :369-414); /2 folded into the DWT, LL-only when the
         caller drops the high bands.  Returns (out, out2, bands)."""
-        hh = self._conv(P, name + ".Conv_0", [pre]) if pre is not None else self._conv(P, name + ".Conv_0", [x], in_act=True)
+        hh = self._conv0(P, name, x, pre)
         xx = self._conv(P, name + ".Conv_2", [x])
         xll = ops.haar_dwt2d(xx, want_high=False, ll_scale=0.5)[0]
         kw = {} if emit is None else {"emit": emit}
@@ -442,7 +449,7 @@ class WavBEST(nn.Module):
     def _up(self, P, S, name, x, bands, pre=None, fuse=False):
         """WaveletUPorDown(up=True) (ref :379-386, :398-408); ``bands`` = convH_0 output
         [B, 3C, N, h, w], step-invariant and cached with the condition branch."""
-        hh = self._conv(P, name + ".Conv_0", [pre]) if pre is not None else self._conv(P, name + ".Conv_0", [x], in_act=True)
+        hh = self._conv0(P, name, x, pre)
         xx = self._conv(P, name + ".Conv_2", [x])
         if fuse:   # Conv_1's prologue applied to the h reconstruction where the IDWT writes it
             pro = self._spec(P, S, shift=name + ".Dense_0", scale=name + ".dense1")
@@ -452,8 +459,16 @@ class WavBEST(nn.Module):
         return self._conv(P, name + ".Conv_1", [h_up], use_bias=False, in_act=True, residual=x_up,
                           **self._shift(P, S, name + ".Dense_0"), **self._scale(P, S, name + ".dense1"))
 
-    def _producer_fuse(self):
-        return _PRODUCER_FUSE and self.compute_dtype == "fp32"
+    def _producer_fuse(self, P):
+        """(conv -> conv edges, wavelet / stem producers): the first in both compute modes (in the bf16 mode the second
+        output is the packed bf16 form, and only if every MFMA convolution of the network runs on the bf16 kernels), the
+        second in fp32 only (the DWT / IDWT / stem kernels write fp32)."""
+        if not (_PRODUCER_FUSE and _EPILOGUE_FUSE):
+            return False, False
+        if self.compute_dtype == "fp32":
+            return True, True
+        n_conv = sum(1 for n_ in P["w"])
+        return len(P["bf16"]) == n_conv, False
 
     # ---- condition branch (independent of x_t and t) -------------------------------------------------
     def _prompt_rows(self, prompt, batch, device):
@@ -483,8 +498,8 @@ class WavBEST(nn.Module):
         pemb = lin(4, lin(2, lin(0, pe)))                 # act(embed2(prompt)) -- one row per distinct prompt row
         S = {"scale": P["scale_bank"].run(pemb)}
         c0 = self.channels[0]
-        fuse = self._producer_fuse()
-        spec = lambda **k: self._spec(P, S, **k) if fuse else None
+        fuse_c, fuse = self._producer_fuse(P)
+        spec = lambda **k: self._spec(P, S, **k) if fuse_c else None
         w0, b0 = self.conv1.conv20.weight.detach().reshape(-1), self.conv1.conv20.bias.detach()
         if fuse:    # the stem writes conv21's modulated input; conv21's epilogue writes SiLU(h) for down1_1.conv20 (flag: no shift)
             osc, oss = P["scale_bank"].slot(S["scale"], "conv1.dense2")
@@ -492,7 +507,9 @@ class WavBEST(nn.Module):
             h, hp = self._conv(P, "conv1.conv21", [a0], use_bias=False, emit=spec())
         else:
             a0 = ops.stem(w0, b0, c0, pan=PAN.contiguous(), ms=MS.contiguous())
-            h, hp = self._conv(P, "conv1.conv21", [a0], use_bias=False, **self._scale(P, S, "conv1.dense2")), None
+            out = self._conv(P, "conv1.conv21", [a0], use_bias=False, **self._scale(P, S, "conv1.dense2"),
+                             **({"emit": spec()} if fuse_c else {}))
+            h, hp = out if fuse_c else (out, None)
         cond = {"h0": h, "pan": PAN, "ms": MS, "prompt": prompt, "scale": S["scale"]}
         for lvl, (dn, upn) in enumerate((("down1_1", "up3"), ("down2_1", "up2"), ("down3_1", "up1")), start=1):
             h, ha = self._resblock(P, S, dn + ".conv20", [h], flag=True, pre=hp, emit=spec())
@@ -550,8 +567,8 @@ class WavBEST(nn.Module):
         temb = ops.linear(e, self.embed[2].weight.detach(), self.embed[2].bias.detach(), act=True)
         S = {"shift": P["shift_bank"].run(temb), "scale": cond["scale"]}
 
-        fuse = self._producer_fuse()
-        spec = lambda **k: self._spec(P, S, **k) if fuse else None
+        fuse_c, fuse = self._producer_fuse(P)
+        spec = lambda **k: self._spec(P, S, **k) if fuse_c else None
         w0, b0 = self.conv2.conv20.weight.detach().reshape(-1), self.conv2.conv20.bias.detach()
         if fuse:
             osc, oss = P["scale_bank"].slot(S["scale"], "conv2.dense2")
@@ -559,7 +576,9 @@ class WavBEST(nn.Module):
             h, hp = self._conv(P, "conv2.conv21", [a0], use_bias=False, emit=spec(shift="down1.conv20.dense1"))
         else:
             a0 = ops.stem(w0, b0, self.channels[0], xin=x_t.contiguous())
-            h, hp = self._conv(P, "conv2.conv21", [a0], use_bias=False, **self._scale(P, S, "conv2.dense2")), None
+            out = self._conv(P, "conv2.conv21", [a0], use_bias=False, **self._scale(P, S, "conv2.dense2"),
+                             **({"emit": spec(shift="down1.conv20.dense1")} if fuse_c else {}))
+            h, hp = out if fuse_c else (out, None)
         hs = [h]
         for dn, nxt in (("down1", "down2.conv20"), ("down2", "down3.conv20"), ("down3", "middle1")):
             h, ha = self._resblock(P, S, dn + ".conv20", [h], flag=False, pre=hp, emit=spec())
