@@ -224,3 +224,31 @@ def test_config5_tiled_512_scene():
     diff.noise_fn = lambda like: first[idx:idx + 1]
     alone = diff.sample_by_dpmsolver(tiles, "GF2", steps=3)
     assert (alone[0] - fused[0, :, 192:256, 320:384]).abs().max() <= 1e-4
+
+
+@pytest.mark.parametrize("channels,b,c,h,w", [([4, 8, 16, 32], 3, 4, 24, 40), (FULL, 1, 8, 24, 24), (FULL, 2, 4, 8, 40)])
+def test_ragged_tile_sizes_vs_oracle(channels, b, c, h, w):
+    """Planes that are not whole numbers of the kernels' 8x8 / 8x16 boxes at some level (24 -> 12 -> 6 -> 3; 40 -> 20 -> 10 -> 5),
+    4- and 8-band inputs: every bounds path of the staged / fused / split-K / 1x1x1 / wavelet kernels against the oracle,
+    forward (inference path) and one DDPM step."""
+    from tmdiff_amd.diffusion_general import GeneralDiffusion
+    ref = U.fill_weights_(U.WavBESTRef(channels=channels)).eval()
+    net = _hip_net(channels, ref)
+    d = case_inputs(4000 + h + w, b, c, h, w)
+    t = torch.arange(1, b + 1).reshape(b, 1) * 211
+    with torch.no_grad():
+        want = ref(d["x_t"], t, d["PAN"], d["MS"], "GF2" if c == 4 else "WV3")
+        got = net(cu(d["x_t"]), t.cuda(), cu(d["PAN"]), cu(d["MS"]), "GF2" if c == 4 else "WV3").cpu()
+    m, l2 = rel_err(got, want)
+    print(f"ragged {channels[0]}ch B={b} {c}x{h}x{w}: max-rel {m:.2e} rel-L2 {l2:.2e}")
+    assert m <= 1e-4 and l2 <= 1e-5
+    noise = randn(4100, b, c, h, w)
+    ora = GeneralDiffusionRef(ref, "l1", noise_fn=lambda like: noise)
+    ora.set_new_noise_schedule({"schedule": "cosine", "n_timestep": 100}, "cpu")
+    diff = GeneralDiffusion(net, "l1", noise_fn=lambda like: noise).cuda()
+    diff.set_new_noise_schedule({"schedule": "cosine", "n_timestep": 100}, "cuda")
+    dc = {k: cu(v) for k, v in d.items()}
+    with torch.no_grad():
+        y_ref = ora.p_sample(d["x_t"], 57, condition_x=d, prompt="QB")
+    y = diff.p_sample(dc["x_t"], 57, condition_x=dc, prompt="QB").cpu()
+    assert_close(y, y_ref, 1e-4, 1e-5, "DDPM step on a ragged tile")
