@@ -212,6 +212,9 @@ int tmdiff_stem_fwd(const float* xin, const float* pan, const float* ms, const f
 int tmdiff_stem_fwd_scaled(const float* xin, const float* pan, const float* ms, const float* w, const float* bias,
                            const float* out_scale, int32_t out_scale_stride, float* y, int32_t B, int32_t Cout, int32_t N,
                            int32_t H, int32_t W, int32_t apply_silu, tmdiff_stream_t stream);
+int tmdiff_stem_fwd_pack_bf16(const float* xin, const float* pan, const float* ms, const float* w, const float* bias,
+                              const float* out_scale, int32_t out_scale_stride, void* units, int32_t B, int32_t Cout, int32_t N,
+                              int32_t H, int32_t W, int32_t apply_silu, tmdiff_stream_t stream);
 int tmdiff_head_fwd(const float* x, const float* w, const float* scale, int32_t scale_stride, float* y, int32_t B,
                     int32_t C, int64_t P, tmdiff_stream_t stream); /* scale_stride as in_scale_stride above */
 /* stem backward: with u = w[co]*x + bias[co], y = SiLU(u): dwb[b, co, 0] = sum_p gy*SiLU'(u)*x and
@@ -262,6 +265,15 @@ int tmdiff_haar_idwt2d_pro(const float* const ll[2], int32_t n_ll, const float* 
                            int64_t hi_planes_per_batch, int64_t hi_batch_stride, float* const out[2], int64_t planes,
                            int32_t h, int32_t w, float in_scale, const tmdiff_plane_prologue* out0_prologue,
                            tmdiff_stream_t stream);
+/* bf16-mode producers: the LL band / first reconstruction (x, ll0, ll1: [B, C, N, ., .] fp32; stacked_bands [B, 3C, N, h, w])
+ * written as the packed bf16 units [B][C/8][N*h*w] of 8 channels (16 bytes) that tmdiff_conv3d_fwd_bf16 reads with x_bf16 = 1,
+ * prologue applied in fp32 and rounded to nearest even exactly as that entry point's own pack pass does.  C % 8 == 0. */
+int tmdiff_haar_dwt2d_pack_bf16(const float* x, void* ll_units, float* lh, float* hl, float* hh, int32_t B, int32_t C,
+                                int32_t N, int32_t H, int32_t W, float ll_scale, float hi_scale,
+                                const tmdiff_plane_prologue* ll_prologue, tmdiff_stream_t stream);
+int tmdiff_haar_idwt2d_pack_bf16(const float* ll0, const float* ll1, const float* stacked_bands, void* out0_units, float* out1,
+                                 int32_t B, int32_t C, int32_t N, int32_t h, int32_t w, float in_scale,
+                                 const tmdiff_plane_prologue* out0_prologue, tmdiff_stream_t stream);
 int tmdiff_haar_dwt2d(const float* x, float* ll, float* lh, float* hl, float* hh, int64_t planes, int32_t H,
                       int32_t W, float ll_scale, float hi_scale, tmdiff_stream_t stream);
 int tmdiff_haar_idwt2d(const float* const ll[2], int32_t n_ll, const float* lh, const float* hl, const float* hh,

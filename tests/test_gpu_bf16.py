@@ -102,3 +102,42 @@ def test_factory_compute_dtype_option():
     opt["model"]["compute_dtype"] = "fp16"
     with pytest.raises(ValueError):
         networks.define_General(opt)
+
+
+def _unpack_units(units, c, shape):
+    """packed bf16 units [B, C/8, positions, 8] (int16 storage) -> fp32 [B, C, *shape]"""
+    b = units.shape[0]
+    return units.view(torch.bfloat16).float().permute(0, 1, 3, 2).reshape(b, c, *shape)
+
+
+def test_packed_bf16_producers_equal_fp32_producers_rounded():
+    """The bf16-mode producers (DWT LL band, IDWT reconstruction, stem) write the consumer's prologue output as packed
+    bf16 units: bit for bit the fp32 producer's output rounded to bf16 (round to nearest even), other outputs unchanged."""
+    from tmdiff_amd import ops
+    torch.manual_seed(3)
+    b, c, n, h, w = 2, 16, 4, 8, 12
+    x = cu(torch.randn(b, c, n, 2 * h, 2 * w))
+    pro = dict(act=True, shift=cu(torch.randn(b, c)), scale=cu(torch.rand(b, c) + 0.5))
+    ref = ops.haar_dwt2d(x, want_high=True, ll_scale=0.5, ll_prologue=pro)
+    got = ops.haar_dwt2d(x, want_high=True, ll_scale=0.5, ll_prologue=pro, pack_bf16=True)
+    assert torch.equal(_unpack_units(got[0], c, (n, h, w)), ref[0].bfloat16().float())
+    for a_, b_ in zip(got[1:], ref[1:]):
+        assert torch.equal(a_, b_)
+    only = ops.haar_dwt2d(x, want_high=False, ll_scale=0.5, ll_prologue=pro, pack_bf16=True)
+    assert only[1] is None and torch.equal(only[0], got[0])
+    # IDWT pair with stacked bands
+    hh_, xx = cu(torch.randn(b, c, n, h, w)), cu(torch.randn(b, c, n, h, w))
+    bands = cu(torch.randn(b, 3 * c, n, h, w))
+    r0, r1 = ops.haar_idwt2d([hh_, xx], None, None, None, in_scale=2.0, stacked_bands=bands, out0_prologue=pro)
+    g0, g1 = ops.haar_idwt2d([hh_, xx], None, None, None, in_scale=2.0, stacked_bands=bands, out0_prologue=pro, pack_bf16=True)
+    assert torch.equal(_unpack_units(g0, c, (n, 2 * h, 2 * w)), r0.bfloat16().float()) and torch.equal(g1, r1)
+    # stem
+    wv, bv, sc = cu(torch.randn(c)), cu(torch.randn(c)), cu(torch.rand(b, c) + 0.5)
+    xin = cu(torch.randn(b, n, 2 * h, 2 * w))
+    s_ref = ops.stem(wv, bv, c, xin=xin, out_scale=sc)
+    s_got = ops.stem(wv, bv, c, xin=xin, out_scale=sc, pack_bf16=True)
+    assert torch.equal(_unpack_units(s_got, c, (n, 2 * h, 2 * w)), s_ref.bfloat16().float())
+    pan, ms = cu(torch.rand(b, 1, 2 * h, 2 * w)), cu(torch.rand(b, n, 2 * h, 2 * w))
+    s_ref = ops.stem(wv, bv, c, pan=pan, ms=ms, out_scale=sc)
+    s_got = ops.stem(wv, bv, c, pan=pan, ms=ms, out_scale=sc, pack_bf16=True)
+    assert torch.equal(_unpack_units(s_got, c, (n, 2 * h, 2 * w)), s_ref.bfloat16().float())

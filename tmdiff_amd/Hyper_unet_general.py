@@ -436,8 +436,10 @@ class WavBEST(nn.Module):
         kw = {} if emit is None else {"emit": emit}
         if fuse:   # Conv_1's prologue (shift, SiLU, text modulation) is applied to the LL band where the DWT writes it
             pro = self._spec(P, S, shift=None if flag else name + ".Dense_0", scale=name + ".dense1")
-            hll, lh, hl, hhh = ops.haar_dwt2d(hh, want_high=want_high, ll_scale=0.5, ll_prologue=pro)
-            out = self._conv(P, name + ".Conv_1", [hll], use_bias=False, residual=xll, **kw)
+            p16 = name + ".Conv_1" in P["bf16"]          # bf16 mode: ... as the packed bf16 units the convolution reads
+            hll, lh, hl, hhh = ops.haar_dwt2d(hh, want_high=want_high, ll_scale=0.5, ll_prologue=pro, pack_bf16=p16)
+            out = self._conv(P, name + ".Conv_1", [hll], use_bias=False, residual=xll,
+                             x_bf16_shape=tuple(xll.shape[2:]) if p16 else None, **kw)
         else:
             hll, lh, hl, hhh = ops.haar_dwt2d(hh, want_high=want_high, ll_scale=0.5)
             sh = {} if flag else self._shift(P, S, name + ".Dense_0")
@@ -453,8 +455,11 @@ class WavBEST(nn.Module):
         xx = self._conv(P, name + ".Conv_2", [x])
         if fuse:   # Conv_1's prologue applied to the h reconstruction where the IDWT writes it
             pro = self._spec(P, S, shift=name + ".Dense_0", scale=name + ".dense1")
-            h_up, x_up = ops.haar_idwt2d([hh, xx], None, None, None, in_scale=2.0, stacked_bands=bands, out0_prologue=pro)
-            return self._conv(P, name + ".Conv_1", [h_up], use_bias=False, residual=x_up)
+            p16 = name + ".Conv_1" in P["bf16"]
+            h_up, x_up = ops.haar_idwt2d([hh, xx], None, None, None, in_scale=2.0, stacked_bands=bands, out0_prologue=pro,
+                                         pack_bf16=p16)
+            return self._conv(P, name + ".Conv_1", [h_up], use_bias=False, residual=x_up,
+                              x_bf16_shape=tuple(x_up.shape[2:]) if p16 else None)
         h_up, x_up = ops.haar_idwt2d([hh, xx], None, None, None, in_scale=2.0, stacked_bands=bands)
         return self._conv(P, name + ".Conv_1", [h_up], use_bias=False, in_act=True, residual=x_up,
                           **self._shift(P, S, name + ".Dense_0"), **self._scale(P, S, name + ".dense1"))
@@ -462,13 +467,13 @@ class WavBEST(nn.Module):
     def _producer_fuse(self, P):
         """(conv -> conv edges, wavelet / stem producers): the first in both compute modes (in the bf16 mode the second
         output is the packed bf16 form, and only if every MFMA convolution of the network runs on the bf16 kernels), the
-        second in fp32 only (the DWT / IDWT / stem kernels write fp32)."""
+        second likewise (fp32 tensors, or the packed bf16 units from the *_pack_bf16 variants of the DWT / IDWT / stem)."""
         if not (_PRODUCER_FUSE and _EPILOGUE_FUSE):
             return False, False
         if self.compute_dtype == "fp32":
             return True, True
-        n_conv = sum(1 for n_ in P["w"])
-        return len(P["bf16"]) == n_conv, False
+        all16 = len(P["bf16"]) == len(P["w"])
+        return all16, all16
 
     # ---- condition branch (independent of x_t and t) -------------------------------------------------
     def _prompt_rows(self, prompt, batch, device):
@@ -503,8 +508,11 @@ class WavBEST(nn.Module):
         w0, b0 = self.conv1.conv20.weight.detach().reshape(-1), self.conv1.conv20.bias.detach()
         if fuse:    # the stem writes conv21's modulated input; conv21's epilogue writes SiLU(h) for down1_1.conv20 (flag: no shift)
             osc, oss = P["scale_bank"].slot(S["scale"], "conv1.dense2")
-            a0 = ops.stem(w0, b0, c0, pan=PAN.contiguous(), ms=MS.contiguous(), out_scale=osc, out_scale_stride=oss)
-            h, hp = self._conv(P, "conv1.conv21", [a0], use_bias=False, emit=spec())
+            p16 = "conv1.conv21" in P["bf16"]
+            a0 = ops.stem(w0, b0, c0, pan=PAN.contiguous(), ms=MS.contiguous(), out_scale=osc, out_scale_stride=oss,
+                          pack_bf16=p16)
+            h, hp = self._conv(P, "conv1.conv21", [a0], use_bias=False, emit=spec(),
+                               x_bf16_shape=(MS.shape[1], MS.shape[2], MS.shape[3]) if p16 else None)
         else:
             a0 = ops.stem(w0, b0, c0, pan=PAN.contiguous(), ms=MS.contiguous())
             out = self._conv(P, "conv1.conv21", [a0], use_bias=False, **self._scale(P, S, "conv1.dense2"),
@@ -572,8 +580,10 @@ class WavBEST(nn.Module):
         w0, b0 = self.conv2.conv20.weight.detach().reshape(-1), self.conv2.conv20.bias.detach()
         if fuse:
             osc, oss = P["scale_bank"].slot(S["scale"], "conv2.dense2")
-            a0 = ops.stem(w0, b0, self.channels[0], xin=x_t.contiguous(), out_scale=osc, out_scale_stride=oss)
-            h, hp = self._conv(P, "conv2.conv21", [a0], use_bias=False, emit=spec(shift="down1.conv20.dense1"))
+            p16 = "conv2.conv21" in P["bf16"]
+            a0 = ops.stem(w0, b0, self.channels[0], xin=x_t.contiguous(), out_scale=osc, out_scale_stride=oss, pack_bf16=p16)
+            h, hp = self._conv(P, "conv2.conv21", [a0], use_bias=False, emit=spec(shift="down1.conv20.dense1"),
+                               x_bf16_shape=tuple(x_t.shape[1:]) if p16 else None)
         else:
             a0 = ops.stem(w0, b0, self.channels[0], xin=x_t.contiguous())
             out = self._conv(P, "conv2.conv21", [a0], use_bias=False, **self._scale(P, S, "conv2.dense2"),

@@ -113,6 +113,12 @@ SIGNATURES.update({
                                         C.POINTER(PlanePrologue), vp]),
     "tmdiff_haar_idwt2d_pro": (C.c_int, [vp * 2, C.c_int32, vp, vp, vp, C.c_int64, C.c_int64, vp * 2, C.c_int64,
                                          C.c_int32, C.c_int32, C.c_float, C.POINTER(PlanePrologue), vp]),
+    "tmdiff_haar_dwt2d_pack_bf16": (C.c_int, [vp, vp, vp, vp, vp, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32,
+                                              C.c_float, C.c_float, C.POINTER(PlanePrologue), vp]),
+    "tmdiff_haar_idwt2d_pack_bf16": (C.c_int, [vp, vp, vp, vp, vp, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32,
+                                               C.c_float, C.POINTER(PlanePrologue), vp]),
+    "tmdiff_stem_fwd_pack_bf16": (C.c_int, [vp, vp, vp, vp, vp, vp, C.c_int32, vp, C.c_int32, C.c_int32, C.c_int32, C.c_int32,
+                                            C.c_int32, C.c_int32, vp]),
     "tmdiff_stem_fwd_scaled": (C.c_int, [vp, vp, vp, vp, vp, vp, C.c_int32, vp, C.c_int32, C.c_int32, C.c_int32, C.c_int32,
                                          C.c_int32, C.c_int32, vp]),
 })

@@ -27,23 +27,37 @@ struct Vec<4> {
 
 __device__ __forceinline__ void butterfly(float a, float b, float c, float d, float& ll, float& lh, float& hl,
                                           float& hh) {
+#pragma clang fp contract(off)
   // a=x[2i,2j] b=x[2i,2j+1] c=x[2i+1,2j] d=x[2i+1,2j+1]
-  const float lo0 = kS * a + kS * c, lo1 = kS * b + kS * d;  // L  = L0 @ X   (low rows)
-  const float hi0 = kS * a - kS * c, hi1 = kS * b - kS * d;  // Hh = H0 @ X   (high rows)
-  ll = kS * lo0 + kS * lo1;
-  lh = kS * lo0 - kS * lo1;
-  hl = kS * hi0 + kS * hi1;
-  hh = kS * hi0 - kS * hi1;
+  // (plain operators under contract(off): every product and sum is individually rounded, never fused into an FMA, so
+  //  every kernel that inlines this gives the same bits -- the __f*_rn helpers of this toolchain are plain operators
+  //  defined elsewhere and would still be contracted)
+  const float sa = kS * a, sb = kS * b, sc = kS * c, sd = kS * d;
+  const float lo0 = sa + sc, lo1 = sb + sd;  // L  = L0 @ X   (low rows)
+  const float hi0 = sa - sc, hi1 = sb - sd;  // Hh = H0 @ X   (high rows)
+  const float l0 = kS * lo0, l1 = kS * lo1, h0 = kS * hi0, h1 = kS * hi1;
+  ll = l0 + l1;
+  lh = l0 - l1;
+  hl = h0 + h1;
+  hh = h0 - h1;
 }
 
 __device__ __forceinline__ void inv_butterfly(float ll, float lh, float hl, float hh, float& a, float& b, float& c,
                                               float& d) {
-  const float lo0 = kS * ll + kS * lh, lo1 = kS * ll - kS * lh;  // L  = LL @ L1^T + LH @ H1^T
-  const float hi0 = kS * hl + kS * hh, hi1 = kS * hl - kS * hh;  // Hh = HL @ L1^T + HH @ H1^T
-  a = kS * lo0 + kS * hi0;
-  b = kS * lo1 + kS * hi1;
-  c = kS * lo0 - kS * hi0;
-  d = kS * lo1 - kS * hi1;
+#pragma clang fp contract(off)
+  const float s0 = kS * ll, s1 = kS * lh, s2 = kS * hl, s3 = kS * hh;
+  const float lo0 = s0 + s1, lo1 = s0 - s1;  // L  = LL @ L1^T + LH @ H1^T
+  const float hi0 = s2 + s3, hi1 = s2 - s3;  // Hh = HL @ L1^T + HH @ H1^T
+  const float l0 = kS * lo0, l1 = kS * lo1, h0 = kS * hi0, h1 = kS * hi1;
+  a = l0 + h0;
+  b = l1 + h1;
+  c = l0 - h0;
+  d = l1 - h1;
+}
+
+__device__ __forceinline__ float scaled(float s, float v) {   // s * v as its own rounded product
+#pragma clang fp contract(off)
+  return s * v;
 }
 
 // One thread -> V adjacent output columns of one output row.  grid-stride over all outputs.
@@ -102,7 +116,7 @@ __global__ void __launch_bounds__(256) dwt2d_kernel(const float* __restrict__ x,
       const float sc = band == 0 ? ll_scale : hi_scale;
       float v[V];
 #pragma unroll
-      for (int k = 0; k < V; ++k) v[k] = sc * o[band][k];
+      for (int k = 0; k < V; ++k) v[k] = scaled(sc, o[band][k]);
       if (band == 0 && pro.on) {
         float sh, scl;
         prologue_coefs(pro, plane, sh, scl);
@@ -158,7 +172,8 @@ __global__ void __launch_bounds__(256) idwt2d_kernel(const float* __restrict__ l
         b0[0] = lls[k][off];
       }
 #pragma unroll
-      for (int c = 0; c < V; ++c) inv_butterfly(in_scale * b0[c], b1[c], b2[c], b3[c], t[2 * c], t[2 * c + 1], bt[2 * c], bt[2 * c + 1]);
+      for (int c = 0; c < V; ++c)
+        inv_butterfly(scaled(in_scale, b0[c]), b1[c], b2[c], b3[c], t[2 * c], t[2 * c + 1], bt[2 * c], bt[2 * c + 1]);
       if (k == 0 && pro.on) {
         float sh, scl;
         prologue_coefs(pro, plane, sh, scl);
@@ -176,6 +191,86 @@ __global__ void __launch_bounds__(256) idwt2d_kernel(const float* __restrict__ l
         top[0] = t[0], top[1] = t[1], bot[0] = bt[0], bot[1] = bt[1];
       }
     }
+  }
+}
+
+// ---- bf16-mode producers: the LL band / the first reconstruction written as the packed bf16 units [B][C/8][positions]
+// (8 channels = 16 bytes per position) that tmdiff_conv3d_fwd_bf16 takes with x_bf16, consumer prologue applied in fp32
+// and rounded (RNE) exactly as its pack pass would -- so that pass disappears.  One thread = one position, 8 channels.
+using bf16x8 = __attribute__((ext_vector_type(8))) __bf16;
+
+__global__ void __launch_bounds__(256) dwt2d_pack_bf16_kernel(const float* __restrict__ x, uint4* __restrict__ units,
+                                                              float* __restrict__ lh, float* __restrict__ hl,
+                                                              float* __restrict__ hh, long total, int C, int N, int h,
+                                                              int w, float ll_scale, float hi_scale,
+                                                              const PlanePrologue pro) {
+  const int W2 = 2 * w;
+  const long hw = (long)h * w, plane = (long)N * hw;
+  for (long i = blockIdx.x * 256L + threadIdx.x; i < total; i += 256L * gridDim.x) {
+    const int j = (int)(i % w);
+    long t = i / w;
+    const int r = (int)(t % h); t /= h;
+    const int n = (int)(t % N); t /= N;
+    const int c8 = (int)(t % (C / 8));
+    const int b = (int)(t / (C / 8));
+    union { bf16x8 v; uint4 u; } pk;
+#pragma unroll
+    for (int ch = 0; ch < 8; ++ch) {
+      const int c = c8 * 8 + ch;
+      const long pl = ((long)b * C + c) * N + n;
+      const float* top = x + (pl * 2 * h + 2 * r) * W2 + 2 * j;
+      const float2 tt = *reinterpret_cast<const float2*>(top), bb = *reinterpret_cast<const float2*>(top + W2);
+      float ll, b1, b2, b3;
+      butterfly(tt.x, tt.y, bb.x, bb.y, ll, b1, b2, b3);
+      const float sh = pro.shift ? pro.shift[(long)b * pro.shift_stride + c] : 0.f;
+      const float sc = pro.scale ? pro.scale[(long)b * pro.scale_stride + c] : 1.f;
+      pk.v[ch] = (__bf16)apply_prologue(pro.act, sh, sc, scaled(ll_scale, ll));
+      if (lh) {
+        const long off = pl * hw + (long)r * w + j;
+        lh[off] = scaled(hi_scale, b1), hl[off] = scaled(hi_scale, b2), hh[off] = scaled(hi_scale, b3);
+      }
+    }
+    units[((long)b * (C / 8) + c8) * plane + ((long)n * h + r) * w + j] = pk.u;
+  }
+}
+
+// (h_up, x_up) = (IDWT(s * hh, bands), IDWT(s * xx, bands)); bands = stacked [B, 3C, N, h, w]; h_up packed with prologue
+__global__ void __launch_bounds__(256) idwt2d_pack_bf16_kernel(const float* __restrict__ ll0, const float* __restrict__ ll1,
+                                                               const float* __restrict__ bands, uint4* __restrict__ units,
+                                                               float* __restrict__ out1, long total, int C, int N, int h,
+                                                               int w, float in_scale, const PlanePrologue pro) {
+  const int W2 = 2 * w, H2 = 2 * h;
+  const long hw = (long)h * w, oplane = (long)N * H2 * W2;
+  for (long i = blockIdx.x * 256L + threadIdx.x; i < total; i += 256L * gridDim.x) {
+    const int j = (int)(i % w);
+    long t = i / w;
+    const int r = (int)(t % h); t /= h;
+    const int n = (int)(t % N); t /= N;
+    const int c8 = (int)(t % (C / 8));
+    const int b = (int)(t / (C / 8));
+    union { bf16x8 v; uint4 u; } pk[4];
+#pragma unroll
+    for (int ch = 0; ch < 8; ++ch) {
+      const int c = c8 * 8 + ch;
+      const long pl = ((long)b * C + c) * N + n;
+      const long off = pl * hw + (long)r * w + j;
+      const long boff = (((long)b * 3 * C + c) * N + n) * hw + (long)r * w + j;   // band k: + k * C * N * hw
+      const float b1 = bands[boff], b2 = bands[boff + (long)C * N * hw], b3 = bands[boff + 2L * C * N * hw];
+      float a0, a1, a2, a3, x0, x1, x2, x3;
+      inv_butterfly(scaled(in_scale, ll0[off]), b1, b2, b3, a0, a1, a2, a3);
+      inv_butterfly(scaled(in_scale, ll1[off]), b1, b2, b3, x0, x1, x2, x3);
+      float* top = out1 + (pl * H2 + 2 * r) * W2 + 2 * j;
+      *reinterpret_cast<float2*>(top) = make_float2(x0, x1);
+      *reinterpret_cast<float2*>(top + W2) = make_float2(x2, x3);
+      const float sh = pro.shift ? pro.shift[(long)b * pro.shift_stride + c] : 0.f;
+      const float sc = pro.scale ? pro.scale[(long)b * pro.scale_stride + c] : 1.f;
+      pk[0].v[ch] = (__bf16)apply_prologue(pro.act, sh, sc, a0);
+      pk[1].v[ch] = (__bf16)apply_prologue(pro.act, sh, sc, a1);
+      pk[2].v[ch] = (__bf16)apply_prologue(pro.act, sh, sc, a2);
+      pk[3].v[ch] = (__bf16)apply_prologue(pro.act, sh, sc, a3);
+    }
+    uint4* u = units + ((long)b * (C / 8) + c8) * oplane + ((long)n * H2 + 2 * r) * W2 + 2 * j;
+    u[0] = pk[0].u, u[1] = pk[1].u, u[W2] = pk[2].u, u[W2 + 1] = pk[3].u;
   }
 }
 
@@ -224,6 +319,46 @@ extern "C" int tmdiff_haar_dwt2d_pro(const float* x, float* ll, float* lh, float
     dwt2d_kernel<1><<<grid_for(total), 256, 0, as_stream(stream)>>>(x, ll, lh, hl, hh, total, h, w, ll_scale, hi_scale, pro);
   }
   return check_launch("haar_dwt2d");
+}
+
+extern "C" int tmdiff_haar_dwt2d_pack_bf16(const float* x, void* ll_units, float* lh, float* hl, float* hh, int32_t B,
+                                           int32_t C, int32_t N, int32_t H, int32_t W, float ll_scale, float hi_scale,
+                                           const tmdiff_plane_prologue* ll_prologue, tmdiff_stream_t stream) {
+  using namespace tmdiff;
+  TMDIFF_REQUIRE(x && ll_units && aligned16(ll_units), "haar_dwt2d_pack_bf16: NULL / unaligned pointer");
+  TMDIFF_REQUIRE((lh && hl && hh) || (!lh && !hl && !hh), "haar_dwt2d_pack_bf16: give all three high bands or none");
+  TMDIFF_REQUIRE(B >= 0 && C > 0 && C % 8 == 0 && N > 0 && H > 0 && W > 0 && H % 2 == 0 && W % 2 == 0,
+                 "haar_dwt2d_pack_bf16: C=%d (multiple of 8) H=%d W=%d (even)", C, H, W);
+  if (B == 0) return TMDIFF_OK;
+  PlanePrologue pro = PlanePrologue{nullptr, nullptr, 0, 0, C, N, 0, 1};
+  if (ll_prologue) {
+    TMDIFF_REQUIRE(ll_prologue->C == C && ll_prologue->n_per_channel == N, "haar_dwt2d_pack_bf16: prologue C / n mismatch");
+    if (int rc = make_prologue(ll_prologue, (int64_t)B * C * N, pro)) return rc;
+  }
+  const long total = (long)B * (C / 8) * N * (H / 2) * (W / 2);
+  dwt2d_pack_bf16_kernel<<<grid_for(total), 256, 0, as_stream(stream)>>>(x, static_cast<uint4*>(ll_units), lh, hl, hh, total, C,
+                                                                       N, H / 2, W / 2, ll_scale, hi_scale, pro);
+  return check_launch("haar_dwt2d_pack_bf16");
+}
+
+extern "C" int tmdiff_haar_idwt2d_pack_bf16(const float* ll0, const float* ll1, const float* stacked_bands, void* out0_units,
+                                            float* out1, int32_t B, int32_t C, int32_t N, int32_t h, int32_t w,
+                                            float in_scale, const tmdiff_plane_prologue* out0_prologue,
+                                            tmdiff_stream_t stream) {
+  using namespace tmdiff;
+  TMDIFF_REQUIRE(ll0 && ll1 && stacked_bands && out0_units && out1 && aligned16(out0_units),
+                 "haar_idwt2d_pack_bf16: NULL / unaligned pointer");
+  TMDIFF_REQUIRE(B >= 0 && C > 0 && C % 8 == 0 && N > 0 && h > 0 && w > 0, "haar_idwt2d_pack_bf16: C=%d (multiple of 8)", C);
+  if (B == 0) return TMDIFF_OK;
+  PlanePrologue pro = PlanePrologue{nullptr, nullptr, 0, 0, C, N, 0, 1};
+  if (out0_prologue) {
+    TMDIFF_REQUIRE(out0_prologue->C == C && out0_prologue->n_per_channel == N, "haar_idwt2d_pack_bf16: prologue C / n mismatch");
+    if (int rc = make_prologue(out0_prologue, (int64_t)B * C * N, pro)) return rc;
+  }
+  const long total = (long)B * (C / 8) * N * h * w;
+  idwt2d_pack_bf16_kernel<<<grid_for(total), 256, 0, as_stream(stream)>>>(ll0, ll1, stacked_bands, static_cast<uint4*>(out0_units),
+                                                                        out1, total, C, N, h, w, in_scale, pro);
+  return check_launch("haar_idwt2d_pack_bf16");
 }
 
 extern "C" int tmdiff_haar_idwt2d(const float* const ll[2], int32_t n_ll, const float* lh, const float* hl,

@@ -59,6 +59,32 @@ __global__ void __launch_bounds__(256) stem_kernel(const float* __restrict__ xin
   }
 }
 
+// bf16-mode stem: the same values as stem_kernel with out_scale, written as packed bf16 units [B][Cout/8][P] (the input form
+// of tmdiff_conv3d_fwd_bf16 with x_bf16) -- the consumer's pack pass disappears.  One thread = one position.
+using bf16x8 = __attribute__((ext_vector_type(8))) __bf16;
+__global__ void __launch_bounds__(256) stem_pack_bf16_kernel(const float* __restrict__ xin, const float* __restrict__ pan,
+                                                             const float* __restrict__ ms, const float* __restrict__ w,
+                                                             const float* __restrict__ bias, uint4* __restrict__ units,
+                                                             int Cout, long P, long HW, int act,
+                                                             const float* __restrict__ oscale, int oscale_stride) {
+  const long p = blockIdx.x * 256L + threadIdx.x;
+  const int b = blockIdx.y;
+  if (p >= P) return;
+  const float x = ms ? pan[b * HW + p % HW] - ms[b * P + p] : xin[b * P + p];
+  for (int c8 = 0; c8 < Cout / 8; ++c8) {
+    union { bf16x8 v; uint4 u; } pk;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+      const int co = c8 * 8 + k;
+      float o = __fadd_rn(__fmul_rn(w[co], x), bias ? bias[co] : 0.f);
+      if (act) o = tmdiff::silu_f(o);
+      if (oscale) o *= oscale[(long)b * oscale_stride + co];
+      pk.v[k] = (__bf16)o;
+    }
+    units[((long)b * (Cout / 8) + c8) * P + p] = pk.u;
+  }
+}
+
 // ---- head: y[b,p] = sum_c (w[c]*scale[b,c]) * silu(x[b,c,p]) ------------------------------------
 template <int V>
 __global__ void __launch_bounds__(256) head_kernel(const float* __restrict__ x, const float* __restrict__ w,
@@ -165,6 +191,22 @@ extern "C" int tmdiff_stem_fwd_scaled(const float* xin, const float* pan, const 
     stem_kernel<1><<<grid, 256, 0, as_stream(stream)>>>(xin, pan, ms, w, bias, y, Cout, P, HW, apply_silu, out_scale, oss);
   }
   return check_launch("stem_fwd");
+}
+
+extern "C" int tmdiff_stem_fwd_pack_bf16(const float* xin, const float* pan, const float* ms, const float* w,
+                                         const float* bias, const float* out_scale, int32_t out_scale_stride, void* units,
+                                         int32_t B, int32_t Cout, int32_t N, int32_t H, int32_t W, int32_t apply_silu,
+                                         tmdiff_stream_t stream) {
+  using namespace tmdiff;
+  TMDIFF_REQUIRE(w && units && aligned16(units), "stem_fwd_pack_bf16: NULL / unaligned weights / output");
+  TMDIFF_REQUIRE((ms && pan) || (!ms && xin), "stem_fwd_pack_bf16: give either (pan, ms) or xin");
+  TMDIFF_REQUIRE(B >= 0 && Cout > 0 && Cout % 8 == 0 && N > 0 && H > 0 && W > 0 && B <= 65535, "stem_fwd_pack_bf16: bad extents");
+  if (B == 0) return TMDIFF_OK;
+  const int oss = out_scale_stride > 0 ? out_scale_stride : (out_scale_stride < 0 ? 0 : Cout);
+  const long HW = (long)H * W, P = HW * N;
+  stem_pack_bf16_kernel<<<dim3((unsigned)((P + 255) / 256), B), 256, 0, as_stream(stream)>>>(
+      xin, pan, ms, w, bias, static_cast<uint4*>(units), Cout, P, HW, apply_silu, out_scale, oss);
+  return check_launch("stem_fwd_pack_bf16");
 }
 
 extern "C" int tmdiff_head_fwd(const float* x, const float* w, const float* scale, int32_t scale_stride, float* y,

@@ -70,7 +70,7 @@ class PackedWeights:
             ct += [k] * nck
             ci += list(range(na.value)) + [(1 << 30) | t for t in range(nck - na.value)]
         dev = self.convs[0][0].device
-        self.entries = torch.frombuffer(bytes(ent), dtype=torch.uint8).clone().to(dev)
+        self.entries = torch.frombuffer(bytearray(ent), dtype=torch.uint8).clone().to(dev)
         self.chunk_tensor = torch.tensor(ct, dtype=torch.int32).to(dev)
         self.chunk_index = torch.tensor(ci, dtype=torch.int32).to(dev)
         self.n_chunks = len(ct)
@@ -307,11 +307,20 @@ def conv3d(segs, w_packed, cout, ksize, out=None, math="fp32", pack_input=None, 
     return ret
 
 
-def stem(w, bias, out_channels, xin=None, pan=None, ms=None, silu=True, out=None, out_scale=None, out_scale_stride=0):
+def stem(w, bias, out_channels, xin=None, pan=None, ms=None, silu=True, out=None, out_scale=None, out_scale_stride=0,
+         pack_bf16=False):
     """out_scale (tensor [B, C0] or a raw pointer into a projection bank, row stride out_scale_stride): the consumer's
-    modulation folded into the stem's output."""
+    modulation folded into the stem's output.  pack_bf16: the result as packed bf16 units [B, C0/8, N*H*W, 8] (int16
+    storage), the input form of a bf16 convolution (x_bf16_shape=(N, H, W))."""
     ref = ms if ms is not None else xin
     b, n, h, wd = ref.shape
+    osc = out_scale if isinstance(out_scale, int) else _chk(out_scale, "out_scale")
+    if pack_bf16:
+        units = torch.empty(b, out_channels // 8, n * h * wd, 8, device=ref.device, dtype=torch.int16)
+        check(lib.tmdiff_stem_fwd_pack_bf16(_chk(xin, "xin"), _chk(pan, "pan"), _chk(ms, "ms"), _chk(w, "w"), _chk(bias, "bias"),
+                                            osc, out_scale_stride, units.data_ptr(), b, out_channels, n, h, wd,
+                                            1 if silu else 0, stream_ptr()), "stem_fwd_pack_bf16")
+        return units
     y = out if out is not None else torch.empty(b, out_channels, n, h, wd, device=ref.device, dtype=torch.float32)
     osc = out_scale if isinstance(out_scale, int) else _chk(out_scale, "out_scale")
     check(lib.tmdiff_stem_fwd_scaled(_chk(xin, "xin"), _chk(pan, "pan"), _chk(ms, "ms"), _chk(w, "w"), _chk(bias, "bias"),
@@ -340,13 +349,21 @@ def _plane_prologue(pro, channels, n_per_channel):
     return C.byref(q)
 
 
-def haar_dwt2d(x, want_high=True, ll_scale=1.0, hi_scale=1.0, outs=None, ll_prologue=None):
+def haar_dwt2d(x, want_high=True, ll_scale=1.0, hi_scale=1.0, outs=None, ll_prologue=None, pack_bf16=False):
     """x [..., H, W] -> (ll, lh, hl, hh); the high bands are None when want_high is False.
     ll_prologue (x must then be [B, C, N, H, W]): the consumer convolution's prologue applied to the LL band as it is
     written -- dict(act=, shift=, scale=, shift_stride=, scale_stride=), per (b, c)."""
     hh_, ww = x.shape[-2:]
     planes = x.numel() // (hh_ * ww)
     shape = (*x.shape[:-2], hh_ // 2, ww // 2)
+    if pack_bf16:     # bf16 mode: LL as packed bf16 units [B, C/8, N*h*w, 8] (int16 storage), high bands fp32
+        b, c, n = x.shape[:3]
+        units = torch.empty(b, c // 8, n * (hh_ // 2) * (ww // 2), 8, device=x.device, dtype=torch.int16)
+        hi = [torch.empty(shape, device=x.device, dtype=torch.float32) for _ in range(3)] if want_high else [None] * 3
+        pro = _plane_prologue(ll_prologue, c, n) if ll_prologue is not None else None
+        check(lib.tmdiff_haar_dwt2d_pack_bf16(_chk(x, "x"), units.data_ptr(), *[_chk(t, "band") for t in hi], b, c, n, hh_, ww,
+                                              ll_scale, hi_scale, pro, stream_ptr()), "haar_dwt2d_pack_bf16")
+        return (units, *hi)
     if outs is None:
         outs = [torch.empty(shape, device=x.device, dtype=torch.float32) for _ in range(4 if want_high else 1)]
     ptrs = [_chk(o, "band") for o in outs] + [None] * (4 - len(outs))
@@ -356,7 +373,7 @@ def haar_dwt2d(x, want_high=True, ll_scale=1.0, hi_scale=1.0, outs=None, ll_prol
     return tuple(outs) + (None,) * (4 - len(outs))
 
 
-def haar_idwt2d(lls, lh, hl, hh, in_scale=1.0, outs=None, stacked_bands=None, out0_prologue=None):
+def haar_idwt2d(lls, lh, hl, hh, in_scale=1.0, outs=None, stacked_bands=None, out0_prologue=None, pack_bf16=False):
     """lls: list of 1 or 2 low bands sharing the high bands; returns a list of reconstructions.
     ``stacked_bands`` [B, 3C, N, h, w] (the convH_0 output) supplies lh/hl/hh as channel slices
     without copying them out.  out0_prologue (lls[0] must then be [B, C, N, h, w]): the consumer convolution's prologue
@@ -364,6 +381,17 @@ def haar_idwt2d(lls, lh, hl, hh, in_scale=1.0, outs=None, stacked_bands=None, ou
     ll0 = lls[0]
     h, w = ll0.shape[-2:]
     planes = ll0.numel() // (h * w)
+    if pack_bf16:     # bf16 mode: first reconstruction as packed bf16 units, second one fp32; stacked bands only
+        if len(lls) != 2 or stacked_bands is None:
+            raise ValueError("haar_idwt2d(pack_bf16=True) takes two low bands and stacked high bands")
+        b, c, n = ll0.shape[:3]
+        units = torch.empty(b, c // 8, n * 4 * h * w, 8, device=ll0.device, dtype=torch.int16)
+        out1 = torch.empty(b, c, n, 2 * h, 2 * w, device=ll0.device, dtype=torch.float32)
+        pro = _plane_prologue(out0_prologue, c, n) if out0_prologue is not None else None
+        check(lib.tmdiff_haar_idwt2d_pack_bf16(_chk(ll0, "ll0"), _chk(lls[1], "ll1"), _chk(stacked_bands, "bands"),
+                                               units.data_ptr(), out1.data_ptr(), b, c, n, h, w, in_scale, pro, stream_ptr()),
+              "haar_idwt2d_pack_bf16")
+        return [units, out1]
     if outs is None:
         outs = [torch.empty((*ll0.shape[:-2], 2 * h, 2 * w), device=ll0.device, dtype=torch.float32) for _ in lls]
     llp = (C.c_void_p * 2)(*[_chk(t, "ll") for t in lls], *([None] * (2 - len(lls))))
