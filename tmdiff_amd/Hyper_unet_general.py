@@ -550,6 +550,7 @@ class WavBEST(nn.Module):
         ``.data`` or a raw kernel (the EMA update does)."""
         self._prep = None
         self._cond = None
+        self.__dict__.pop("_train_pack", None)       # the training path's packed weights (ops.PackedWeights)
 
     # ---- forward ------------------------------------------------------------------------------------
     def forward(self, x_t, t_input, PAN=None, MS=None, prompt=None):
