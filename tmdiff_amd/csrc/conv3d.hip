@@ -636,7 +636,8 @@ Conv3Plan plan_conv3(const tmdiff_conv3d_desc* d) {
   const long wg256 = boxes48 * ((cout_g + 63) / 64);
   // Layers whose 256-position grid would leave CUs idle or badly quantised (the 8x8x8 level: 128-384 workgroups) use
   // 128-position tiles; 32-channel tiles take 512 positions when that still gives every CU a workgroup.
-  if (c64 && wg256 < 2 * 256 && d->N > 2) {
+  static const long small_limit = getenv("TMDIFF_SMALLGRID") ? atol(getenv("TMDIFF_SMALLGRID")) : 2 * 256;  // experiments
+  if (c64 && wg256 < small_limit && d->N > 2) {
     p.tile = 0;
     p.blocks = (long)d->B * d->groups * ((d->N + 1) / 2) * ((d->H + 7) / 8) * ((d->W + 7) / 8) * (cout_g / 64);
   } else if (c64) {
