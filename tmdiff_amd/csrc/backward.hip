@@ -10,6 +10,17 @@
 
 #include "common.h"
 
+#ifndef TMDIFF_WGRAD_SPAN8
+// Eighths of a box's K-steps over which the DMA pieces of the next box are issued (0 = one burst up front).  The LDS-DMA of
+// dword pieces is the kernel's limiter (ablations on one box, weighted TFLOP/s: no in-loop DMA 115, a third of the x pieces
+// 102, all pieces 88-95): the earlier the pieces go out the earlier they have trickled in -- 8/8: 82, 5/8: 88, 2/8: 93,
+// 1/8: 95, burst: 94.
+#define TMDIFF_WGRAD_SPAN8 1
+#endif
+#ifndef TMDIFF_WGRAD_DEBUG
+#define TMDIFF_WGRAD_DEBUG 0  // experiment switches (results wrong): 1 = no in-loop DMA, 2 = no per-box barrier, 4 = no operand reads, 8 = a third of the x pieces
+#endif
+
 namespace {
 
 template <int B, int E, class F>
@@ -217,7 +228,7 @@ __global__ void __launch_bounds__(64 * WG_WAVES, 1) conv3d_wgrad_kernel(const Wg
       if constexpr (j < GJ) {
         const bool ok = (goff[j] >= 0) & (co0 + ch < a.cout_g);
         dma_word(ok ? gbase + (long)ch * plane + goff[j] : &kZeroWord, st + ch * GS + j * 64);
-      } else {
+      } else if constexpr (!((TMDIFF_WGRAD_DEBUG & 8) && ((j - GJ) % 3 != 0))) {   // (8: only every third x piece: results wrong)
         constexpr int jj = j - GJ;
         const bool ok = (xoff[jj] >= 0) & (ci0 + ch < a.cin_g);
         dma_word(ok ? xbase + (long)ch * plane + xoff[jj] : &kZeroWord, st + 32 * GS + ch * XS + jj * 64);
@@ -257,6 +268,8 @@ __global__ void __launch_bounds__(64 * WG_WAVES, 1) conv3d_wgrad_kernel(const Wg
       if (do_bias) bsum += av[k0 & 1];
     };
     fetch(std::integral_constant<int, 0>{});
+    if constexpr (TMDIFF_WGRAD_SPAN8 == 0)   // experiments: the whole next box requested up front
+      static_for<0, NPIECE>([&](auto ic) __attribute__((always_inline)) { issue_piece(ic, st_next); });
     static_for<0, PER_WAVE>([&](auto kc) __attribute__((always_inline)) {
       constexpr int k0 = decltype(kc)::value;
       static_for<0, NT>([&](auto jc) __attribute__((always_inline)) {
@@ -265,15 +278,16 @@ __global__ void __launch_bounds__(64 * WG_WAVES, 1) conv3d_wgrad_kernel(const Wg
         acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[k0 & 1], bv[k0 & 1][j], acc[j], 0, 0, 0);
         if constexpr (j == 0) {
           __builtin_amdgcn_sched_barrier(0);
-          if constexpr (k0 + 1 < PER_WAVE) fetch(std::integral_constant<int, k0 + 1>{});
+          if constexpr (k0 + 1 < PER_WAVE && !(TMDIFF_WGRAD_DEBUG & 4)) fetch(std::integral_constant<int, k0 + 1>{});
           __builtin_amdgcn_sched_barrier(0);
         }
       });
       __builtin_amdgcn_sched_barrier(0);
-      // (all pieces go out in the first 5/8 of the box, so that the last ones have landed when the barrier comes)
-      constexpr int SPAN = PER_WAVE * 5 / 8 > 0 ? PER_WAVE * 5 / 8 : 1;
+      // (all pieces go out in the first TMDIFF_WGRAD_SPAN8 eighths of the box, so that they have landed when the barrier comes)
+      constexpr int SPAN = PER_WAVE * TMDIFF_WGRAD_SPAN8 / 8 > 0 ? PER_WAVE * TMDIFF_WGRAD_SPAN8 / 8 : 1;
       constexpr int p_lo = k0 < SPAN ? k0 * NPIECE / SPAN : NPIECE, p_hi = k0 < SPAN ? (k0 + 1) * NPIECE / SPAN : NPIECE;
-      static_for<p_lo, p_hi>([&](auto ic) __attribute__((always_inline)) { issue_piece(ic, st_next); });
+      if constexpr (!(TMDIFF_WGRAD_DEBUG & 1) && TMDIFF_WGRAD_SPAN8 != 0)
+        static_for<p_lo, p_hi>([&](auto ic) __attribute__((always_inline)) { issue_piece(ic, st_next); });
       __builtin_amdgcn_sched_barrier(0);
     });
   };
@@ -290,11 +304,11 @@ __global__ void __launch_bounds__(64 * WG_WAVES, 1) conv3d_wgrad_kernel(const Wg
     //  the MFMA stream stays free of branches)
     locate(bx + 1 < box_hi ? bx + 1 : box_lo);
     mfma_box(st0, st1);
-    __syncthreads();
+    if constexpr (!(TMDIFF_WGRAD_DEBUG & 2)) __syncthreads();
     if (bx + 1 < box_hi) {
       locate(bx + 2 < box_hi ? bx + 2 : box_lo);
       mfma_box(st1, st0);
-      __syncthreads();
+      if constexpr (!(TMDIFF_WGRAD_DEBUG & 2)) __syncthreads();
     }
   }
   // ---- the waves that shared a tap (KS=3: the two band planes; KS=1: all eight) add their accumulators through LDS in a
