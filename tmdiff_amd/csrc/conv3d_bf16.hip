@@ -25,6 +25,18 @@
 
 #include "common.h"
 
+// Experiment switches of the packed-input kernel (tools/build_variant.sh; every one of them gives wrong results):
+// 1 = no LDS-DMA inside the chunk loop, 2 = no weight pieces inside the loop, 4 = no output stores, 8 = no barriers,
+// 16 = no input pieces inside the loop.
+#ifndef TMDIFF_BF16_DEBUG
+#define TMDIFF_BF16_DEBUG 0
+#endif
+// Diagnostic build (-DTMDIFF_BF16_STAMPS=1, tools/bf16_stamps.py): every wave of the packed-input kernel adds up its
+// s_memtime cycles per phase into d->splitk_ws (8 counters per wave); no stamp exists in the production build.
+#ifndef TMDIFF_BF16_STAMPS
+#define TMDIFF_BF16_STAMPS 0
+#endif
+
 namespace {
 
 using f32x16 = __attribute__((ext_vector_type(16))) float;
@@ -51,6 +63,8 @@ struct BfArgs {
   int y2_shift_stride, y2_scale_stride, y2_act;
   int tiles_n, tiles_h, tiles_w, tiles_co;
   unsigned total_blocks;
+  int vec4;                     // W % 4 == 0 and y / residual 16-byte aligned: dwordx4 epilogue through LDS
+  unsigned long long* stamps;   // diagnostic builds only
 };
 
 template <int B, int E, class F>
@@ -99,28 +113,63 @@ __device__ __forceinline__ unsigned pack_bf16x2(float lo, float hi) {
   return p.u;
 }
 
-// Epilogue shared by both kernels: D layout col = lane&31 (position), row (r&3) + 8*(r>>2) + 4*kg (channel);
-// bias_v[m] holds (in lane l31) the scaled bias of channel co0 + m*32 + l31.
-template <int NS, int MSUB, int TW>
-__device__ __forceinline__ void store_tile(const BfArgs& a, f32x16 (&acc)[NS][MSUB], const float (&bias_v)[MSUB], int b,
-                                           int g, int co0, int n0, int h0, int w0, int wv, int l31, int kg, long plane) {
-  float sh2_v[MSUB], sc2_v[MSUB];  // second-output shift / scale of channel co0 + m*32 + l31
+// SiLU of the bf16 mode: the quotient by v_rcp_f32 (1 ulp) instead of the IEEE division sequence (a dozen instructions
+// per element, which made the second-output epilogue cost more than the tile's MFMAs); the result is rounded to bf16
+// right after.  Every prologue evaluation of this file uses it, so producer- and consumer-side packing stay bit-equal.
+__device__ __forceinline__ float silu_bf(float v) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  return v * __builtin_amdgcn_rcpf(1.0f + __expf(-v));
+#else
+  return v;
+#endif
+}
+
+// Epilogue, D layout: col = lane&31 (position), row (r&3) + 8*(r>>2) + 4*kg (channel).  xxx_v[m] hold (in lane l31) the
+// scaled bias / second-output shift / scale of channel co0 + m*32 + l31.
+// The consumer's prologue on 16 finished values of one position, rounded to bf16 and regrouped into units of 8
+// consecutive channels: register quads (0-3, 4-7) hold channels {0-3, 8-11} in lanes 0-31 and {4-7, 12-15} in lanes
+// 32-63; trading halves gives lanes 0-31 channels 0-7 and lanes 32-63 channels 8-15 (same for quads 8-11, 12-15).
+__device__ __forceinline__ void second_output_units(const f32x16& v, const float (&sh)[16], const float (&sc)[16], bool act,
+                                                    uint4& lo, uint4& hi) {
+  unsigned d[8];
 #pragma unroll
-  for (int m = 0; m < MSUB; ++m) {
-    const int col = g * a.cout_g + co0 + m * 32 + l31;
-    sh2_v[m] = (a.y2 && a.y2_shift) ? a.y2_shift[(long)b * a.y2_shift_stride + col] : 0.f;
-    sc2_v[m] = (a.y2 && a.y2_scale) ? a.y2_scale[(long)b * a.y2_scale_stride + col] : 1.f;
-  }
+  for (int r = 0; r < 16; r += 2) {
+    float t[2];
 #pragma unroll
-  for (int m = 0; m < MSUB; ++m) {
-    float bias_r[16];
-#pragma unroll
-    for (int r = 0; r < 16; ++r) {
-      const int row = (r & 3) + 8 * (r >> 2);
-      const float b0 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(bias_v[m]), row));
-      const float b1 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(bias_v[m]), row + 4));
-      bias_r[r] = kg ? b1 : b0;
+    for (int e = 0; e < 2; ++e) {
+      const float u = v[r + e] + sh[r + e];
+      t[e] = (act ? silu_bf(u) : u) * sc[r + e];
     }
+    d[r / 2] = pack_bf16x2(t[0], t[1]);
+  }
+  swap_halves(d[0], d[2]); swap_halves(d[1], d[3]);   // quads 0 / 1
+  swap_halves(d[4], d[6]); swap_halves(d[5], d[7]);   // quads 2 / 3
+  lo = make_uint4(d[0], d[1], d[2], d[3]);   // channel octet kg
+  hi = make_uint4(d[4], d[5], d[6], d[7]);   // channel octet 2 + kg
+}
+
+// this lane's 16 per-register channel constants out of the per-lane vector (channel l31)
+__device__ __forceinline__ void lane_rows(float v, int kg, float (&out)[16]) {
+#pragma unroll
+  for (int r = 0; r < 16; ++r) {
+    const int row = (r & 3) + 8 * (r >> 2);
+    const float x0 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), row));
+    const float x1 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), row + 4));
+    out[r] = kg ? x1 : x0;
+  }
+}
+
+// Generic epilogue (any width, any alignment): one dword per register.
+template <int NS, int MSUB, int TW>
+__device__ __forceinline__ void store_tile(const BfArgs& a, f32x16 (&acc)[NS][MSUB], const float (&bias_v)[MSUB],
+                                           const float (&sh2_v)[MSUB], const float (&sc2_v)[MSUB], int b, int g, int co0,
+                                           int n0, int h0, int w0, int wv, int l31, int kg, long plane) {
+#pragma unroll
+  for (int m = 0; m < MSUB; ++m) {
+    float bias_r[16], sh2_r[16], sc2_r[16];
+    lane_rows(bias_v[m], kg, bias_r);
+    lane_rows(sh2_v[m], kg, sh2_r);
+    lane_rows(sc2_v[m], kg, sc2_r);
 #pragma unroll
     for (int s = 0; s < NS; ++s) {
       constexpr int per_row = TW / 8;
@@ -142,36 +191,118 @@ __device__ __forceinline__ void store_tile(const BfArgs& a, f32x16 (&acc)[NS][MS
         acc[s][m][r] = v;
       }
       if (a.y2) {
-        // The consumer's prologue on the finished values, rounded to bf16 and regrouped into units of 8 consecutive
-        // channels: register quads (0-3, 4-7) hold channels {0-3, 8-11} in lanes 0-31 and {4-7, 12-15} in lanes 32-63;
-        // trading halves gives lanes 0-31 channels 0-7 and lanes 32-63 channels 8-15 (same for quads 8-11, 12-15).
-        unsigned d[8];
-#pragma unroll
-        for (int r = 0; r < 16; r += 2) {
-          float t[2];
-#pragma unroll
-          for (int e = 0; e < 2; ++e) {
-            const int row = ((r + e) & 3) + 8 * ((r + e) >> 2);
-            const float s0 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(sh2_v[m]), row));
-            const float s1 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(sh2_v[m]), row + 4));
-            const float c0 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(sc2_v[m]), row));
-            const float c1 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(sc2_v[m]), row + 4));
-            float u = acc[s][m][r + e] + (kg ? s1 : s0);
-            const float ua = tmdiff::silu_f(u);
-            t[e] = (a.y2_act ? ua : u) * (kg ? c1 : c0);
-          }
-          d[r / 2] = pack_bf16x2(t[0], t[1]);
-        }
-        swap_halves(d[0], d[2]); swap_halves(d[1], d[3]);   // quads 0 / 1
-        swap_halves(d[4], d[6]); swap_halves(d[5], d[7]);   // quads 2 / 3
+        uint4 lo, hi;
+        second_output_units(acc[s][m], sh2_r, sc2_r, a.y2_act != 0, lo, hi);
         const long ubase = ((long)b * (a.Cout / 8) + (g * a.cout_g + co0 + m * 32) / 8 + kg) * plane + sp;
-        if (pok) {
-          a.y2[ubase] = make_uint4(d[0], d[1], d[2], d[3]);              // channel octet kg
-          a.y2[ubase + 2 * plane] = make_uint4(d[4], d[5], d[6], d[7]);  // channel octet 2 + kg
-        }
+        if (pok) a.y2[ubase] = lo, a.y2[ubase + 2 * plane] = hi;
       }
     }
   }
+}
+
+// Vector epilogue (a.vec4: W % 4 == 0, y / residual 16-byte aligned), specialised on what is read and written and on the
+// tile lying wholly inside the image (FULL: no predicates).  A vector-memory instruction costs its wave a fixed price
+// whatever its width, and straight from the D layout every register is one dword store (and one residual load) of
+// 32-byte runs -- 136 instructions per wave for four sub-tiles, 12-39 k cycles against 7 k cycles of MFMAs (s_memtime
+// stamps, tools/bf16_stamps.py).  Here a 32 x 32 sub-tile goes through a wave-private 4 KB LDS tile T[channel][position]
+// (ds_write_b32 in the D layout, ds_read_b128 along the positions) and leaves as dwordx4: lane (tc, tq) owns channels
+// tc + 8j and the 4 consecutive w of quarter-row tq; all residual quads of the tile are requested first.  When a second
+// output is wanted on top of a residual the finished values make the trip back (ds_write_b128 / ds_read_b32) into the D
+// layout, which is what the packed bf16 units want (one position, 8 channels per lane).  LDS traffic of one wave is
+// processed in order, so the tile needs no barrier, only the compiler kept from reordering (wavefront fence).
+template <int NS, int MSUB, int TW, bool Y, bool RES, bool Y2, bool FULL>
+__device__ __forceinline__ void store_tile_v(const BfArgs& a, f32x16 (&acc)[NS][MSUB], const float (&bias_v)[MSUB],
+                                             const float (&sh2_v)[MSUB], const float (&sc2_v)[MSUB], int b, int g, int co0,
+                                             int n0, int h0, int w0, int wv, int l31, int kg, long plane, float* T) {
+  constexpr int per_row = TW / 8;
+  const int lane = l31 + 32 * kg, tq = lane & 7, tc = lane >> 3;
+  const int n = n0 + wv;
+  int toff[NS], poff[NS];      // offsets inside a channel plane: the transposed lane's quad, the D-layout lane's position
+  bool tok[NS], pok[NS];
+#pragma unroll
+  for (int s = 0; s < NS; ++s) {
+    const int hs = h0 + (s / per_row) * 4, ws = w0 + (s % per_row) * 8;
+    const int ht = hs + (tq >> 1), wt = ws + (tq & 1) * 4;      // (W % 4 == 0: the four positions stand or fall together)
+    const int h = hs + (l31 >> 3), w = ws + (l31 & 7);
+    tok[s] = FULL || (n < a.N && ht < a.H && wt < a.W);
+    pok[s] = FULL || (n < a.N && h < a.H && w < a.W);
+    toff[s] = tok[s] ? (n * a.H + ht) * a.W + wt : 0;
+    poff[s] = pok[s] ? (n * a.H + h) * a.W + w : 0;
+  }
+  const long cbase = ((long)b * a.Cout + g * a.cout_g + co0 + tc) * plane;
+  // residual quads of sub-tile (s, m): requested one sub-tile ahead of their use
+  float4 rs[NS * MSUB + 1][4];
+  auto load_res = [&](int i) __attribute__((always_inline)) {
+    const int m = i / NS, s = i % NS;
+#pragma unroll
+    for (int j = 0; j < 4; ++j)   // (outside the image: a valid address, the value is never stored)
+      rs[i][j] = *reinterpret_cast<const float4*>(a.residual + cbase + (long)(m * 32 + 8 * j) * plane + toff[s]);
+  };
+  if constexpr (RES) load_res(0);
+#pragma unroll
+  for (int m = 0; m < MSUB; ++m) {
+    float bias_r[16], sh2_r[16], sc2_r[16];
+    lane_rows(bias_v[m], kg, bias_r);
+    if constexpr (Y2) {
+      lane_rows(sh2_v[m], kg, sh2_r);
+      lane_rows(sc2_v[m], kg, sc2_r);
+    }
+#pragma unroll
+    for (int s = 0; s < NS; ++s) {
+      if constexpr (RES) {
+        if (m * NS + s + 1 < NS * MSUB) load_res(m * NS + s + 1);
+      }
+      if constexpr (Y || RES) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) T[((r & 3) + 8 * (r >> 2) + 4 * kg) * 32 + l31] = acc[s][m][r] + bias_r[r];
+        __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          float4 t = *reinterpret_cast<const float4*>(T + (tc + 8 * j) * 32 + tq * 4);
+          if constexpr (RES) {
+            const float4 q = rs[m * NS + s][j];
+            t.x += q.x, t.y += q.y, t.z += q.z, t.w += q.w;
+          }
+          t.x *= a.out_scale, t.y *= a.out_scale, t.z *= a.out_scale, t.w *= a.out_scale;
+          if constexpr (Y) {
+            float4* dst = reinterpret_cast<float4*>(a.y + cbase + (long)(m * 32 + 8 * j) * plane + toff[s]);
+            if (FULL || tok[s]) *dst = t;
+          }
+          if constexpr (Y2 && RES) *reinterpret_cast<float4*>(T + (tc + 8 * j) * 32 + tq * 4) = t;
+        }
+        __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+      }
+      if constexpr (Y2) {
+        if constexpr (RES) {
+#pragma unroll
+          for (int r = 0; r < 16; ++r) acc[s][m][r] = T[((r & 3) + 8 * (r >> 2) + 4 * kg) * 32 + l31];
+          __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+        } else {
+#pragma unroll
+          for (int r = 0; r < 16; ++r) acc[s][m][r] = (acc[s][m][r] + bias_r[r]) * a.out_scale;
+        }
+        uint4 lo, hi;
+        second_output_units(acc[s][m], sh2_r, sc2_r, a.y2_act != 0, lo, hi);
+        uint4* dst = a.y2 + ((long)b * (a.Cout / 8) + (g * a.cout_g + co0 + m * 32) / 8 + kg) * plane + poff[s];
+        if (FULL || pok[s]) dst[0] = lo, dst[2 * plane] = hi;
+      }
+    }
+  }
+}
+
+template <int NS, int MSUB, int TW, bool FULL>
+__device__ __forceinline__ void store_tile_vec(const BfArgs& a, f32x16 (&acc)[NS][MSUB], const float (&bias_v)[MSUB],
+                                               const float (&sh2_v)[MSUB], const float (&sc2_v)[MSUB], int b, int g, int co0,
+                                               int n0, int h0, int w0, int wv, int l31, int kg, long plane, float* T) {
+#define TMDIFF_EPI(Y, R, Y2) \
+  store_tile_v<NS, MSUB, TW, Y, R, Y2, FULL>(a, acc, bias_v, sh2_v, sc2_v, b, g, co0, n0, h0, w0, wv, l31, kg, plane, T)
+  if (a.y) {
+    if (a.residual) { if (a.y2) TMDIFF_EPI(true, true, true); else TMDIFF_EPI(true, true, false); }
+    else            { if (a.y2) TMDIFF_EPI(true, false, true); else TMDIFF_EPI(true, false, false); }
+  } else {
+    if (a.residual) TMDIFF_EPI(false, true, true); else TMDIFF_EPI(false, false, true);
+  }
+#undef TMDIFF_EPI
 }
 
 template <int NS, int MSUB, int TH, int TW, bool ACT>
@@ -244,6 +375,13 @@ __global__ void __launch_bounds__(256, 2) conv3d_bf16_kernel(const BfArgs a) {
   float bias_v[MSUB];
 #pragma unroll
   for (int m = 0; m < MSUB; ++m) bias_v[m] = a.bias ? a.bias[g * a.cout_g + co0 + m * 32 + l31] * a.bias_scale : 0.f;
+  float sh2_v[MSUB], sc2_v[MSUB];  // second-output shift / scale of channel co0 + m*32 + l31
+#pragma unroll
+  for (int m = 0; m < MSUB; ++m) {
+    const int col = g * a.cout_g + co0 + m * 32 + l31;
+    sh2_v[m] = (a.y2 && a.y2_shift) ? a.y2_shift[(long)b * a.y2_shift_stride + col] : 0.f;
+    sc2_v[m] = (a.y2 && a.y2_scale) ? a.y2_scale[(long)b * a.y2_scale_stride + col] : 1.f;
+  }
 
   f32x16 acc[NS][MSUB];
 #pragma unroll
@@ -289,7 +427,7 @@ __global__ void __launch_bounds__(256, 2) conv3d_bf16_kernel(const BfArgs a) {
 #pragma unroll
       for (int j = 0; j < 8; ++j) {
         float v = xr[i][j] + sh[j];
-        if constexpr (ACT) v = tmdiff::silu_f(v);
+        if constexpr (ACT) v = silu_bf(v);
         v *= sc[j];
         pk.h[j] = (__bf16)(inb[i] ? v : 0.f);
       }
@@ -323,7 +461,7 @@ __global__ void __launch_bounds__(256, 2) conv3d_bf16_kernel(const BfArgs a) {
     __syncthreads();
   }
 
-  store_tile<NS, MSUB, TW>(a, acc, bias_v, b, g, co0, n0, h0, w0, wv, l31, kg, plane);
+  store_tile<NS, MSUB, TW>(a, acc, bias_v, sh2_v, sc2_v, b, g, co0, n0, h0, w0, wv, l31, kg, plane);
 }
 
 // ---- two-kernel variant: prologue + bf16 packing once, then a staging-free convolution -----------------------
@@ -366,7 +504,7 @@ __global__ void __launch_bounds__(256) pack_x_bf16_kernel(const BfArgs a, uint4*
 #pragma unroll
     for (int j = 0; j < 8; ++j) {
       float t = v[j] + sh[j];
-      if constexpr (ACT) t = tmdiff::silu_f(t);
+      if constexpr (ACT) t = silu_bf(t);
       pk.h[j] = (__bf16)(t * sc[j]);
     }
     xp[(long)bc * plane + pos] = pk.u;
@@ -386,6 +524,9 @@ __global__ void __launch_bounds__(256, 2) conv3d_bf16_dma_kernel(const BfArgs a,
   static_assert(TH * TW == 32 * NS, "a wave covers one band plane = NS tiles of 4x8 positions");
   __shared__ uint4 st0[STAGE];
   __shared__ uint4 st1[STAGE];
+#if TMDIFF_BF16_STAMPS
+  const unsigned long long t_entry = __builtin_amdgcn_s_memtime(), rt_entry = __builtin_amdgcn_s_memrealtime();
+#endif
 
   const int tid = threadIdx.x;
   const int lane = tid & 63, wv = tid >> 6;
@@ -448,6 +589,13 @@ __global__ void __launch_bounds__(256, 2) conv3d_bf16_dma_kernel(const BfArgs a,
     }
   };
 
+  // the first chunk is requested as soon as its addresses exist; the rest of the set-up runs under its flight time
+#if TMDIFF_BF16_STAMPS
+  const unsigned long long t_start = __builtin_amdgcn_s_memtime();
+#endif
+  static_for<0, NPIECE>([&](auto ic) __attribute__((always_inline)) { issue_piece(ic, 0, st0); });
+  __builtin_amdgcn_sched_barrier(0);
+
   // ---- operand addresses (16-byte units inside a stage) ---------------------------------------------------------
   const int lane_pos = (l31 >> 3) * RS + (l31 & 7);
   int baddr[TAPS2 / 2];
@@ -463,6 +611,13 @@ __global__ void __launch_bounds__(256, 2) conv3d_bf16_dma_kernel(const BfArgs a,
   float bias_v[MSUB];
 #pragma unroll
   for (int m = 0; m < MSUB; ++m) bias_v[m] = a.bias ? a.bias[g * a.cout_g + co0 + m * 32 + l31] * a.bias_scale : 0.f;
+  float sh2_v[MSUB], sc2_v[MSUB];  // second-output shift / scale of channel co0 + m*32 + l31
+#pragma unroll
+  for (int m = 0; m < MSUB; ++m) {
+    const int col = g * a.cout_g + co0 + m * 32 + l31;
+    sh2_v[m] = (a.y2 && a.y2_shift) ? a.y2_shift[(long)b * a.y2_shift_stride + col] : 0.f;
+    sc2_v[m] = (a.y2 && a.y2_scale) ? a.y2_scale[(long)b * a.y2_scale_stride + col] : 1.f;
+  }
 
   f32x16 acc[NS][MSUB];
 #pragma unroll
@@ -501,7 +656,8 @@ __global__ void __launch_bounds__(256, 2) conv3d_bf16_dma_kernel(const BfArgs a,
           if constexpr (p + 1 < TAPS2 / 2) fetch(std::integral_constant<int, p + 1>{});
           __builtin_amdgcn_sched_barrier(0);
         }
-        if constexpr (j == NS * MSUB - 1 && p < NPIECE) {
+        if constexpr (j == NS * MSUB - 1 && p < NPIECE && !(TMDIFF_BF16_DEBUG & 1) && !((TMDIFF_BF16_DEBUG & 2) && p >= XK) &&
+                      !((TMDIFF_BF16_DEBUG & 16) && p < XK)) {
           __builtin_amdgcn_sched_barrier(0);
           issue_piece(std::integral_constant<int, p>{}, c_next, st_next);
           __builtin_amdgcn_sched_barrier(0);
@@ -513,19 +669,68 @@ __global__ void __launch_bounds__(256, 2) conv3d_bf16_dma_kernel(const BfArgs a,
 
   // two stages, one barrier per chunk: while chunk c is multiplied out of one stage the pieces of chunk c+1 land in
   // the other; the barrier at the end of a chunk says "everyone has read this stage and my pieces have landed".
-  static_for<0, NPIECE>([&](auto ic) __attribute__((always_inline)) { issue_piece(ic, 0, st0); });
+#if TMDIFF_BF16_STAMPS
+  unsigned long long tk[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};   // prologue, mfma phase, landing wait, barrier, epilogue,
+                                                                      // total, HW_ID, LDS_ALLOC, realtime in / out, setup
+  unsigned long long t_a, t_b;
+#define STAMP_PHASE(i) (t_b = __builtin_amdgcn_s_memtime(), tk[i] += t_b - t_a, t_a = t_b)
+#else
+#define STAMP_PHASE(i) ((void)0)
+#endif
   __syncthreads();
+#if TMDIFF_BF16_STAMPS
+  t_a = __builtin_amdgcn_s_memtime();
+  tk[0] = t_a - t_start;
+#endif
+  auto chunk_end = [&]() __attribute__((always_inline)) {
+#if TMDIFF_BF16_STAMPS
+    STAMP_PHASE(1);
+    __builtin_amdgcn_s_waitcnt(0x0F70);   // vmcnt(0): this wave's pieces have landed
+    STAMP_PHASE(2);
+#endif
+    if constexpr (!(TMDIFF_BF16_DEBUG & 8)) __syncthreads();
+    STAMP_PHASE(3);
+  };
   for (int c = 0; c < nchunks; c += 2) {
     // (past the last chunk the pieces of chunk 0 are fetched again into the idle stage: valid addresses, nobody
     //  reads them, and the MFMA stream stays free of branches)
     mfma_chunk(st0, c + 1 < nchunks ? c + 1 : 0, st1);
-    __syncthreads();
+    chunk_end();
     if (c + 1 < nchunks) {
       mfma_chunk(st1, c + 2 < nchunks ? c + 2 : 0, st0);
-      __syncthreads();
+      chunk_end();
     }
   }
-  store_tile<NS, MSUB, TW>(a, acc, bias_v, b, g, co0, n0, h0, w0, wv, l31, kg, plane);
+  if constexpr (TMDIFF_BF16_DEBUG & 4) {   // keep the accumulators alive, store (practically) nothing
+    float t = 0.f;
+#pragma unroll
+    for (int s = 0; s < NS; ++s)
+#pragma unroll
+      for (int m = 0; m < MSUB; ++m)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) t += acc[s][m][r];
+    if (t == 123456.789f && a.y) a.y[0] = t;
+    return;
+  }
+  // (the chunk loop ends with a barrier: nobody reads the stages any more)
+  static_assert(sizeof(st0) >= 4 * 4096, "the epilogue borrows 4 KB of LDS per wave");
+  float* const T = reinterpret_cast<float*>(st0) + wv * 1024;
+  if (!a.vec4)
+    store_tile<NS, MSUB, TW>(a, acc, bias_v, sh2_v, sc2_v, b, g, co0, n0, h0, w0, wv, l31, kg, plane);
+  else if (n0 + TN <= a.N && h0 + TH <= a.H && w0 + TW <= a.W)
+    store_tile_vec<NS, MSUB, TW, true>(a, acc, bias_v, sh2_v, sc2_v, b, g, co0, n0, h0, w0, wv, l31, kg, plane, T);
+  else
+    store_tile_vec<NS, MSUB, TW, false>(a, acc, bias_v, sh2_v, sc2_v, b, g, co0, n0, h0, w0, wv, l31, kg, plane, T);
+#if TMDIFF_BF16_STAMPS
+  __builtin_amdgcn_s_waitcnt(0x0F70);     // (stores issued and acknowledged)
+  STAMP_PHASE(4);
+  tk[5] = t_a - t_start;
+  tk[6] = __builtin_amdgcn_s_getreg(0xF804), tk[7] = __builtin_amdgcn_s_getreg(0xF806);
+  tk[8] = rt_entry, tk[9] = __builtin_amdgcn_s_memrealtime(), tk[10] = t_start - t_entry;
+  if (a.stamps && lane == 0)
+    for (int i = 0; i < 12; ++i) a.stamps[((long)blockIdx.x * 4 + wv) * 12 + i] = tk[i];
+#endif
+#undef STAMP_PHASE
 }
 
 // ---- 1x1x1 convolution, bf16 operands -------------------------------------------------------------------------
@@ -599,7 +804,7 @@ __global__ void __launch_bounds__(256, 2) conv1_bf16_kernel(const BfArgs a) {
 #pragma unroll
       for (int j = 0; j < 8; ++j) {
         float v = xr[buf][s][j] + shs[buf][j];
-        if constexpr (ACT) v = tmdiff::silu_f(v);
+        if constexpr (ACT) v = silu_bf(v);
         bv[s].h[j] = (__bf16)(v * scs[buf][j]);
       }
 #pragma unroll
@@ -798,6 +1003,8 @@ extern "C" int tmdiff_conv3d_fwd_bf16(const tmdiff_conv3d_desc* d, void* workspa
   a.y2 = reinterpret_cast<uint4*>(d->y2); a.y2_shift = d->y2_shift; a.y2_scale = d->y2_scale; a.y2_act = d->y2_act;
   a.y2_shift_stride = d->y2_shift_stride > 0 ? d->y2_shift_stride : (d->y2_shift_stride < 0 ? 0 : d->Cout);
   a.y2_scale_stride = d->y2_scale_stride > 0 ? d->y2_scale_stride : (d->y2_scale_stride < 0 ? 0 : d->Cout);
+  a.vec4 = d->W % 4 == 0 && (!d->y || aligned16(d->y)) && (!d->residual || aligned16(d->residual));
+  a.stamps = TMDIFF_BF16_STAMPS ? static_cast<unsigned long long*>(d->splitk_ws) : nullptr;
   hipStream_t st = as_stream(stream);
   if (d->x_bf16) {  // input already packed by its producer: straight to the staging-free kernel
     const uint4* xp = reinterpret_cast<const uint4*>(d->seg_x[0]);
