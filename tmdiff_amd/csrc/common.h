@@ -64,6 +64,8 @@ struct Conv3Plan {
   int ksplit;    // 1 = no split; else the chunks (4 input channels each) are divided into ksplit equal ranges
 };
 Conv3Plan plan_conv3(const tmdiff_conv3d_desc* d);
+// the dwordx4 epilogue (epilogue.h) applies: W % 4 == 0, 16-byte aligned outputs / residual (TMDIFF_EPILOGUE_VEC=0: never)
+bool epilogue_vec_ok(const tmdiff_conv3d_desc* d);
 
 // sum of the split-K partials + epilogue (conv3d.hip)
 struct SplitKReduceArgs {

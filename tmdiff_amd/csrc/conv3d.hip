@@ -22,6 +22,7 @@
 #include <type_traits>
 
 #include "common.h"
+#include "epilogue.h"
 
 #ifndef TMDIFF_CONV_DEBUG
 #define TMDIFF_CONV_DEBUG 0  // experiment switches: 1 = no in-loop global loads, 2 = no hand-off items (results wrong)
@@ -72,6 +73,7 @@ struct ConvArgs {
   float drop_inv;
   int ksplit, split_ch;                     // split-K: ksplit ranges of split_ch input channels (1, cin_g = no split)
   float* part;                              // split-K partial outputs [ksplit][B][Cout][plane] (NULL = no split)
+  int vec4;                                 // W % 4 == 0, y / y2 / residual 16-byte aligned: dwordx4 epilogue (epilogue.h)
 };
 
 // Tile geometry.  A workgroup = 4 waves; wave w owns NS position sub-tiles (32 positions each) x MSUB
@@ -376,7 +378,16 @@ __global__ void __launch_bounds__(256, 2) conv3d_mfma_kernel(const ConvArgs a) {
     return;
   }
 
-  // ---- epilogue: bias, residual, scale; D layout: col = lane&31 (position), row = channel --------
+  if constexpr (FAST) {
+    if (a.vec4) {
+      static_assert(sizeof(lds) >= 4 * 4096, "the epilogue borrows 4 KB of LDS per wave");
+      __syncthreads();   // (the chunk loop leaves without a barrier: the other waves may still be reading the stage)
+      tmdiff::epilogue_vec<NS, MSUB, TN, TH, TW>(a, acc, bias_v, sh2_v, sc2_v, b, g, co0, n0, h0, w0, wv, lane, plane,
+                                                 lds + wv * 1024);
+      return;
+    }
+  }
+  // ---- scalar epilogue: bias, residual, scale; D layout: col = lane&31 (position), row = channel --------
   // Loads first (bias rows, then all residual elements of a sub-tile), then the stores: no load->store chains.
 #pragma unroll
   for (int m = 0; m < MSUB; ++m) {
@@ -628,6 +639,14 @@ static long splitk_target() {
   return t;
 }
 
+bool epilogue_vec_ok(const tmdiff_conv3d_desc* d) {
+  static const bool on = [] {
+    const char* e = getenv("TMDIFF_EPILOGUE_VEC");   // experiments: "0" = the scalar epilogue everywhere
+    return !(e && e[0] == '0');
+  }();
+  return on && d->W % 4 == 0 && aligned16(d->y) && aligned16(d->residual) && (d->y2_bf16 || aligned16(d->y2));
+}
+
 Conv3Plan plan_conv3(const tmdiff_conv3d_desc* d) {
   Conv3Plan p{3, 0, 1};
   const int cin_g = d->Cin / d->groups, cout_g = d->Cout / d->groups;
@@ -762,6 +781,7 @@ extern "C" int tmdiff_conv3d_fwd(const tmdiff_conv3d_desc* d, tmdiff_stream_t st
   a.y2_shift_stride = d->y2_shift_stride > 0 ? d->y2_shift_stride : (d->y2_shift_stride < 0 ? 0 : d->Cout);
   a.y2_scale_stride = d->y2_scale_stride > 0 ? d->y2_scale_stride : (d->y2_scale_stride < 0 ? 0 : d->Cout);
   a.w_vec4 = (a.cout_g % 4 == 0) && aligned16(d->w_packed);
+  a.vec4 = epilogue_vec_ok(d);
   hipStream_t st = as_stream(stream);
 
   a.ksplit = 1; a.split_ch = a.cin_g; a.part = nullptr;

@@ -16,6 +16,7 @@
 #include <type_traits>
 
 #include "common.h"
+#include "epilogue.h"
 
 namespace {
 
@@ -47,6 +48,7 @@ struct DmaArgs {
   unsigned total_blocks;
   int ksplit, split_chunks;  // split-K: ksplit ranges of split_chunks chunks each (1, cin_g / KC = no split)
   float* part;               // split-K partial outputs [ksplit][B][Cout][plane] (NULL = no split)
+  int vec4;                  // W % 4 == 0 and y / y2 / residual 16-byte aligned: dwordx4 epilogue (epilogue.h)
 };
 
 __device__ const float4 kZero4 = {0.f, 0.f, 0.f, 0.f};  // source of zero padding / filler lanes
@@ -252,7 +254,13 @@ __global__ void __launch_bounds__(256, 2) conv3d_dma_kernel(const DmaArgs a) {
     return;
   }
 
-  // ---- epilogue: bias, residual, scale; D layout: col = lane&31 (position), row = channel ----------------------
+  if (a.vec4) {   // (the chunk loop ends with a barrier: nobody reads the stages any more)
+    static_assert(sizeof(st0) >= 4 * 4096, "the epilogue borrows 4 KB of LDS per wave");
+    tmdiff::epilogue_vec<NS, MSUB, TN, TH, TW>(a, acc, bias_v, sh2_v, sc2_v, b, g, co0, n0, h0, w0, wv, lane, plane,
+                                               st0 + wv * 1024);
+    return;
+  }
+  // ---- scalar epilogue: bias, residual, scale; D layout: col = lane&31 (position), row = channel ---------------
 #pragma unroll
   for (int m = 0; m < MSUB; ++m) {
     float bias_r[16];
@@ -373,6 +381,7 @@ extern "C" int tmdiff_conv3d_fwd_staged(const tmdiff_conv3d_desc* d, void* works
   a.y2 = d->y2; a.y2_shift = d->y2_shift; a.y2_scale = d->y2_scale; a.y2_act = d->y2_act;
   a.y2_shift_stride = d->y2_shift_stride > 0 ? d->y2_shift_stride : (d->y2_shift_stride < 0 ? 0 : d->Cout);
   a.y2_scale_stride = d->y2_scale_stride > 0 ? d->y2_scale_stride : (d->y2_scale_stride < 0 ? 0 : d->Cout);
+  a.vec4 = tmdiff::epilogue_vec_ok(d);
 
   // tile configuration and split-K factor: plan_conv3 (conv3d.hip), the same rule as tmdiff_conv3d_fwd
   Conv3Plan plan = plan_conv3(d);

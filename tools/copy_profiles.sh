@@ -11,3 +11,5 @@ cp $R/attention.txt profiles/${TAG}_attention.txt; cp $R/pmc_attention.txt profi
 cp $R/hbm_kernels.txt profiles/${TAG}_hbm_kernels.txt; grep config $R/configs.txt | grep -v Warning > profiles/${TAG}_configs.txt
 tail -1 $R/bench_line.json > profiles/${TAG}_bench_line.json; tail -1 $R/bench_train_line.json > profiles/${TAG}_bench_train_line.json
 grep "^{" $R/train_2rank_gloo.json > profiles/${TAG}_train_2rank_gloo.json
+cp $R/conv_bf16_packed.txt profiles/${TAG}_conv_bf16_packed.txt; cp $R/conv_bf16_stamps.txt profiles/${TAG}_conv_bf16_stamps.txt
+cp $R/prof_bf16/p_kernel_stats.csv profiles/${TAG}_bf16_step_kernel_stats.csv
