@@ -283,3 +283,67 @@ def test_bench_train_two_ranks_share_the_gpu_over_gloo():
     assert ar["buckets"] >= 3 and ar["launched_from_backward_hooks"] == ar["buckets"]
     assert 100 < ar["payload_mb"] < 130                      # 216 gradient tensors of the ch 32-256 network, fp32
     assert np.isfinite(line["train_step"]["loss"]) and line["train_step"]["ms_per_step"] > 0
+
+
+_RCCL_ONE_RANK = r"""
+import os, sys, json, torch, torch.distributed as dist
+sys.path.insert(0, sys.argv[1])
+from tmdiff_amd import dist as tdist
+from tmdiff_amd.Hyper_unet_general import WavBEST
+from tmdiff_amd.diffusion_general import GeneralDiffusion
+from tmdiff_amd.util import fill_weights_, synthetic_tile_batch
+torch.cuda.set_device(0)                           # (WORLD_SIZE=1: tdist.init_from_env would leave a single process alone)
+dist.init_process_group("nccl", device_id=torch.device("cuda", 0))
+dev = torch.device("cuda", 0)
+def run(reduce):
+    torch.manual_seed(3); torch.cuda.manual_seed(3)
+    import numpy as np; np.random.seed(3)
+    net = fill_weights_(WavBEST(channels=(4, 8, 16, 32))).to(dev).train()
+    diff = GeneralDiffusion(net, "l1").to(dev)
+    diff.set_loss(dev)
+    diff.set_new_noise_schedule({"schedule": "cosine", "n_timestep": 100}, dev)
+    opt = torch.optim.AdamW(net.parameters(), lr=1e-3)
+    red = tdist.GradReducer(diff, op="sum", bucket_bytes=64 << 10, min_world=1) if reduce else None
+    d = synthetic_tile_batch(11, 2, 8, 16, device=dev)
+    stats = []
+    for step in range(3):
+        loss = diff(d, "WV3").sum()
+        loss.backward()
+        n = red.finish() if red else 0
+        launched = red.launched if red else 0
+        opt.step()
+        if red: red.zero_grad()
+        else: opt.zero_grad(set_to_none=True)
+        stats.append((float(loss), n, launched))
+    return stats, [p.detach().clone() for p in net.parameters()]
+s0, w0 = run(False)
+s1, w1 = run(True)
+same = all(torch.equal(a, b) for a, b in zip(w0, w1))
+print(json.dumps({"plain": s0, "reduced": s1, "same_weights": same, "backend": dist.get_backend()}))
+dist.barrier(); dist.destroy_process_group()
+"""
+
+
+def test_grad_reducer_over_rccl_one_rank():
+    """The RCCL code path on the one GPU this box has: a one-rank `nccl` group (RCCL refuses two ranks on one device), the
+    finetune step of a narrow network through GradReducer(min_world=1) -- flat buckets, all_reduce(async_op=True) started
+    from the backward hooks on GPU tensors, handle.wait() before AdamW.  A one-rank SUM is the identity, so three steps
+    must leave exactly the weights of the same three steps without the reducer."""
+    import json
+    import socket
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
+    env.update(RANK="0", LOCAL_RANK="0", WORLD_SIZE="1", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port),
+               HSA_ENABLE_IPC_MODE_LEGACY="0")
+    p = subprocess.run([sys.executable, "-c", _RCCL_ONE_RANK, root], capture_output=True, text=True, env=env, timeout=600)
+    assert p.returncode == 0, p.stderr[-3000:]
+    out = json.loads([l for l in p.stdout.splitlines() if l.startswith("{")][-1])
+    assert out["backend"] == "nccl" and out["same_weights"]
+    assert [s[0] for s in out["plain"]] == [s[0] for s in out["reduced"]]
+    n1, launched1 = out["reduced"][1][1], out["reduced"][1][2]
+    assert n1 >= 3 and launched1 == n1                       # several 64 KB buckets, every one sent from a backward hook

@@ -99,11 +99,13 @@ class GradReducer:
     ``optimizer.zero_grad()`` (which would drop the views).
     """
 
-    def __init__(self, module, op="sum", bucket_bytes=32 << 20, group=None):
+    def __init__(self, module, op="sum", bucket_bytes=32 << 20, group=None, min_world=2):
+        """min_world: the smallest group the buckets / hooks are set up for (2: a single process does no exchange;
+        1 lets a one-rank group run the whole machinery, which is how the RCCL path is exercised on a one-GPU box)."""
         if op not in ("sum", "mean"):
             raise ValueError("op must be 'sum' (DataParallel semantics of the reference) or 'mean'")
         self.module, self.op, self.bucket_bytes, self.group = module, op, bucket_bytes, group
-        self.active = dist.is_initialized() and dist.get_world_size(group) > 1
+        self.active = dist.is_initialized() and dist.get_world_size(group) >= min_world
         self.world = dist.get_world_size(group) if self.active else 1
         self.buckets = None          # list of dicts {flat, params, pending}
         self._order, self._bucket_of, self._handles = [], {}, []
@@ -168,7 +170,8 @@ class GradReducer:
         if not self.active:
             return 0
         if self.buckets is None:     # first step: plain path, then lay the buckets out in the recorded order
-            n = allreduce_gradients(self.module, self.op, self.bucket_bytes, self.group)
+            n = _allreduce_tensors([p.grad for p in self.module.parameters() if p.grad is not None], self.op,
+                                   self.bucket_bytes, self.group)
             self._build()
             return n
         # buckets whose hooks did not all fire (a parameter got no gradient this step: its slot is still zero)
