@@ -31,6 +31,7 @@ from . import ops
 
 PROMPTS = ("QB", "WV3", "GF2", "WV2", "WV4")
 _EPILOGUE_FUSE = os.environ.get("TMDIFF_EPILOGUE_FUSE", "1") != "0"   # experiments: "0" = consumers apply their own prologue
+_CONV2_AFTER_LL = os.environ.get("TMDIFF_CONV2_AFTER_LL", "1") != "0"   # experiments: "0" = Conv_2 of a down block at full resolution, as the reference orders it
 _PRODUCER_FUSE = os.environ.get("TMDIFF_PRODUCER_FUSE", "1") != "0"   # experiments: "0" = only the conv20 -> conv21 exchange
 
 
@@ -174,7 +175,8 @@ class WaveletUPorDown(nn.Module):
     def run(self, x, shift, scale, skipH=None, want_high=True):
         from . import autograd as A
         hh = A.conv3d([x], self.Conv_0.weight, self.Conv_0.bias, act=True)
-        xx = A.conv3d([x], self.Conv_2.weight, self.Conv_2.bias)
+        # down: Conv_2 commutes with the halved LL band (see WavBEST._down), so it runs after it, on a quarter of the positions
+        xx = None if self.down and _CONV2_AFTER_LL else A.conv3d([x], self.Conv_2.weight, self.Conv_2.bias)
         hH = None
         if self.up:
             ch = self.convH_0[0]
@@ -182,7 +184,10 @@ class WaveletUPorDown(nn.Module):
             h_in, x_in = A.haar_idwt2d_pair(hh, xx, bands, in_scale=2.0)
         elif self.down:
             h_in, lh, hl, hhh = A.haar_dwt2d(hh, want_high=want_high, ll_scale=0.5)
-            x_in = A.haar_dwt2d(xx, want_high=False, ll_scale=0.5)[0]
+            if xx is None:
+                x_in = A.conv3d([A.haar_dwt2d(x, want_high=False, ll_scale=0.5)[0]], self.Conv_2.weight, self.Conv_2.bias)
+            else:
+                x_in = A.haar_dwt2d(xx, want_high=False, ll_scale=0.5)[0]
             hH = (lh, hl, hhh)
         else:
             raise NotImplementedError("WavBEST only instantiates up or down wavelet blocks")
@@ -431,8 +436,14 @@ class WavBEST(nn.Module):
         """WaveletUPorDown(down=True) (ref :369-414); /2 folded into the DWT, LL-only when the
         caller drops the high bands.  Returns (out, out2, bands)."""
         hh = self._conv0(P, name, x, pre)
-        xx = self._conv(P, name + ".Conv_2", [x])
-        xll = ops.haar_dwt2d(xx, want_high=False, ll_scale=0.5)[0]
+        # The reference runs the 1x1x1 Conv_2 at full resolution and keeps the halved LL band of its output (:390, :396).
+        # Both are linear and act on different axes (channels / the 2x2 pixel block), and the halved LL band of a
+        # constant is that constant, so LL(Conv_2(x)) / 2 == Conv_2(LL(x) / 2): the convolution runs on a quarter of
+        # the positions and the full-resolution intermediate is never written (same value up to fp32 summation order).
+        if _CONV2_AFTER_LL:
+            xll = self._conv(P, name + ".Conv_2", [ops.haar_dwt2d(x, want_high=False, ll_scale=0.5)[0]])
+        else:
+            xll = ops.haar_dwt2d(self._conv(P, name + ".Conv_2", [x]), want_high=False, ll_scale=0.5)[0]
         kw = {} if emit is None else {"emit": emit}
         if fuse:   # Conv_1's prologue (shift, SiLU, text modulation) is applied to the LL band where the DWT writes it
             pro = self._spec(P, S, shift=None if flag else name + ".Dense_0", scale=name + ".dense1")
