@@ -141,6 +141,25 @@ int tmdiff_conv3d_fwd_staged_supported(const tmdiff_conv3d_desc* d);
 size_t tmdiff_conv3d_fwd_staged_workspace_bytes(const tmdiff_conv3d_desc* d);
 int tmdiff_conv3d_fwd_staged(const tmdiff_conv3d_desc* d, void* workspace, tmdiff_stream_t stream);
 
+/* ---- 3x3x3 convolution followed by the scaled Haar LL band, as one strided convolution (exact fp32) -----------
+ * Replaces the pair  h = Conv_0(x') ; hLL = dwt(h).LL * ll_scale  of WaveletUPorDown(down=True) where the high bands are
+ * not used (reference GeneralModel/Hyper_unet_general.py:371-372, :389, :396; the main branch of WavBEST.forward).  The LL
+ * band is linear and local, so the pair equals a convolution with a 3x4x4 kernel and stride (1,2,2) whose weights are
+ * sums of the 3x3x3 ones: 48 instead of 4 x 27 multiply-adds per output, same numbers up to fp32 summation order.
+ *   d         : the descriptor of the 3x3x3 convolution (N, H, W = INPUT extents, H and W even; one plain fp32 input
+ *               without shift / scale / act / mask; groups 1; Cin % 2 == 0, Cout % 64 == 0; bias as for the convolution);
+ *               y / y2 / residual are [B, Cout, N, H/2, W/2] and follow the usual epilogue
+ *               out = (LL(conv(x) + bias) * ll_scale + residual) * out_scale,  y2 = act2(out + shift2) * scale2.
+ *   w_packed  : from tmdiff_conv3d_ll_pack_weights(w [Cout, Cin, 3, 3, 3], ..., ll_scale)
+ *               (tmdiff_conv3d_ll_packed_bytes bytes; 0 = shape not supported).
+ * Shapes it does not take return TMDIFF_E_UNSUPPORTED (tmdiff_conv3d_ll_supported says so beforehand): run the
+ * convolution and tmdiff_haar_dwt2d instead. */
+int tmdiff_conv3d_ll_supported(const tmdiff_conv3d_desc* d);
+size_t tmdiff_conv3d_ll_packed_bytes(int32_t Cout, int32_t Cin);
+int tmdiff_conv3d_ll_pack_weights(const float* w, float* packed, int32_t Cout, int32_t Cin, float ll_scale,
+                                  tmdiff_stream_t stream);
+int tmdiff_conv3d_ll_fwd(const tmdiff_conv3d_desc* d, float ll_scale, tmdiff_stream_t stream);
+
 /* ---- bf16 compute / fp32 accumulate (WorldView-3 inference) --------------------------
  * Same descriptor and fused prologue / epilogue as tmdiff_conv3d_fwd; activations, bias, residual and output stay
  * fp32 in memory.  The prologue result x' and the weights are rounded to bf16 (round to nearest even), products

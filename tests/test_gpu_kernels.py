@@ -555,6 +555,47 @@ def test_conv3d_bf16_packed_second_output(ops, cfg):
     assert torch.equal(only, packed)
 
 
+@pytest.mark.parametrize("case", [
+    # B, Cin, Cout, N, H, W           (output plane N x H/2 x W/2)
+    (2, 8, 64, 8, 32, 32),            # 256-position tiles, dwordx4 epilogue, whole tiles
+    (1, 6, 128, 3, 24, 12),           # odd chunk count, ragged tiles in n / h / w, W/2 = 6: scalar epilogue
+    (3, 4, 64, 8, 16, 16),            # small grid: 128-position tiles (two bands)
+    (1, 16, 64, 5, 20, 40),           # ragged n and h with the dwordx4 epilogue (W/2 = 20)
+])
+def test_conv3d_ll_is_conv_then_halved_ll_band(ops, case):
+    """tmdiff_conv3d_ll_fwd: `3x3x3 convolution, then the LL band * 1/2` as ONE strided convolution on composed weights,
+    against the oracle's Haar transform of the CPU convolution and against the two HIP kernels it replaces; with bias,
+    residual, out_scale and the second output (the consumer's prologue)."""
+    B, cin, cout, N, H, W = case
+    torch.manual_seed(11 + cin)
+    x, w, bias = torch.randn(B, cin, N, H, W), torch.randn(cout, cin, 3, 3, 3) / (cin * 27) ** 0.5, torch.randn(cout)
+    res = torch.randn(B, cout, N, H // 2, W // 2)
+    sh2, sc2 = torch.randn(B, cout) * 0.3, torch.rand(B, cout) + 0.5
+    full = F.conv3d(x.double(), w.double(), bias.double(), padding=1)
+    ll = 0.25 * (full[..., 0::2, 0::2] + full[..., 0::2, 1::2] + full[..., 1::2, 0::2] + full[..., 1::2, 1::2])
+    ref_ll = haar_dwt2d(full.float().reshape(B, cout * N, H, W))[0].reshape(B, cout, N, H // 2, W // 2) * 0.5
+    assert_close(ll.float(), ref_ll, 1e-5, 1e-6, "the test's LL formula vs the oracle transform")
+    wp = ops.pack_conv_weight_ll(cu(w), 0.5)
+    y = ops.conv3d_ll(cu(x), wp, cout, 0.5, bias=cu(bias))
+    assert_close(y, ll.float(), 2e-5, 2e-6, "conv3d_ll")
+    # the pair of kernels it replaces
+    pair = ops.haar_dwt2d(ops.conv3d([cu(x)], ops.pack_conv_weight(cu(w)), cout, 3, bias=cu(bias)), want_high=False, ll_scale=0.5)[0]
+    assert_close(y, pair.cpu(), 2e-5, 2e-6, "conv3d_ll vs conv3d + haar_dwt2d")
+    # epilogue: residual, scale, second output = SiLU(out + shift) * scale
+    want = (ll.float() + res) * 0.7071
+    v = want + sh2[:, :, None, None, None]
+    want2 = v * torch.sigmoid(v) * sc2[:, :, None, None, None]
+    y, y2 = ops.conv3d_ll(cu(x), wp, cout, 0.5, bias=cu(bias), residual=cu(res), out_scale=0.7071,
+                          emit=dict(act=True, shift=cu(sh2), scale=cu(sc2)))
+    assert_close(y, want, 2e-5, 2e-6, "conv3d_ll + residual")
+    assert_close(y2, want2, 2e-5, 2e-6, "conv3d_ll second output")
+    only = ops.conv3d_ll(cu(x), wp, cout, 0.5, bias=cu(bias), residual=cu(res), out_scale=0.7071, keep_y=False,
+                         emit=dict(act=True, shift=cu(sh2), scale=cu(sc2)))
+    assert torch.equal(only, y2)
+    with pytest.raises(ValueError):
+        ops.conv3d_ll(cu(x[..., :-1]), wp, cout, 0.5)      # odd width
+
+
 def test_conv3d_large_plane_config3_shape(ops):
     """One level-0 convolution at the config-3 plane size (8 x 256 x 256 = 524288 positions per channel): offsets, tiling
     and zero padding on a large plane, for the fused, staged and bf16 kernels, against the CPU convolution."""

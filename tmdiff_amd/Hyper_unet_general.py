@@ -32,6 +32,7 @@ from . import ops
 PROMPTS = ("QB", "WV3", "GF2", "WV2", "WV4")
 _EPILOGUE_FUSE = os.environ.get("TMDIFF_EPILOGUE_FUSE", "1") != "0"   # experiments: "0" = consumers apply their own prologue
 _CONV2_AFTER_LL = os.environ.get("TMDIFF_CONV2_AFTER_LL", "1") != "0"   # experiments: "0" = Conv_2 of a down block at full resolution, as the reference orders it
+_LL_COMPOSE = os.environ.get("TMDIFF_LL_COMPOSE", "1") != "0"   # experiments: "0" = Conv_0 at full resolution + LL-only DWT where the high bands are dropped
 _PRODUCER_FUSE = os.environ.get("TMDIFF_PRODUCER_FUSE", "1") != "0"   # experiments: "0" = only the conv20 -> conv21 exchange
 
 
@@ -335,7 +336,7 @@ class WavBEST(nn.Module):
         dev = params[0].device
         if dev.type != "cuda":
             raise RuntimeError("tmdiff_amd.WavBEST runs on the HIP kernels only: move the module to a GPU (.cuda())")
-        prep = {"key": key, "w": {}, "bf16": set(), "freqs": self._freqs_cpu.to(dev)}
+        prep = {"key": key, "w": {}, "w_ll": {}, "bf16": set(), "freqs": self._freqs_cpu.to(dev)}
         for name, m in self.named_modules():
             if isinstance(m, nn.Conv3d) and m.in_channels > 1 and m.out_channels > 1:
                 w = m.weight.detach().float().contiguous()
@@ -347,6 +348,13 @@ class WavBEST(nn.Module):
                     prep["bf16"].add(name)
                 else:
                     prep["w"][name] = ops.pack_conv_weight(w, groups=m.groups)
+        # Conv_0 of the main branch's down blocks is followed by an LL-only DWT (its high bands are dropped): the pair runs
+        # as one strided convolution on composed weights (csrc/conv3d_ll.hip), exact-fp32 mode only
+        if self.compute_dtype == "fp32" and _LL_COMPOSE:
+            for blk in ("down1", "down2", "down3"):
+                m = self.get_submodule(blk + ".down.Conv_0")
+                if ops.ll_conv_supported(m.out_channels, m.in_channels, m.kernel_size[0], m.groups):
+                    prep["w_ll"][blk + ".down.Conv_0"] = ops.pack_conv_weight_ll(m.weight.detach().float().contiguous(), 0.5)
         shift, scale = [], []
         for name, m in self.named_modules():
             if isinstance(m, ResBlockModulateBEST):
@@ -435,7 +443,8 @@ class WavBEST(nn.Module):
     def _down(self, P, S, name, x, flag, want_high, pre=None, emit=None, fuse=False):
         """WaveletUPorDown(down=True) (ref :369-414); /2 folded into the DWT, LL-only when the
         caller drops the high bands.  Returns (out, out2, bands)."""
-        hh = self._conv0(P, name, x, pre)
+        w_ll = None if want_high or pre is None or pre.dtype != torch.float32 else P["w_ll"].get(name + ".Conv_0")
+        hh = None if w_ll is not None else self._conv0(P, name, x, pre)
         # The reference runs the 1x1x1 Conv_2 at full resolution and keeps the halved LL band of its output (:390, :396).
         # Both are linear and act on different axes (channels / the 2x2 pixel block), and the halved LL band of a
         # constant is that constant, so LL(Conv_2(x)) / 2 == Conv_2(LL(x) / 2): the convolution runs on a quarter of
@@ -445,6 +454,21 @@ class WavBEST(nn.Module):
         else:
             xll = ops.haar_dwt2d(self._conv(P, name + ".Conv_2", [x]), want_high=False, ll_scale=0.5)[0]
         kw = {} if emit is None else {"emit": emit}
+        if w_ll is not None:
+            # Conv_0 and the halved LL band of its output as ONE strided convolution (only the LL band is used here); with
+            # `fuse` its epilogue applies Conv_1's prologue, as the DWT does below
+            c0 = self.get_submodule(name + ".Conv_0")
+            if fuse:
+                pro = self._spec(P, S, shift=None if flag else name + ".Dense_0", scale=name + ".dense1")
+                hll = ops.conv3d_ll(pre, w_ll, c0.out_channels, 0.5, bias=c0.bias.detach(), emit=pro, keep_y=False)
+                out = self._conv(P, name + ".Conv_1", [hll], use_bias=False, residual=xll, **kw)
+            else:
+                hll = ops.conv3d_ll(pre, w_ll, c0.out_channels, 0.5, bias=c0.bias.detach())
+                sh = {} if flag else self._shift(P, S, name + ".Dense_0")
+                out = self._conv(P, name + ".Conv_1", [hll], use_bias=False, in_act=True, residual=xll,
+                                 **self._scale(P, S, name + ".dense1"), **sh, **kw)
+            out, out2 = out if emit is not None else (out, None)
+            return out, out2, (None, None, None)
         if fuse:   # Conv_1's prologue (shift, SiLU, text modulation) is applied to the LL band where the DWT writes it
             pro = self._spec(P, S, shift=None if flag else name + ".Dense_0", scale=name + ".dense1")
             p16 = name + ".Conv_1" in P["bf16"]          # bf16 mode: ... as the packed bf16 units the convolution reads

@@ -125,12 +125,13 @@ def pack_conv_weight_bf16(w, groups=1):
 def make_conv_desc(segs, w_packed, cout, ksize, y, groups=1, bias=None, bias_scale=1.0, in_shift=None, in_scale=None,
                    shift_stride=0, scale_stride=0, in_act=False, in_mask=None, residual=None, out_scale=1.0,
                    y2=None, y2_shift=None, y2_scale=None, y2_shift_stride=0, y2_scale_stride=0, y2_act=False,
-                   x_bf16_shape=None, drop=None):
+                   x_bf16_shape=None, drop=None, out_div=1):
     """Fill a tmdiff_conv3d_desc.  `segs` = list of 1..3 tensors [B, c_i, N, H, W] (concat-free input).
     in_shift / in_scale may be tensors or raw (ptr) ints into a projection bank.  y may be None when only the second
     output y2 = act2(y + y2_shift) * y2_scale (the consumer's prologue, same pointer conventions) is wanted.
     A y2 of dtype int16 is written as bf16 units [B, Cout/8, N*H*W, 8]; x_bf16_shape = (N, H, W) says that segs[0] is
-    such a tensor (bf16 entry point only).  drop = (seed, p): in-kernel dropout of the prologue output (no mask tensor)."""
+    such a tensor (bf16 entry point only).  drop = (seed, p): in-kernel dropout of the prologue output (no mask tensor).
+    out_div = 2: outputs / residual at half the H and W of the input (tmdiff_conv3d_ll_fwd)."""
     d = Conv3dDesc()
     if drop is not None:
         if in_mask is not None:
@@ -167,7 +168,7 @@ def make_conv_desc(segs, w_packed, cout, ksize, y, groups=1, bias=None, bias_sca
     d.in_shift_stride, d.in_scale_stride = shift_stride, scale_stride
     d.in_mask = _chk(in_mask, "in_mask")
     d.in_act = 1 if in_act else 0
-    oshape = (b, cout, n, h, w)
+    oshape = (b, cout, n, h // out_div, w // out_div)
     if residual is not None and tuple(residual.shape) != oshape:
         raise ValueError("conv3d: residual shape != output shape")
     d.residual = _chk(residual, "residual")
@@ -304,6 +305,54 @@ def conv3d(segs, w_packed, cout, ksize, out=None, math="fp32", pack_input=None, 
     check(fwd(C.byref(d), stream_ptr()), what)
     e1.record()
     TIMER.records.append((e0, e1, 2.0 * b * cout * (d.Cin // d.groups) * ksize ** 3 * n * h * w, ksize, what))
+    return ret
+
+
+def ll_conv_supported(cout, cin, ksize=3, groups=1):
+    """Shapes tmdiff_conv3d_ll_fwd takes (conv3d_ll_halved below)."""
+    return ksize == 3 and groups == 1 and cin % 2 == 0 and cout % 64 == 0
+
+
+def pack_conv_weight_ll(w, ll_scale=0.5):
+    """[Cout, Cin, 3, 3, 3] -> the composed, packed weights of `3x3x3 convolution, then LL band * ll_scale` (conv3d_ll)."""
+    cout, cin = w.shape[0], w.shape[1]
+    nb = lib.tmdiff_conv3d_ll_packed_bytes(cout, cin)
+    if tuple(w.shape[2:]) != (3, 3, 3) or nb == 0:
+        raise ValueError(f"pack_conv_weight_ll: weight shape {tuple(w.shape)} not supported")
+    out = torch.empty(nb // 4, device=w.device, dtype=torch.float32)
+    check(lib.tmdiff_conv3d_ll_pack_weights(_chk(w.detach(), "w"), out.data_ptr(), cout, cin, float(ll_scale), stream_ptr()),
+          "conv3d_ll_pack_weights")
+    return out
+
+
+def conv3d_ll(x, w_packed, cout, ll_scale=0.5, emit=None, keep_y=True, **kw):
+    """haar_dwt2d(conv3d(x, w), want_high=False, ll_scale)[0] as ONE strided convolution (csrc/conv3d_ll.hip): x is one
+    plain fp32 tensor [B, Cin, N, H, W] (H, W even), the result [B, Cout, N, H/2, W/2].  bias / residual / out_scale / emit
+    as in conv3d (residual and the outputs at the halved size); returns y, (y, y2) or y2 alone (keep_y=False)."""
+    b, _, n, h, w = x.shape
+    dev = x.device
+    oshape = (b, cout, n, h // 2, w // 2)
+    y = torch.empty(oshape, device=dev, dtype=torch.float32) if keep_y else None
+    y2 = None
+    if emit is not None:
+        y2 = torch.empty(oshape, device=dev, dtype=torch.float32)
+        kw = dict(kw, y2_act=emit.get("act", False), y2_shift=emit.get("shift"), y2_scale=emit.get("scale"),
+                  y2_shift_stride=emit.get("shift_stride", 0), y2_scale_stride=emit.get("scale_stride", 0))
+    elif y is None:
+        raise ValueError("conv3d_ll: keep_y=False needs emit=")
+    d = make_conv_desc([x], w_packed, cout, 3, y, y2=y2, out_div=2, **kw)
+    if not lib.tmdiff_conv3d_ll_supported(C.byref(d)):
+        raise ValueError("conv3d_ll: shape not supported (ll_conv_supported)")
+    ret = y if y2 is None else ((y, y2) if y is not None else y2)
+    if TIMER is None:
+        check(lib.tmdiff_conv3d_ll_fwd(C.byref(d), float(ll_scale), stream_ptr()), "conv3d_ll_fwd")
+        return ret
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    check(lib.tmdiff_conv3d_ll_fwd(C.byref(d), float(ll_scale), stream_ptr()), "conv3d_ll_fwd")
+    e1.record()
+    # EXECUTED flops: 48 multiply-adds per (ci, co, output position) -- the pair it replaces would execute 4 x 27
+    TIMER.records.append((e0, e1, 2.0 * b * cout * d.Cin * 48 * n * (h // 2) * (w // 2), 3, "conv3d_ll_fwd"))
     return ret
 
 

@@ -1,11 +1,12 @@
 #!/usr/bin/env python3
 """bench_traffic.py DIR TAG: aggregate the FETCH_SIZE / WRITE_SIZE passes of tools/bench_traffic.sh over the 3x3x3 conv
-launches of bench.py (conv3d_mfma_kernel<3,..>, conv3d_dma_kernel<3,..> and the prologue_apply pass of the staged form).
+launches of bench.py (conv3d_mfma_kernel<3,..>, conv3d_dma_kernel<3,..>, conv3d_ll_kernel and the prologue_apply pass of the
+staged form).
 FETCH_SIZE is doubled (gfx950 tallies 128-B read requests at 64 B, MI355X_MICROARCH.md "HBM"); both counters are KiB."""
 import collections, csv, glob, json, re, sys
 
 out, tag = sys.argv[1], sys.argv[2]
-K3 = re.compile(r"conv3d_(mfma|dma)_kernel<3,")
+K3 = re.compile(r"conv3d_(mfma|dma)_kernel<3,|conv3d_ll_kernel<")
 PRO = re.compile(r"prologue_apply_kernel")
 
 
@@ -38,7 +39,7 @@ res = {"bytes_per_k3_launch": round(fetch + write), "fetch_bytes_per_launch": ro
        "launches_sampled": n, "prologue_pass_launches": len(fp),
        "algorithmic_bytes_per_launch": round(9.6e9 / 51),
        "collection": "rocprofv3 --kernel-trace --pmc FETCH_SIZE | WRITE_SIZE (separate passes) -- python3 bench.py --steps 3 "
-                     "--warmup 1 --no-extras; all conv3d_{mfma,dma}_kernel<3,..> dispatches + prologue_apply_kernel passes, "
+                     "--warmup 1 --no-extras; all conv3d_{mfma,dma}_kernel<3,..> / conv3d_ll_kernel dispatches + prologue_apply_kernel passes, "
                      "FETCH_SIZE x2 (gfx950), KiB -> bytes"}
 res["ratio_to_algorithmic"] = round(res["bytes_per_k3_launch"] / res["algorithmic_bytes_per_launch"], 3)
 json.dump(res, open(f"profiles/{tag}_bench_traffic.json", "w"), indent=1)
