@@ -187,6 +187,12 @@ int tmdiff_conv3d_fwd_bf16(const tmdiff_conv3d_desc* d, void* workspace, tmdiff_
  *   dL/dx, dL/dshift, dL/dscale = tmdiff_conv3d_prologue_bwd(dL/dx', x, ...)
  * ATen computes these inside autograd for F.conv3d / nn.Conv3d (Hyper_unet_general.py:74, :244, :372...). */
 
+/* x'[B, Cin, N, H, W] = act(cat(segments) + shift) * scale * mask (or in-kernel dropout): the prologue of the convolution
+ * described by d, on its own (the pass tmdiff_conv3d_fwd_staged and tmdiff_conv3d_wgrad run internally).  The finetune path
+ * uses it where the convolution itself is tmdiff_conv3d_ll_fwd, which takes a plain input; x' is then kept for the weight
+ * gradient. */
+int tmdiff_conv3d_prologue_fwd(const tmdiff_conv3d_desc* d, float* xp, tmdiff_stream_t stream);
+
 /* dw [Cout, Cin/groups, k,k,k] (PyTorch layout) = sum_{b,pos} g[b,co,pos] * x'[b,ci,pos+tap]; x' is formed from
  * the segments / shift / scale / mask / act of `d` exactly as in the forward (d->y, residual, bias, w_packed are
  * ignored).  `g` is [B, Cout, N, H, W].  workspace: tmdiff_conv3d_wgrad_workspace_bytes(d) bytes (partial sums). */

@@ -366,3 +366,28 @@ def test_wgrad_with_bias_gradient_on_the_side(shape):
     want = 2.0 * g.double().sum(dim=(0, 2, 3, 4))
     assert_close(db.cpu(), want.float().cpu(), 1e-5, 1e-5, "dbias inside wgrad")
     assert_close(ops.channel_sum(g, 2.0).cpu(), want.float().cpu(), 1e-5, 1e-5, "channel_sum")
+
+
+@pytest.mark.parametrize("shape", [(2, 8, 64, 4, 16, 16), (1, 6, 128, 3, 12, 20)])
+def test_composed_conv_ll_gradients_vs_cpu_autograd(shape):
+    """autograd.conv3d_ll = LL(conv3d(SiLU(x), w) + b) / 2 with the forward as ONE strided convolution on composed weights
+    (down blocks whose high bands are dropped): output and the gradients w.r.t. x, w, b against CPU autograd of the
+    reference's operator order (convolution at full resolution, then the Haar LL band, halved)."""
+    import torch.nn.functional as F
+    from tmdiff_amd import autograd as A
+    B, cin, cout, N, H, W = shape
+    torch.manual_seed(23)
+    x = torch.randn(B, cin, N, H, W, requires_grad=True)
+    w = (torch.randn(cout, cin, 3, 3, 3) / (cin * 27) ** 0.5).requires_grad_()
+    b = torch.randn(cout, requires_grad=True)
+    r = torch.randn(B, cout, N, H // 2, W // 2)
+    full = F.conv3d(F.silu(x), w, b, padding=1)
+    want = 0.25 * (full[..., 0::2, 0::2] + full[..., 0::2, 1::2] + full[..., 1::2, 0::2] + full[..., 1::2, 1::2])
+    (want * r).sum().backward()
+    xg, wg, bg = (t.detach().cuda().requires_grad_() for t in (x, w, b))
+    got = A.conv3d_ll(xg, wg, bg, 0.5)
+    (got * r.cuda()).sum().backward()
+    assert_close(got.detach(), want.detach(), 2e-5, 2e-6, "conv3d_ll forward")
+    assert_close(xg.grad, x.grad, 3e-5, 3e-6, "d/dx")
+    assert_close(wg.grad, w.grad, 3e-5, 3e-6, "d/dw")
+    assert_close(bg.grad, b.grad, 3e-5, 3e-6, "d/db")

@@ -175,7 +175,11 @@ class WaveletUPorDown(nn.Module):
 
     def run(self, x, shift, scale, skipH=None, want_high=True):
         from . import autograd as A
-        hh = A.conv3d([x], self.Conv_0.weight, self.Conv_0.bias, act=True)
+        # down, high bands dropped: Conv_0 + halved LL band as one strided convolution (autograd._ConvLL)
+        ll = (self.down and not want_high and _LL_COMPOSE and
+              ops.ll_conv_supported(self.Conv_0.out_channels, self.Conv_0.in_channels, 3, 1) and
+              x.shape[3] % 2 == 0 and x.shape[4] % 2 == 0)
+        hh = None if ll else A.conv3d([x], self.Conv_0.weight, self.Conv_0.bias, act=True)
         # down: Conv_2 commutes with the halved LL band (see WavBEST._down), so it runs after it, on a quarter of the positions
         xx = None if self.down and _CONV2_AFTER_LL else A.conv3d([x], self.Conv_2.weight, self.Conv_2.bias)
         hH = None
@@ -184,7 +188,10 @@ class WaveletUPorDown(nn.Module):
             bands = A.conv3d(list(skipH), ch.weight, ch.bias, bias_scale=2.0, groups=3)      # convH_0(cat/2)*2
             h_in, x_in = A.haar_idwt2d_pair(hh, xx, bands, in_scale=2.0)
         elif self.down:
-            h_in, lh, hl, hhh = A.haar_dwt2d(hh, want_high=want_high, ll_scale=0.5)
+            if ll:
+                h_in, lh, hl, hhh = A.conv3d_ll(x, self.Conv_0.weight, self.Conv_0.bias, 0.5), None, None, None
+            else:
+                h_in, lh, hl, hhh = A.haar_dwt2d(hh, want_high=want_high, ll_scale=0.5)
             if xx is None:
                 x_in = A.conv3d([A.haar_dwt2d(x, want_high=False, ll_scale=0.5)[0]], self.Conv_2.weight, self.Conv_2.bias)
             else:

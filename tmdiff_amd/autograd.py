@@ -120,6 +120,52 @@ def conv3d(segs, weight, bias=None, bias_scale=1.0, shift=None, scale=None, act=
                               fix(scale), residual, mask, *segs)
 
 
+class _ConvLL(torch.autograd.Function):
+    """o = LL(conv3d(act(x), w) + bias) * ll_scale -- Conv_0 of a down block whose high bands are dropped, followed by the
+    halved LL band (WaveletUPorDown, reference Hyper_unet_general.py:371-372, :389, :396).  Forward: the prologue pass (its
+    output x' is kept for the weight gradient) and ONE strided convolution on composed weights (ops.conv3d_ll: 48 instead
+    of 4 x 27 multiply-adds per output).  Backward: the adjoint of the LL band spreads the gradient back to full
+    resolution, then the data / weight / bias / prologue gradients of the 3x3x3 convolution as in _FusedConv3d."""
+
+    @staticmethod
+    def forward(ctx, ll_scale, weight, bias, x):
+        w, x = weight.contiguous(), x.contiguous()
+        cout = w.shape[0]
+        d = ops.Conv3dDesc()
+        b, cin, n, h, wd = x.shape
+        d.B, d.N, d.H, d.W, d.Cin, d.Cout, d.groups, d.ksize, d.nseg = b, n, h, wd, cin, cout, 1, 3, 1
+        d.seg_c[0], d.seg_x[0], d.in_act = cin, x.data_ptr(), 1
+        xp = ops.conv3d_prologue(d, tuple(x.shape))
+        y = ops.conv3d_ll(xp, ops.pack_conv_weight_ll(w, ll_scale), cout, ll_scale, bias=bias)
+        ctx.ll_scale = ll_scale
+        ctx.has_bias = bias is not None
+        ctx.save_for_backward(w, x, xp)
+        return y
+
+    @staticmethod
+    def backward(ctx, go):
+        w, x, xp = ctx.saved_tensors
+        need = ctx.needs_input_grad          # (ll_scale, weight, bias, x)
+        go = go.contiguous()
+        cout, cin = w.shape[0], w.shape[1]
+        g = ops.haar_idwt2d([go], None, None, None, in_scale=ctx.ll_scale)[0]      # adjoint of the scaled LL band
+        d_w = ops.conv3d_wgrad(ops.make_conv_desc([xp], 0, cout, 3, g), g, tuple(w.shape)) if need[1] else None
+        d_b = ops.channel_sum(go, 2.0 * ctx.ll_scale) if (ctx.has_bias and need[2]) else None
+        d_x = None
+        if need[3]:
+            pre = ops.PACKED.lookup(w) if ops.PACKED is not None else None
+            wp_t = pre[1] if pre is not None else ops.pack_conv_weight(w, mode=1)
+            gp = ops.conv3d([g], wp_t, cin, 3)                                     # dL/dx'
+            d_x = torch.empty_like(x)
+            ops.conv3d_prologue_bwd(ops.make_conv_desc([x], 0, cout, 3, g, in_act=True), gp, [d_x], [False], False, False)
+        return None, d_w, d_b, d_x
+
+
+def conv3d_ll(x, weight, bias=None, ll_scale=0.5):
+    """Differentiable LL(conv3d(SiLU(x), w) + bias) * ll_scale (see _ConvLL); shapes per ops.ll_conv_supported."""
+    return _ConvLL.apply(float(ll_scale), weight, bias, x)
+
+
 class _HaarDWT(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, want_high, ll_scale):

@@ -734,6 +734,21 @@ int tmdiff::launch_prologue_apply(const tmdiff_conv3d_desc* d, float* xp, hipStr
   return check_launch("prologue_apply");
 }
 
+extern "C" int tmdiff_conv3d_prologue_fwd(const tmdiff_conv3d_desc* d, float* xp, tmdiff_stream_t stream) {
+  using namespace tmdiff;
+  TMDIFF_REQUIRE(d && xp, "conv3d_prologue_fwd: NULL pointer");
+  TMDIFF_REQUIRE(d->B >= 0 && d->N > 0 && d->H > 0 && d->W > 0 && d->Cin > 0, "conv3d_prologue_fwd: bad extents");
+  TMDIFF_REQUIRE(d->nseg >= 1 && d->nseg <= 3, "conv3d_prologue_fwd: nseg=%d", d->nseg);
+  int csum = 0;
+  for (int i = 0; i < d->nseg; ++i) {
+    TMDIFF_REQUIRE(d->seg_x[i] && d->seg_c[i] > 0, "conv3d_prologue_fwd: segment %d is empty", i);
+    csum += d->seg_c[i];
+  }
+  TMDIFF_REQUIRE(csum == d->Cin, "conv3d_prologue_fwd: segments hold %d channels, Cin=%d", csum, d->Cin);
+  if (d->B == 0) return TMDIFF_OK;
+  return launch_prologue_apply(d, xp, as_stream(stream));
+}
+
 extern "C" size_t tmdiff_conv3d_wgrad_workspace_bytes(const tmdiff_conv3d_desc* d) {
   if (!d || d->B <= 0 || d->groups <= 0 || (d->ksize != 1 && d->ksize != 3)) return 0;
   const WgradPlan p = plan_wgrad(d);

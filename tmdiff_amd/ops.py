@@ -308,6 +308,13 @@ def conv3d(segs, w_packed, cout, ksize, out=None, math="fp32", pack_input=None, 
     return ret
 
 
+def conv3d_prologue(desc, shape):
+    """x' = the prologue output of the convolution `desc` describes (shape [B, Cin, N, H, W]), as a tensor of its own."""
+    xp = torch.empty(shape, device=torch.device("cuda", torch.cuda.current_device()), dtype=torch.float32)
+    check(lib.tmdiff_conv3d_prologue_fwd(C.byref(desc), xp.data_ptr(), stream_ptr()), "conv3d_prologue_fwd")
+    return xp
+
+
 def ll_conv_supported(cout, cin, ksize=3, groups=1):
     """Shapes tmdiff_conv3d_ll_fwd takes (conv3d_ll_halved below)."""
     return ksize == 3 and groups == 1 and cin % 2 == 0 and cout % 64 == 0
