@@ -153,8 +153,11 @@ int tmdiff_conv3d_fwd_staged(const tmdiff_conv3d_desc* d, void* workspace, tmdif
  *   w_packed  : from tmdiff_conv3d_ll_pack_weights(w [Cout, Cin, 3, 3, 3], ..., ll_scale)
  *               (tmdiff_conv3d_ll_packed_bytes bytes; 0 = shape not supported).
  * Shapes it does not take return TMDIFF_E_UNSUPPORTED (tmdiff_conv3d_ll_supported says so beforehand): run the
- * convolution and tmdiff_haar_dwt2d instead. */
+ * convolution and tmdiff_haar_dwt2d instead.
+ * Small grids are split over the input channels like tmdiff_conv3d_fwd when d->splitk_ws lends
+ * tmdiff_conv3d_ll_splitk_workspace_bytes(d) bytes (0: the grid fills the chip). */
 int tmdiff_conv3d_ll_supported(const tmdiff_conv3d_desc* d);
+size_t tmdiff_conv3d_ll_splitk_workspace_bytes(const tmdiff_conv3d_desc* d);
 size_t tmdiff_conv3d_ll_packed_bytes(int32_t Cout, int32_t Cin);
 int tmdiff_conv3d_ll_pack_weights(const float* w, float* packed, int32_t Cout, int32_t Cin, float ll_scale,
                                   tmdiff_stream_t stream);

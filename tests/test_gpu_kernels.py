@@ -561,6 +561,7 @@ def test_conv3d_bf16_packed_second_output(ops, cfg):
     (1, 6, 128, 3, 24, 12),           # odd chunk count, ragged tiles in n / h / w, W/2 = 6: scalar epilogue
     (3, 4, 64, 8, 16, 16),            # small grid: 128-position tiles (two bands)
     (1, 16, 64, 5, 20, 40),           # ragged n and h with the dwordx4 epilogue (W/2 = 20)
+    (1, 64, 64, 8, 16, 16),           # 4 workgroups: split over the input channels (16 ranges) + reduction kernel
 ])
 def test_conv3d_ll_is_conv_then_halved_ll_band(ops, case):
     """tmdiff_conv3d_ll_fwd: `3x3x3 convolution, then the LL band * 1/2` as ONE strided convolution on composed weights,

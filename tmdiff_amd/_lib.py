@@ -47,6 +47,7 @@ SIGNATURES = {
     "tmdiff_conv3d_fwd_staged": (C.c_int, [C.POINTER(Conv3dDesc), vp, vp]),
     "tmdiff_conv3d_prologue_fwd": (C.c_int, [C.POINTER(Conv3dDesc), vp, vp]),
     "tmdiff_conv3d_ll_supported": (C.c_int, [C.POINTER(Conv3dDesc)]),
+    "tmdiff_conv3d_ll_splitk_workspace_bytes": (C.c_size_t, [C.POINTER(Conv3dDesc)]),
     "tmdiff_conv3d_ll_packed_bytes": (C.c_size_t, [C.c_int32, C.c_int32]),
     "tmdiff_conv3d_ll_pack_weights": (C.c_int, [vp, vp, C.c_int32, C.c_int32, C.c_float, vp]),
     "tmdiff_conv3d_ll_fwd": (C.c_int, [C.POINTER(Conv3dDesc), C.c_float, vp]),

@@ -54,6 +54,8 @@ struct LlArgs {
   int tiles_n, tiles_h, tiles_w, tiles_co;
   unsigned total_blocks;
   int vec4;
+  int ksplit, split_chunks;  // split-K over the input channels: ksplit ranges of split_chunks chunks (1, Cin / KC = no split)
+  float* part;               // partial outputs [ksplit][B][Cout][plane] (NULL = no split), summed by splitk_reduce_kernel
 };
 
 __device__ const float4 kZero4 = {0.f, 0.f, 0.f, 0.f};  // source of zero padding / filler lanes
@@ -109,13 +111,14 @@ __global__ void __launch_bounds__(256, 2) conv3d_ll_kernel(const LlArgs a) {
   const int tw_i = __builtin_amdgcn_readfirstlane(id % a.tiles_w); id /= a.tiles_w;
   const int th_i = __builtin_amdgcn_readfirstlane(id % a.tiles_h); id /= a.tiles_h;
   const int tn_i = __builtin_amdgcn_readfirstlane(id % a.tiles_n); id /= a.tiles_n;
-  const int b = __builtin_amdgcn_readfirstlane(id);
+  const int b = __builtin_amdgcn_readfirstlane(id % a.B);
+  const int split = __builtin_amdgcn_readfirstlane(id / a.B);   // split-K range of this workgroup (outermost index)
   constexpr int g = 0;
   const int n0 = tn_i * TN, h0 = th_i * TH, w0 = tw_i * TW;   // output coordinates
   const int co0 = co_tile * CO;
   const long plane = (long)a.N * a.H * a.W;                    // output plane
   const int plane_in = a.N * a.Hi * a.Wi;
-  const int nchunks = a.Cin / KC;
+  const int nchunks = a.split_chunks;                            // chunks of this workgroup: [split * nchunks, +nchunks)
 
   // ---- DMA sources of this lane (the same for every chunk) -----------------------------------------------------
   int xsrc[XK];  // float offset from the chunk base, or -1 = zero word
@@ -135,8 +138,9 @@ __global__ void __launch_bounds__(256, 2) conv3d_ll_kernel(const LlArgs a) {
     const int u = (wv + 4 * k) * 64 + lane;
     wsrc[k] = u < G::W_UNITS ? (u / (CO / 4)) * a.cout_g + (u % (CO / 4)) * 4 : -1;
   }
-  const float* xg = a.xq + (long)b * a.Cin * plane_in;
-  const float* wg = a.wp + co0;
+  const long c_first = (long)split * nchunks * KC;               // first input channel of the range
+  const float* xg = a.xq + ((long)b * a.Cin + c_first) * plane_in;
+  const float* wg = a.wp + c_first * LL_TAPS * a.cout_g + co0;
   const float* zero = reinterpret_cast<const float*>(&kZero4);
 
   constexpr int NPIECE = XK + WK;
@@ -237,6 +241,22 @@ __global__ void __launch_bounds__(256, 2) conv3d_ll_kernel(const LlArgs a) {
     }
   }
 
+  if (a.part) {   // split-K: raw partial sums; splitk_reduce_kernel (conv3d.hip) adds them up and applies the epilogue
+#pragma unroll
+    for (int m = 0; m < MSUB; ++m)
+#pragma unroll
+      for (int s = 0; s < NS; ++s) {
+        const int p = (wv * NS + s) * 32 + l31;
+        const int n = n0 + p / (TW * TH), h = h0 + (p / TW) % TH, w = w0 + p % TW;
+        const bool pok = n < a.N && h < a.H && w < a.W;
+        const long sp = pok ? ((long)n * a.H + h) * a.W + w : 0;
+        float* dst = a.part + (((long)split * a.B + b) * a.Cout + co0 + m * 32 + 4 * khalf) * plane + sp;
+#pragma unroll
+        for (int r = 0; r < 16; ++r)
+          if (pok) dst[((r & 3) + 8 * (r >> 2)) * plane] = acc[s][m][r];
+      }
+    return;
+  }
   if (a.vec4) {   // (the chunk loop ends with a barrier: nobody reads the stages any more)
     static_assert(sizeof(st0) >= 4 * 4096, "the epilogue borrows 4 KB of LDS per wave");
     tmdiff::epilogue_vec<NS, MSUB, TN, TH, TW>(a, acc, bias_v, sh2_v, sc2_v, b, g, co0, n0, h0, w0, wv, lane, plane,
@@ -279,7 +299,7 @@ int launch(LlArgs& a, hipStream_t st) {
   a.tiles_h = (a.H + TH - 1) / TH;
   a.tiles_w = (a.W + TW - 1) / TW;
   a.tiles_co = a.Cout / CO;
-  const long blocks = (long)a.B * a.tiles_n * a.tiles_h * a.tiles_w * a.tiles_co;
+  const long blocks = (long)a.ksplit * a.B * a.tiles_n * a.tiles_h * a.tiles_w * a.tiles_co;
   if (blocks <= 0 || blocks > 0x7fffffffL) return tmdiff::fail(TMDIFF_E_INVALID, "conv3d_ll_fwd: grid of %ld blocks", blocks);
   a.total_blocks = (unsigned)blocks;
   conv3d_ll_kernel<NS, MSUB, KC, TN, TH, TW><<<(unsigned)blocks, 256, 0, st>>>(a);
@@ -316,9 +336,38 @@ bool ll_ok(const tmdiff_conv3d_desc* d) {
   return d->Cin > 0 && d->Cin % 2 == 0 && d->Cout > 0 && d->Cout % 64 == 0 && d->H > 0 && d->W > 0 && d->H % 2 == 0 && d->W % 2 == 0;
 }
 
+// tile choice and split-K factor (as plan_conv3 for the stride-1 kernels): 256-position tiles, 128-position ones (two
+// bands) when those would not give every CU two workgroups; below the split target the input channels are divided
+struct LlPlan { bool small; long blocks; int ksplit; };
+LlPlan plan_ll(const tmdiff_conv3d_desc* d) {
+  const int N = d->N, H = d->H / 2, W = d->W / 2;
+  LlPlan p{false, 0, 1};
+  const long wg256 = (long)d->B * ((N + 3) / 4) * ((H + 7) / 8) * ((W + 7) / 8) * (d->Cout / 64);
+  p.small = wg256 < 2 * 256 && N > 2;
+  p.blocks = p.small ? (long)d->B * ((N + 1) / 2) * ((H + 7) / 8) * ((W + 7) / 8) * (d->Cout / 64) : wg256;
+  static const long target = [] {
+    const char* e = getenv("TMDIFF_SPLITK");
+    return e ? atol(e) : 384L;
+  }();
+  if (target <= 0 || p.blocks >= target) return p;
+  const int nchunks = d->Cin / 2;
+  for (int s = 2; s <= nchunks / 2; ++s) {            // at least two chunks per range
+    if (nchunks % s) continue;
+    p.ksplit = s;
+    if (p.blocks * s >= target) break;
+  }
+  return p;
+}
+
 }  // namespace
 
 extern "C" int tmdiff_conv3d_ll_supported(const tmdiff_conv3d_desc* d) { return ll_ok(d) ? 1 : 0; }
+
+extern "C" size_t tmdiff_conv3d_ll_splitk_workspace_bytes(const tmdiff_conv3d_desc* d) {
+  if (!ll_ok(d) || d->B <= 0) return 0;
+  const LlPlan p = plan_ll(d);
+  return p.ksplit > 1 ? (size_t)p.ksplit * d->B * d->Cout * d->N * (d->H / 2) * (d->W / 2) * sizeof(float) : 0;
+}
 
 extern "C" size_t tmdiff_conv3d_ll_packed_bytes(int32_t Cout, int32_t Cin) {
   if (Cout <= 0 || Cin <= 0 || Cout % 64) return 0;
@@ -362,8 +411,15 @@ extern "C" int tmdiff_conv3d_ll_fwd(const tmdiff_conv3d_desc* d, float ll_scale,
   }();
   a.vec4 = vec_on && a.W % 4 == 0 && aligned16(d->y) && aligned16(d->y2) && aligned16(d->residual);
   hipStream_t st = as_stream(stream);
-  // 256-position tiles; 128-position tiles (two bands) when those would not give every CU two workgroups
-  const long wg256 = (long)d->B * ((a.N + 3) / 4) * ((a.H + 7) / 8) * ((a.W + 7) / 8) * (a.Cout / 64);
-  if (wg256 < 2 * 256 && a.N > 2) return launch<1, 2, 2, 2, 8, 8>(a, st);
-  return launch<2, 2, 2, 4, 8, 8>(a, st);
+  const LlPlan plan = plan_ll(d);
+  a.ksplit = 1; a.split_chunks = a.Cin / 2; a.part = nullptr;
+  const size_t need = (size_t)plan.ksplit * d->B * d->Cout * a.N * a.H * a.W * sizeof(float);
+  if (plan.ksplit > 1 && d->splitk_ws && (size_t)d->splitk_ws_bytes >= need && aligned16(d->splitk_ws)) {
+    a.ksplit = plan.ksplit; a.split_chunks = a.Cin / 2 / plan.ksplit; a.part = static_cast<float*>(d->splitk_ws);
+  }
+  const int rc = plan.small ? launch<1, 2, 2, 2, 8, 8>(a, st) : launch<2, 2, 2, 4, 8, 8>(a, st);
+  if (rc || !a.part) return rc;
+  SplitKReduceArgs r{a.part, a.ksplit, d->B, d->Cout, (long)a.N * a.H * a.W, d->bias, a.bias_scale, d->residual,
+                     d->out_scale, d->y, d->y2, d->y2_shift, d->y2_scale, a.y2_shift_stride, a.y2_scale_stride, d->y2_act};
+  return launch_splitk_reduce(r, st);
 }

@@ -350,6 +350,9 @@ def conv3d_ll(x, w_packed, cout, ll_scale=0.5, emit=None, keep_y=True, **kw):
     d = make_conv_desc([x], w_packed, cout, 3, y, y2=y2, out_div=2, **kw)
     if not lib.tmdiff_conv3d_ll_supported(C.byref(d)):
         raise ValueError("conv3d_ll: shape not supported (ll_conv_supported)")
+    nsk = lib.tmdiff_conv3d_ll_splitk_workspace_bytes(C.byref(d))      # small grids: lend the split-K workspace
+    if nsk:
+        d.splitk_ws, d.splitk_ws_bytes = _workspace(dev, nsk, "splitk").data_ptr(), nsk
     ret = y if y2 is None else ((y, y2) if y is not None else y2)
     if TIMER is None:
         check(lib.tmdiff_conv3d_ll_fwd(C.byref(d), float(ll_scale), stream_ptr()), "conv3d_ll_fwd")

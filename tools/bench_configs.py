@@ -55,7 +55,7 @@ if "c4" in which:   # finetune step, local batch 8, ch 32-256, AdamW, dropout on
     opt = torch.optim.AdamW(net.parameters(), lr=1e-4, weight_decay=1e-4)
     d = synthetic_tile_batch(3407, 8, 8, 64, device="cuda")
     def step():
-        opt.zero_grad(set_to_none=True); loss = diff(d, "WV3").sum(); loss.backward(); opt.step(); return float(loss)
+        opt.zero_grad(set_to_none=True); loss = diff(d, "WV3").sum(); loss.backward(); opt.step(); return float(loss.detach())
     step(); step()
     dt, loss = sync_time(lambda: [step() for _ in range(5)])
     print(f"config4 (1 GPU share): train step local batch 8, 8x64x64, dropout on: {dt / 5 * 1e3:.1f} ms/step "
