@@ -252,6 +252,14 @@ def main():
         arrs[f"T{T}_last_only"] = diff.p_sample_loop(d, continous=False, prompt="WV3")
     save("ddpm", **arrs)
 
+    # ---- (9b) the full T = 1000 chain of BASELINE config 2 (one tile; ~2 min of reference CPU time) -----------------
+    if not ONLY or "ddpm1000" in ONLY:
+        diff = RD.GeneralDiffusion(net, loss_type="l1")
+        diff.set_new_noise_schedule({"schedule": "cosine", "n_timestep": 1000}, "cpu")
+        d = case_inputs(77, 1, 8, 16)
+        torch.manual_seed(1000)
+        save("ddpm1000", last_only=diff.p_sample_loop(d, continous=False, prompt="WV3"))
+
     # ---- (10) DPM-Solver++ ------------------------------------------------------------------
     arrs = {}
     diff = RD.GeneralDiffusion(net, loss_type="l1")
