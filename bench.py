@@ -425,11 +425,15 @@ def main():
     if rank == 0:
         n3, ms3, fl3 = conv.get(3, (0, 0.0, 0.0))
         n1, ms1, fl1 = conv.get(1, (0, 0.0, 0.0))
+        n0, ms0, by0 = conv.get(0, (0, 0.0, 0.0))        # Winograd input-transform passes (HBM-bound; "flops" slot = bytes)
         achieved = fl3 / (ms3 * 1e-3) / 1e12 if ms3 > 0 else 0.0
         # FLOPs in the reference's operator order: a conv3d_ll_fwd launch (Conv_0 + halved LL band of a main-branch down
         # block as one strided convolution, csrc/conv3d_ll.hip) executes 48 of the 4 x 27 multiply-adds per output
-        fl3_ref = fl3 + sum(fl * (108.0 / 48.0 - 1.0) for (k, what), (n, ms, fl) in conv_by_entry.items()
-                            if k == 3 and what == "conv3d_ll_fwd")
+        # ... and a conv3d_wino_fwd launch (Winograd F(2,3) along the band axis, csrc/conv3d_wino.hip; its input-transform
+        # pass is inside the timed launch) 36 of the 2 x 27 per output pair
+        fl3_ref = fl3 + sum(fl * ((108.0 / 48.0 if what == "conv3d_ll_fwd" else 1.5) - 1.0)
+                            for (k, what), (n, ms, fl) in conv_by_entry.items()
+                            if k == 3 and what in ("conv3d_ll_fwd", "conv3d_wino_fwd"))
         traffic, traffic_src = load_traffic()
         line = {
             "metric": "UNet denoise-steps/sec (8-ch 64x64, batch 32)",
@@ -449,8 +453,9 @@ def main():
             "roofline": {"bound": "mfma", "achieved": round(achieved, 2), "peak": PEAK_FP32_MFMA, "unit": "TFLOP/s",
                          "frac": round(achieved / PEAK_FP32_MFMA, 4), "traffic": traffic, "traffic_source": traffic_src,
                          "kernel": "3x3x3 conv launches, fp32 v_mfma_f32_32x32x2_f32: conv3d_mfma_kernel<3,..> (fused prologue), "
-                                   "prologue_apply_kernel + conv3d_dma_kernel<3,..> (staged) or conv3d_ll_kernel (Conv_0 + LL band "
-                                   "of the main branch's down blocks as one strided convolution), chosen per layer",
+                                   "prologue_apply_kernel + conv3d_dma_kernel<3,..> (staged), wino_input_kernel + conv3d_wino_kernel "
+                                   "(Winograd F(2,3) along the band axis: 1.5x fewer multiply-adds) or conv3d_ll_kernel (Conv_0 + LL "
+                                   "band of the main branch's down blocks as one strided convolution), chosen per layer",
                          "flops_counted": "EXECUTED on the matrix pipe (what the roofline bounds); in the reference's operator "
                                           "order the same launches are worth `reference_order_tflops`",
                          "reference_order_tflops": round(fl3_ref / (ms3 * 1e-3) / 1e12, 2) if ms3 > 0 else 0.0,
@@ -465,6 +470,13 @@ def main():
                          "by_entry": {what: {"launches": n, "avg_launch_us": round(ms / n * 1e3, 2),
                                              "tflops": round(fl / (ms * 1e-3) / 1e12, 2)}
                                       for (k, what), (n, ms, fl) in sorted(conv_by_entry.items()) if k == 3},
+                         "input_transform_passes": {"launches": n0, "avg_launch_us": round(ms0 / max(n0, 1) * 1e3, 2),
+                                                    "tb_per_s": round(by0 / (ms0 * 1e-3) / 1e12, 2) if ms0 > 0 else 0.0,
+                                                    "note": "wino_input_kernel in front of every conv3d_wino_kernel launch: "
+                                                            "HBM-bound (4 B read + 8 B written per input element), timed apart "
+                                                            "and NOT inside `achieved`; with them the 3x3x3 launches run at "
+                                                            f"{round(fl3 / ((ms3 + ms0) * 1e-3) / 1e12, 2) if ms3 > 0 else 0.0} "
+                                                            "TFLOP/s executed"},
                          "k1_conv": {"launches": n1, "avg_launch_us": round(ms1 / max(n1, 1) * 1e3, 2),
                                      "tflops": round(fl1 / (ms1 * 1e-3) / 1e12, 2) if ms1 > 0 else 0.0}},
         }

@@ -597,6 +597,47 @@ def test_conv3d_ll_is_conv_then_halved_ll_band(ops, case):
         ops.conv3d_ll(cu(x[..., :-1]), wp, cout, 0.5)      # odd width
 
 
+@pytest.mark.parametrize("case", [
+    # B, segs, Cout, N, H, W, groups
+    (2, (8,), 64, 8, 16, 16, 1),          # 64-channel tiles, whole tiles
+    (1, (6,), 32, 4, 12, 20, 1),          # 32-channel tiles, ragged in t / h / w, odd chunk count
+    (1, (8, 8, 8), 96, 6, 8, 12, 1),      # three segments (concat-free), Cout = 96, three pairs (ragged in t)
+    (2, (4, 4, 4), 192, 4, 8, 8, 3),      # groups = 3 (convH_0): one segment per group, 64 output channels each
+])
+def test_conv3d_winograd_along_bands(ops, case):
+    """tmdiff_conv3d_wino_fwd: F(2,3) along the band axis (input transform pass with the prologue + 36-tap kernel + output
+    transform in the epilogue) against the CPU convolution (fp64) and the direct HIP kernel; prologue, bias, residual,
+    scale and second output included."""
+    B, segc, cout, N, H, W, groups = case
+    cin = sum(segc)
+    torch.manual_seed(31 + cout)
+    segs = [torch.randn(B, c, N, H, W) for c in segc]
+    x = torch.cat(segs, 1)
+    w, bias = torch.randn(cout, cin // groups, 3, 3, 3) / (cin // groups * 27) ** 0.5, torch.randn(cout)
+    sh, sc = torch.randn(B, cin) * 0.3, torch.rand(B, cin) + 0.5
+    res = torch.randn(B, cout, N, H, W)
+    sh2, sc2 = torch.randn(B, cout) * 0.3, torch.rand(B, cout) + 0.5
+    wp = ops.pack_conv_weight_wino(cu(w), groups=groups)
+    want = F.conv3d(x.double(), w.double(), bias.double(), padding=1, groups=groups).float()
+    y = ops.conv3d_wino([cu(s_) for s_ in segs], wp, cout, bias=cu(bias), groups=groups)
+    assert_close(y, want, 2e-5, 2e-6, "winograd, plain input")
+    xs = x.double() + sh[:, :, None, None, None].double()
+    xs = xs * torch.sigmoid(xs) * sc[:, :, None, None, None].double()
+    want = ((F.conv3d(xs, w.double(), bias.double(), padding=1, groups=groups) + res.double()) * 0.7071).float()
+    v = want + sh2[:, :, None, None, None]
+    want2 = v * torch.sigmoid(v) * sc2[:, :, None, None, None]
+    y, y2 = ops.conv3d_wino([cu(s_) for s_ in segs], wp, cout, bias=cu(bias), in_shift=cu(sh), in_scale=cu(sc), in_act=True,
+                            residual=cu(res), out_scale=0.7071, emit=dict(act=True, shift=cu(sh2), scale=cu(sc2)), groups=groups)
+    assert_close(y, want, 2e-5, 2e-6, "winograd, prologue + residual")
+    assert_close(y2, want2, 2e-5, 2e-6, "winograd, second output")
+    direct = ops.conv3d([cu(s_) for s_ in segs], ops.pack_conv_weight(cu(w), groups=groups), cout, 3, groups=groups, bias=cu(bias),
+                        in_shift=cu(sh), in_scale=cu(sc), in_act=True, residual=cu(res), out_scale=0.7071)
+    assert_close(y, direct.cpu(), 1e-5, 1e-6, "winograd vs the direct kernel")
+    # a grid too small for the kernel (no split-K) or an odd band count goes to the fallback
+    marker = object()
+    assert ops.conv3d_wino([cu(s_[:, :, :N - 1]) for s_ in segs], wp, cout, groups=groups, fallback=lambda: marker) is marker
+
+
 def test_conv3d_large_plane_config3_shape(ops):
     """One level-0 convolution at the config-3 plane size (8 x 256 x 256 = 524288 positions per channel): offsets, tiling
     and zero padding on a large plane, for the fused, staged and bf16 kernels, against the CPU convolution."""

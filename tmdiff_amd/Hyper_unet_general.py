@@ -32,6 +32,7 @@ from . import ops
 PROMPTS = ("QB", "WV3", "GF2", "WV2", "WV4")
 _EPILOGUE_FUSE = os.environ.get("TMDIFF_EPILOGUE_FUSE", "1") != "0"   # experiments: "0" = consumers apply their own prologue
 _CONV2_AFTER_LL = os.environ.get("TMDIFF_CONV2_AFTER_LL", "1") != "0"   # experiments: "0" = Conv_2 of a down block at full resolution, as the reference orders it
+_WINOGRAD = os.environ.get("TMDIFF_WINOGRAD", "1") != "0"     # experiments: "0" = every 3x3x3 convolution on the direct kernels
 _LL_COMPOSE = os.environ.get("TMDIFF_LL_COMPOSE", "1") != "0"   # experiments: "0" = Conv_0 at full resolution + LL-only DWT where the high bands are dropped
 _PRODUCER_FUSE = os.environ.get("TMDIFF_PRODUCER_FUSE", "1") != "0"   # experiments: "0" = only the conv20 -> conv21 exchange
 
@@ -343,7 +344,7 @@ class WavBEST(nn.Module):
         dev = params[0].device
         if dev.type != "cuda":
             raise RuntimeError("tmdiff_amd.WavBEST runs on the HIP kernels only: move the module to a GPU (.cuda())")
-        prep = {"key": key, "w": {}, "w_ll": {}, "bf16": set(), "freqs": self._freqs_cpu.to(dev)}
+        prep = {"key": key, "w": {}, "w_ll": {}, "w_wino": {}, "bf16": set(), "freqs": self._freqs_cpu.to(dev)}
         for name, m in self.named_modules():
             if isinstance(m, nn.Conv3d) and m.in_channels > 1 and m.out_channels > 1:
                 w = m.weight.detach().float().contiguous()
@@ -355,6 +356,10 @@ class WavBEST(nn.Module):
                     prep["bf16"].add(name)
                 else:
                     prep["w"][name] = ops.pack_conv_weight(w, groups=m.groups)
+                    # exact-fp32 mode: the 3x3x3 convolutions also in the Winograd F(2,3)-along-n form (csrc/conv3d_wino.hip:
+                    # 1.5x fewer multiply-adds; taken when the band count is even and the grid fills the chip)
+                    if _WINOGRAD and ops.wino_conv_supported(m.out_channels, m.in_channels, m.kernel_size[0], m.groups):
+                        prep["w_wino"][name] = ops.pack_conv_weight_wino(w, groups=m.groups)
         # Conv_0 of the main branch's down blocks is followed by an LL-only DWT (its high bands are dropped): the pair runs
         # as one strided convolution on composed weights (csrc/conv3d_ll.hip), exact-fp32 mode only
         if self.compute_dtype == "fp32" and _LL_COMPOSE:
@@ -383,10 +388,13 @@ class WavBEST(nn.Module):
     # ---- fused building blocks -------------------------------------------------------------------
     def _conv(self, P, name, segs, use_bias=True, bias_scale=1.0, **kw):
         m = self.get_submodule(name)
-        return ops.conv3d(segs, P["w"][name], m.out_channels, m.kernel_size[0], groups=m.groups,
-                          math="bf16" if name in P["bf16"] else "fp32",
-                          bias=m.bias.detach() if (use_bias and m.bias is not None) else None,
-                          bias_scale=bias_scale, **kw)
+        bias = m.bias.detach() if (use_bias and m.bias is not None) else None
+        direct = lambda: ops.conv3d(segs, P["w"][name], m.out_channels, m.kernel_size[0], groups=m.groups,
+                                    math="bf16" if name in P["bf16"] else "fp32", bias=bias, bias_scale=bias_scale, **kw)
+        ww = P["w_wino"].get(name)
+        if ww is None or kw.get("x_bf16_shape") is not None:
+            return direct()
+        return ops.conv3d_wino(segs, ww, m.out_channels, bias=bias, bias_scale=bias_scale, fallback=direct, groups=m.groups, **kw)
 
     @staticmethod
     def _shift(P, S, name):

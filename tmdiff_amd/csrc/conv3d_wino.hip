@@ -1,0 +1,451 @@
+// 3x3x3 convolution with Winograd F(2,3) along the band axis n, on the exact-fp32 matrix cores.
+//
+// A pair of output bands (2t, 2t+1) of one (h, w) column needs the four input bands 2t-1 .. 2t+2.  With
+//     v0 = d0 - d2,  v1 = d1 + d2,  v2 = d2 - d1,  v3 = d1 - d3              (input transform, per element)
+//     u0 = g0,  u1 = (g0 + g1 + g2) / 2,  u2 = (g0 - g1 + g2) / 2,  u3 = g2   (weight transform along the n taps)
+//     m_k = sum over (ci, dh, dw) of u_k * v_k                                (four 3x3 convolutions in (h, w))
+//     y(2t) = m0 + m1 + m2,   y(2t+1) = m1 - m2 - m3
+// the pair costs 4 x 9 = 36 multiply-adds per (ci, co) instead of 2 x 27 = 54: 1.5x fewer FLOPs on the matrix pipe.
+// fp32 error: a few 1e-7 relative (sums of three inputs / weights before the product, three products per output).
+//
+// Pieces: wino_input_kernel writes V[b][c][t][k][h][w] (prologue applied first, segments concatenated; 2x the bytes of
+// x, an HBM pass), tmdiff_conv3d_wino_pack_weights writes U as [ci][dh*3+dw][k][co], and conv3d_wino_kernel is the
+// staged kernel (conv3d_dma.hip) over "taps" (dh, dw, k): the LDS box of an output tile holds, per channel, the TT x 4
+// planes (t, k) of its pairs with a one-pixel halo in (h, w); tap (dh, dw, k) multiplies plane k shifted by (dh, dw) into
+// accumulator k; the epilogue forms the two output bands in registers and hands them to the shared vector epilogue.
+#include <cstdlib>
+#include <type_traits>
+
+#include "common.h"
+#include "epilogue.h"
+
+namespace {
+
+using f32x16 = __attribute__((ext_vector_type(16))) float;
+
+template <int B, int E, class F>
+__device__ __forceinline__ void static_for(F&& f) {
+  if constexpr (B < E) {
+    f(std::integral_constant<int, B>{});
+    static_for<B + 1, E>(f);
+  }
+}
+
+struct WinoArgs {
+  int B, N, H, W;       // output = input extents (N even)
+  int Cin, Cout, cin_g, cout_g, groups;
+  const float* v;       // V [B, Cin, N/2, 4, H, W]
+  const float* wp;      // U packed [g][ci][9][4][co]
+  const float* bias;
+  float bias_scale;
+  const float* residual;
+  float out_scale;
+  float* y;
+  float* y2;
+  const float* y2_shift;
+  const float* y2_scale;
+  int y2_shift_stride, y2_scale_stride, y2_act;
+  int tiles_t, tiles_h, tiles_w, tiles_co;
+  unsigned total_blocks;
+  int vec4;
+};
+
+struct WinoInArgs {
+  int B, Cin, N, H, W, nseg;
+  int seg_c[3];
+  const float* seg_x[3];
+  const float* in_shift;
+  const float* in_scale;
+  int shift_stride, scale_stride, in_act;
+  float* v;
+};
+
+// one thread: one (b, c, t, h, w4) -- the four input bands of pair t (prologue applied), the four transformed planes out
+__global__ void __launch_bounds__(256) wino_input_kernel(const WinoInArgs a) {
+  const int bc = blockIdx.y, b = bc / a.Cin, c = bc % a.Cin;
+  int cs = c, seg = 0;
+  if (a.nseg > 1 && cs >= a.seg_c[0]) { cs -= a.seg_c[0]; seg = 1; }
+  if (seg == 1 && a.nseg > 2 && cs >= a.seg_c[1]) { cs -= a.seg_c[1]; seg = 2; }
+  const int segc = seg == 0 ? a.seg_c[0] : (seg == 1 ? a.seg_c[1] : a.seg_c[2]);
+  const long hw = (long)a.H * a.W;
+  const float* xs = (seg == 0 ? a.seg_x[0] : (seg == 1 ? a.seg_x[1] : a.seg_x[2])) + ((long)b * segc + cs) * a.N * hw;
+  const float sh = a.in_shift ? a.in_shift[(long)b * a.shift_stride + c] : 0.f;
+  const float sc = a.in_scale ? a.in_scale[(long)b * a.scale_stride + c] : 1.f;
+  const bool plain = !a.in_shift && !a.in_scale && !a.in_act;
+  const int T = a.N / 2;
+  float* vp = a.v + (long)bc * T * 4 * hw;
+  const long quads = hw / 4;                         // (H * W % 4 == 0: checked by the entry point)
+  for (long i = blockIdx.x * 256L + threadIdx.x; i < T * quads; i += 256L * gridDim.x) {
+    const int t = (int)(i / quads);
+    const long q = (i % quads) * 4;
+    float d[4][4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      const int n = 2 * t - 1 + k;
+      if (n >= 0 && n < a.N) {
+        const float4 x4 = *reinterpret_cast<const float4*>(xs + n * hw + q);
+        d[k][0] = x4.x, d[k][1] = x4.y, d[k][2] = x4.z, d[k][3] = x4.w;
+        if (!plain) {
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            float u = d[k][e] + sh;
+            const float ua = tmdiff::silu_f(u);
+            d[k][e] = (a.in_act ? ua : u) * sc;
+          }
+        }
+      } else {
+        d[k][0] = d[k][1] = d[k][2] = d[k][3] = 0.f;   // zero padding of the convolution
+      }
+    }
+    float4 o[4];
+    o[0] = make_float4(d[0][0] - d[2][0], d[0][1] - d[2][1], d[0][2] - d[2][2], d[0][3] - d[2][3]);
+    o[1] = make_float4(d[1][0] + d[2][0], d[1][1] + d[2][1], d[1][2] + d[2][2], d[1][3] + d[2][3]);
+    o[2] = make_float4(d[2][0] - d[1][0], d[2][1] - d[1][1], d[2][2] - d[1][2], d[2][3] - d[1][3]);
+    o[3] = make_float4(d[1][0] - d[3][0], d[1][1] - d[3][1], d[1][2] - d[3][2], d[1][3] - d[3][3]);
+#pragma unroll
+    for (int k = 0; k < 4; ++k) *reinterpret_cast<float4*>(vp + ((long)t * 4 + k) * hw + q) = o[k];
+  }
+}
+
+__device__ const float4 kZero4 = {0.f, 0.f, 0.f, 0.f};  // source of zero padding / filler lanes
+
+__device__ __forceinline__ void dma_b32(const float* src, float* dst) {
+#if defined(__HIP_DEVICE_COMPILE__)  // the builtin exists in the device pass only
+  __builtin_amdgcn_global_load_lds(src, dst, 4, 0, 0);
+#endif
+}
+__device__ __forceinline__ void dma_b128(const float* src, float* dst) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  __builtin_amdgcn_global_load_lds(src, dst, 16, 0, 0);
+#endif
+}
+
+__device__ __forceinline__ unsigned xcd_remap(unsigned bid, unsigned nwg) {
+  const unsigned q = nwg / 8, r = nwg % 8, xcd = bid % 8, k = bid / 8;
+  return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + k;
+}
+
+constexpr int W_TAPS = 36;   // (dh, dw) x k
+
+template <int NS, int MSUB, int KC, int TT, int TH, int TW>
+struct GeoW {
+  static constexpr int CO = 32 * MSUB;
+  static constexpr int HH = TH + 2, HW = TW + 2;
+  static constexpr int PLANE = HH * HW;
+  static constexpr int TILE_ELEMS = TT * 4 * PLANE;         // [TT pairs][4 planes][HH][HW] of one channel
+  static constexpr int LDS_IN = KC * TILE_ELEMS;
+  static constexpr int XP = (LDS_IN + 63) / 64;             // dword pieces (64 floats each)
+  static constexpr int X_FLOATS = XP * 64;
+  static constexpr int W_UNITS = KC * W_TAPS * CO / 4;      // weight slab [KC][36][CO] in 16-byte units
+  static constexpr int WP = (W_UNITS + 63) / 64;
+  static constexpr int STAGE = X_FLOATS + WP * 256;
+  static_assert(TT * TH * TW == 4 * NS * 32, "workgroup tile = 4 waves x NS sub-tiles x 32 pair positions");
+  static_assert(KC % 2 == 0, "K step is 2 channels");
+  static_assert((TH * TW) % 32 == 0, "a sub-tile of 32 pair positions lies in one pair");
+};
+
+template <int NS, int MSUB, int KC, int TT, int TH, int TW>
+__global__ void __launch_bounds__(256, 2) conv3d_wino_kernel(const WinoArgs a) {
+  using G = GeoW<NS, MSUB, KC, TT, TH, TW>;
+  constexpr int CO = G::CO;
+  constexpr int XK = (G::XP + 3) / 4, WK = (G::WP + 3) / 4;  // pieces per wave
+  __shared__ __attribute__((aligned(16))) float st0[G::STAGE];
+  __shared__ __attribute__((aligned(16))) float st1[G::STAGE];
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63, wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int l31 = lane & 31, khalf = lane >> 5;
+
+  unsigned id = xcd_remap(blockIdx.x, a.total_blocks);
+  const int co_tile = __builtin_amdgcn_readfirstlane(id % a.tiles_co); id /= a.tiles_co;
+  const int tw_i = __builtin_amdgcn_readfirstlane(id % a.tiles_w); id /= a.tiles_w;
+  const int th_i = __builtin_amdgcn_readfirstlane(id % a.tiles_h); id /= a.tiles_h;
+  const int tt_i = __builtin_amdgcn_readfirstlane(id % a.tiles_t); id /= a.tiles_t;
+  const int g = __builtin_amdgcn_readfirstlane(id % a.groups);
+  const int b = __builtin_amdgcn_readfirstlane(id / a.groups);
+  const int t0 = tt_i * TT, h0 = th_i * TH, w0 = tw_i * TW;
+  const int co0 = co_tile * CO;
+  const int T = a.N / 2;
+  const long plane = (long)a.N * a.H * a.W;                    // output plane
+  const int plane_v = T * 4 * a.H * a.W;                       // one channel of V
+  const int nchunks = a.cin_g / KC;
+
+  // ---- DMA sources of this lane (the same for every chunk) -----------------------------------------------------
+  int xsrc[XK];  // float offset from the chunk base, or -1 = zero word
+#pragma unroll
+  for (int k = 0; k < XK; ++k) {
+    const int f = (wv + 4 * k) * 64 + lane;
+    const int kc = f / G::TILE_ELEMS, e = f % G::TILE_ELEMS;
+    const int tz = e / (4 * G::PLANE), xi = (e / G::PLANE) % 4, r = e % G::PLANE;
+    const int hz = r / G::HW, wz = r % G::HW;
+    const int t = t0 + tz, h = h0 + hz - 1, w = w0 + wz - 1;
+    const bool ok = f < G::LDS_IN && t < T && h >= 0 && h < a.H && w >= 0 && w < a.W;
+    xsrc[k] = ok ? kc * plane_v + ((t * 4 + xi) * a.H + h) * a.W + w : -1;
+  }
+  int wsrc[WK];  // float offset inside the chunk's rows, or -1
+#pragma unroll
+  for (int k = 0; k < WK; ++k) {
+    const int u = (wv + 4 * k) * 64 + lane;
+    wsrc[k] = u < G::W_UNITS ? (u / (CO / 4)) * a.cout_g + (u % (CO / 4)) * 4 : -1;
+  }
+  const float* xg = a.v + ((long)b * a.Cin + (long)g * a.cin_g) * plane_v;
+  const float* wg = a.wp + (long)g * a.cin_g * W_TAPS * a.cout_g + co0;
+  const float* zero = reinterpret_cast<const float*>(&kZero4);
+
+  constexpr int NPIECE = XK + WK;
+  auto issue_piece = [&](auto ic, int c, float* st) __attribute__((always_inline)) {
+    constexpr int i = decltype(ic)::value;
+    if constexpr (i < XK) {
+      constexpr int k = i;
+      const int q = wv + 4 * k;
+      if (G::XP % 4 == 0 || q < G::XP) dma_b32(xsrc[k] >= 0 ? xg + (long)c * KC * plane_v + xsrc[k] : zero, st + q * 64);
+    } else if constexpr (i < NPIECE) {
+      constexpr int k = i - XK;
+      const int q = wv + 4 * k;
+      if (G::WP % 4 == 0 || q < G::WP)
+        dma_b128(wsrc[k] >= 0 ? wg + (long)c * KC * W_TAPS * a.cout_g + wsrc[k] : zero, st + G::X_FLOATS + q * 256);
+    }
+  };
+  static_for<0, NPIECE>([&](auto ic) __attribute__((always_inline)) { issue_piece(ic, 0, st0); });
+  __builtin_amdgcn_sched_barrier(0);
+
+  // ---- per-lane operand offsets (floats inside a stage) ----------------------------------------------------------
+  int boff[NS];
+#pragma unroll
+  for (int s = 0; s < NS; ++s) {
+    const int p = (wv * NS + s) * 32 + l31;
+    const int pw = p % TW, ph = (p / TW) % TH, pt = p / (TW * TH);
+    boff[s] = (pt * 4 * G::HH + ph) * G::HW + pw + khalf * G::TILE_ELEMS;
+  }
+  const int aoff = G::X_FLOATS + khalf * W_TAPS * CO + l31 * MSUB;  // slab rows hold the tile's channels as [l31][m]
+
+  float bias_v[MSUB], sh2_v[MSUB], sc2_v[MSUB];
+#pragma unroll
+  for (int m = 0; m < MSUB; ++m) {
+    const int col = g * a.cout_g + co0 + m * 32 + l31;
+    bias_v[m] = a.bias ? a.bias[col] * a.bias_scale : 0.f;
+    sh2_v[m] = (a.y2 && a.y2_shift) ? a.y2_shift[(long)b * a.y2_shift_stride + col] : 0.f;
+    sc2_v[m] = (a.y2 && a.y2_scale) ? a.y2_scale[(long)b * a.y2_scale_stride + col] : 1.f;
+  }
+
+  f32x16 acc[4 * NS][MSUB];     // [k * NS + s][m]
+#pragma unroll
+  for (int s = 0; s < 4 * NS; ++s)
+#pragma unroll
+    for (int m = 0; m < MSUB; ++m)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[s][m][r] = 0.f;
+
+  constexpr int MF = NS * MSUB;
+  constexpr int KSTEPS = (KC / 2) * W_TAPS;
+  constexpr int PSTRIDE = KSTEPS / NPIECE > 0 ? KSTEPS / NPIECE : 1;
+  static_assert(NPIECE <= KSTEPS, "at most one piece per K-step");
+  auto mfma_chunk = [&](const float* st, int c_next, float* st_next) __attribute__((always_inline)) {
+    float av[2][MSUB], bv[2][NS];
+    auto fetch = [&](auto ksc) __attribute__((always_inline)) {
+      constexpr int ks = decltype(ksc)::value;
+      constexpr int kp = ks / W_TAPS, tap = ks % W_TAPS;
+      constexpr int xi = tap % 4, dh = (tap / 4) / 3, dw = (tap / 4) % 3;
+      constexpr int toff = (xi * G::HH + dh) * G::HW + dw;
+      const float* ap = st + aoff + (kp * 2 * W_TAPS + tap) * CO;
+      if constexpr (MSUB == 1) {
+        av[ks & 1][0] = ap[0];
+      } else {
+        const float2 t2 = *reinterpret_cast<const float2*>(ap);
+        av[ks & 1][0] = t2.x, av[ks & 1][1] = t2.y;
+      }
+#pragma unroll
+      for (int s = 0; s < NS; ++s) bv[ks & 1][s] = st[boff[s] + kp * 2 * G::TILE_ELEMS + toff];
+    };
+    fetch(std::integral_constant<int, 0>{});
+    static_for<0, KSTEPS>([&](auto ksc) __attribute__((always_inline)) {
+      constexpr int ks = decltype(ksc)::value;
+      constexpr int xi = (ks % W_TAPS) % 4;
+      static_for<0, MF>([&](auto jc) __attribute__((always_inline)) {
+        constexpr int j = decltype(jc)::value;
+        constexpr int s = j / MSUB, m = j % MSUB;
+        acc[xi * NS + s][m] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[ks & 1][m], bv[ks & 1][s], acc[xi * NS + s][m], 0, 0, 0);
+        if constexpr (j == 0) {
+          __builtin_amdgcn_sched_barrier(0);
+          if constexpr (ks + 1 < KSTEPS) fetch(std::integral_constant<int, ks + 1>{});
+          __builtin_amdgcn_sched_barrier(0);
+        }
+        if constexpr (j == MF - 1 && ks % PSTRIDE == 0 && ks / PSTRIDE < NPIECE) {
+          __builtin_amdgcn_sched_barrier(0);
+          issue_piece(std::integral_constant<int, ks / PSTRIDE>{}, c_next, st_next);
+          __builtin_amdgcn_sched_barrier(0);
+        }
+      });
+      __builtin_amdgcn_sched_barrier(0);
+    });
+  };
+
+  __syncthreads();
+  for (int c = 0; c < nchunks; c += 2) {
+    mfma_chunk(st0, c + 1 < nchunks ? c + 1 : 0, st1);
+    __syncthreads();
+    if (c + 1 < nchunks) {
+      mfma_chunk(st1, c + 2 < nchunks ? c + 2 : 0, st0);
+      __syncthreads();
+    }
+  }
+
+  // ---- output transform in registers: bands 2t (m0 + m1 + m2) and 2t + 1 (m1 - m2 - m3) of every sub-tile ---------
+  f32x16 out[2 * NS][MSUB];      // [s * 2 + j][m]
+  int sub_base[2 * NS];          // linear position (over the 2 TT x TH x TW output tile) of the sub-tile's first position
+#pragma unroll
+  for (int s = 0; s < NS; ++s) {
+    const int pb = (wv * NS + s) * 32;
+    const int pt = pb / (TW * TH), rem = pb % (TW * TH);
+#pragma unroll
+    for (int j = 0; j < 2; ++j) sub_base[s * 2 + j] = (2 * pt + j) * (TW * TH) + rem;
+#pragma unroll
+    for (int m = 0; m < MSUB; ++m)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const float m0 = acc[0 * NS + s][m][r], m1 = acc[1 * NS + s][m][r], m2 = acc[2 * NS + s][m][r], m3 = acc[3 * NS + s][m][r];
+        out[s * 2][m][r] = m0 + m1 + m2;
+        out[s * 2 + 1][m][r] = m1 - m2 - m3;
+      }
+  }
+  // (the chunk loop ends with a barrier: nobody reads the stages any more)
+  static_assert(sizeof(st0) >= 4 * 4096, "the epilogue borrows 4 KB of LDS per wave");
+  tmdiff::epilogue_vec<2 * NS, MSUB, 2 * TT, TH, TW>(a, out, bias_v, sh2_v, sc2_v, b, g, co0, 2 * t0, h0, w0, wv, lane, plane,
+                                                     st0 + wv * 1024, sub_base);
+}
+
+template <int NS, int MSUB, int KC, int TT, int TH, int TW>
+int launch(WinoArgs& a, hipStream_t st) {
+  constexpr int CO = 32 * MSUB;
+  a.tiles_t = (a.N / 2 + TT - 1) / TT;
+  a.tiles_h = (a.H + TH - 1) / TH;
+  a.tiles_w = (a.W + TW - 1) / TW;
+  a.tiles_co = a.cout_g / CO;
+  const long blocks = (long)a.B * a.groups * a.tiles_t * a.tiles_h * a.tiles_w * a.tiles_co;
+  if (blocks <= 0 || blocks > 0x7fffffffL) return tmdiff::fail(TMDIFF_E_INVALID, "conv3d_wino_fwd: grid of %ld blocks", blocks);
+  a.total_blocks = (unsigned)blocks;
+  conv3d_wino_kernel<NS, MSUB, KC, TT, TH, TW><<<(unsigned)blocks, 256, 0, st>>>(a);
+  return tmdiff::check_launch("conv3d_wino_fwd");
+}
+
+// packed[g][ci][tap9][k][col(co)] = (G g)[k] of w[g * cout_g + co][ci][.][dh][dw]   (ci, co inside the group)
+// (column order inside a 64-channel tile as tmdiff_conv3d_pack_weights: channel c at (c % 32) * 2 + c / 32)
+__global__ void __launch_bounds__(256) wino_pack_weights_kernel(const float* __restrict__ w, float* __restrict__ packed, int cout_g,
+                                                                int cin_g, long total) {
+  for (long i = blockIdx.x * 256L + threadIdx.x; i < total; i += 256L * gridDim.x) {
+    const int col = (int)(i % cout_g);
+    long r = i / cout_g;
+    const int k = (int)(r % 4); r /= 4;
+    const int tap9 = (int)(r % 9); r /= 9;
+    const int ci = (int)(r % cin_g);
+    const int g = (int)(r / cin_g);
+    int co = col;
+    if (cout_g % 64 == 0) {
+      const int tile = col / 64, j = col % 64;
+      co = tile * 64 + (j % 2) * 32 + j / 2;
+    }
+    const float* wk = w + (((long)g * cout_g + co) * cin_g + ci) * 27 + tap9;   // [dn][dh][dw]: dn stride 9
+    const float g0 = wk[0], g1 = wk[9], g2 = wk[18];
+    packed[i] = k == 0 ? g0 : (k == 1 ? 0.5f * (g0 + g1 + g2) : (k == 2 ? 0.5f * (g0 - g1 + g2) : g2));
+  }
+}
+
+bool wino_ok(const tmdiff_conv3d_desc* d) {
+  if (!d || d->ksize != 3 || (d->groups != 1 && d->groups != 3) || d->in_mask || d->drop_p > 0.f || d->x_bf16 || d->y2_bf16) return false;
+  if (d->nseg < 1 || d->nseg > 3 || d->Cin <= 0 || d->Cout <= 0 || d->Cin % d->groups || d->Cout % d->groups) return false;
+  return (d->Cin / d->groups) % 2 == 0 && (d->Cout / d->groups) % 32 == 0 && d->N > 0 && d->N % 2 == 0 && d->H > 0 && d->W > 0 &&
+         d->W % 4 == 0;
+}
+
+}  // namespace
+
+extern "C" int tmdiff_conv3d_wino_supported(const tmdiff_conv3d_desc* d) { return wino_ok(d) ? 1 : 0; }
+
+// workgroups the convolution kernel would launch (0 = shape not supported): callers keep small grids on tmdiff_conv3d_fwd,
+// whose split-K fills the chip
+extern "C" int64_t tmdiff_conv3d_wino_blocks(const tmdiff_conv3d_desc* d) {
+  if (!wino_ok(d) || d->B <= 0) return 0;
+  const int T = d->N / 2, cg = d->Cout / d->groups;
+  if (cg % 64 == 0) return (int64_t)d->B * d->groups * ((T + 1) / 2) * ((d->H + 7) / 8) * ((d->W + 7) / 8) * (cg / 64);
+  return (int64_t)d->B * d->groups * ((T + 1) / 2) * ((d->H + 7) / 8) * ((d->W + 15) / 16) * (cg / 32);
+}
+
+extern "C" size_t tmdiff_conv3d_wino_workspace_bytes(const tmdiff_conv3d_desc* d) {
+  if (!wino_ok(d) || d->B <= 0) return 0;
+  return (size_t)d->B * d->Cin * (d->N / 2) * 4 * d->H * d->W * sizeof(float);
+}
+
+extern "C" size_t tmdiff_conv3d_wino_packed_bytes(int32_t Cout, int32_t Cin, int32_t groups) {
+  if (groups < 1 || Cout <= 0 || Cin <= 0 || Cout % groups || Cin % groups || (Cout / groups) % 32) return 0;
+  return (size_t)(Cin / groups) * W_TAPS * Cout * sizeof(float);
+}
+
+extern "C" int tmdiff_conv3d_wino_pack_weights(const float* w, float* packed, int32_t Cout, int32_t Cin, int32_t groups,
+                                               tmdiff_stream_t stream) {
+  using namespace tmdiff;
+  TMDIFF_REQUIRE(w && packed && aligned16(packed), "conv3d_wino_pack_weights: NULL / unaligned pointer");
+  TMDIFF_REQUIRE(groups >= 1 && Cout > 0 && Cin > 0 && Cout % groups == 0 && Cin % groups == 0 && (Cout / groups) % 32 == 0,
+                 "conv3d_wino_pack_weights: Cout=%d Cin=%d groups=%d (Cout/groups a multiple of 32)", Cout, Cin, groups);
+  const long total = (long)(Cin / groups) * W_TAPS * Cout;
+  long blocks = (total + 255) / 256;
+  if (blocks > 4096) blocks = 4096;
+  wino_pack_weights_kernel<<<(int)blocks, 256, 0, as_stream(stream)>>>(w, packed, Cout / groups, Cin / groups, total);
+  return check_launch("conv3d_wino_pack_weights");
+}
+
+// stage: 0 = input transform + convolution, 1 = the transform pass alone (fills the workspace), 2 = the convolution alone
+// (the workspace already holds this input's transform: a measurement, or several convolutions of one tensor)
+extern "C" int tmdiff_conv3d_wino_fwd_stage(const tmdiff_conv3d_desc* d, void* workspace, int32_t stage, tmdiff_stream_t stream) {
+  using namespace tmdiff;
+  TMDIFF_REQUIRE(d != nullptr, "conv3d_wino_fwd: NULL descriptor");
+  if (!wino_ok(d))
+    return fail(TMDIFF_E_UNSUPPORTED, "conv3d_wino_fwd: fp32 3x3x3, groups 1 or 3, even N, W %% 4 == 0, Cin/g %% 2 == 0, Cout/g %% 32 == 0, no mask");
+  TMDIFF_REQUIRE(d->B >= 0, "conv3d_wino_fwd: bad extents");
+  if (d->B == 0) return TMDIFF_OK;
+  TMDIFF_REQUIRE(workspace && aligned16(workspace), "conv3d_wino_fwd: needs its workspace (tmdiff_conv3d_wino_workspace_bytes)");
+  TMDIFF_REQUIRE(d->w_packed && (d->y || d->y2) && aligned16(d->w_packed), "conv3d_wino_fwd: NULL / unaligned weights or output");
+  TMDIFF_REQUIRE((long)d->Cin * (d->N / 2) * 4 * d->H * d->W < (1L << 31) / 2, "conv3d_wino_fwd: input too large for 32-bit offsets");
+  TMDIFF_REQUIRE((long)d->B * d->Cin <= 65535, "conv3d_wino_fwd: B*Cin = %ld exceeds the grid", (long)d->B * d->Cin);
+  int csum = 0;
+  for (int i = 0; i < d->nseg; ++i) {
+    TMDIFF_REQUIRE(d->seg_x[i] != nullptr && d->seg_c[i] > 0 && aligned16(d->seg_x[i]), "conv3d_wino_fwd: segment %d is empty / unaligned", i);
+    csum += d->seg_c[i];
+  }
+  TMDIFF_REQUIRE(csum == d->Cin, "conv3d_wino_fwd: segments hold %d channels, Cin=%d", csum, d->Cin);
+  hipStream_t st = as_stream(stream);
+
+  WinoInArgs q;
+  q.B = d->B; q.Cin = d->Cin; q.N = d->N; q.H = d->H; q.W = d->W; q.nseg = d->nseg;
+  for (int i = 0; i < 3; ++i) { q.seg_c[i] = i < d->nseg ? d->seg_c[i] : 0; q.seg_x[i] = i < d->nseg ? d->seg_x[i] : nullptr; }
+  q.in_shift = d->in_shift; q.in_scale = d->in_scale; q.in_act = d->in_act;
+  q.shift_stride = d->in_shift_stride > 0 ? d->in_shift_stride : (d->in_shift_stride < 0 ? 0 : d->Cin);
+  q.scale_stride = d->in_scale_stride > 0 ? d->in_scale_stride : (d->in_scale_stride < 0 ? 0 : d->Cin);
+  q.v = static_cast<float*>(workspace);
+  TMDIFF_REQUIRE(stage >= 0 && stage <= 2, "conv3d_wino_fwd: stage=%d", stage);
+  if (stage != 2) {
+    long pb = ((long)(d->N / 2) * d->H * d->W / 4 + 255) / 256;
+    if (pb > 64) pb = 64;
+    wino_input_kernel<<<dim3((unsigned)pb, (unsigned)(d->B * d->Cin)), 256, 0, st>>>(q);
+    const int rc = check_launch("conv3d_wino_fwd (input transform)");
+    if (rc || stage == 1) return rc;
+  }
+
+  WinoArgs a;
+  a.B = d->B; a.N = d->N; a.H = d->H; a.W = d->W;
+  a.Cin = d->Cin; a.Cout = d->Cout; a.groups = d->groups; a.cin_g = d->Cin / d->groups; a.cout_g = d->Cout / d->groups;
+  a.v = q.v; a.wp = d->w_packed;
+  a.bias = d->bias; a.bias_scale = d->bias_scale;
+  a.residual = d->residual; a.out_scale = d->out_scale; a.y = d->y;
+  a.y2 = d->y2; a.y2_shift = d->y2_shift; a.y2_scale = d->y2_scale; a.y2_act = d->y2_act;
+  a.y2_shift_stride = d->y2_shift_stride > 0 ? d->y2_shift_stride : (d->y2_shift_stride < 0 ? 0 : d->Cout);
+  a.y2_scale_stride = d->y2_scale_stride > 0 ? d->y2_scale_stride : (d->y2_scale_stride < 0 ? 0 : d->Cout);
+  a.vec4 = 1;
+  if (!(d->W % 4 == 0 && aligned16(d->y) && aligned16(d->y2) && aligned16(d->residual)))
+    return fail(TMDIFF_E_UNSUPPORTED, "conv3d_wino_fwd: W %% 4 == 0 and 16-byte aligned outputs / residual");
+  if (a.cout_g % 64 == 0) return launch<1, 2, 2, 2, 8, 8>(a, st);
+  return launch<2, 1, 2, 2, 8, 16>(a, st);
+}
+
+extern "C" int tmdiff_conv3d_wino_fwd(const tmdiff_conv3d_desc* d, void* workspace, tmdiff_stream_t stream) {
+  return tmdiff_conv3d_wino_fwd_stage(d, workspace, 0, stream);
+}

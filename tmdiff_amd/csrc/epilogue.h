@@ -26,14 +26,17 @@ __device__ __forceinline__ float lane_value(float v, int src_lane) {
 template <int NS, int MSUB, int TH, int TW, bool Y, bool RES, bool Y2, bool FULL, class Args, class Acc>
 __device__ __forceinline__ void epilogue_vec_v(const Args& a, Acc (&acc)[NS][MSUB], const float (&bias_v)[MSUB],
                                                const float (&sh2_v)[MSUB], const float (&sc2_v)[MSUB], int b, int g, int co0,
-                                               int n0, int h0, int w0, int wv, int lane, long plane, float* T) {
+                                               int n0, int h0, int w0, int wv, int lane, long plane, float* T,
+                                               const int* sub_base = nullptr) {
+  // sub_base[s]: linear index (over the TN x TH x TW output tile, w fastest) of the first position of sub-tile s; by
+  // default the waves' sub-tiles follow one another ((wv * NS + s) * 32)
   static_assert(TW % 4 == 0, "a quad of positions lies in one row");
   const int l31 = lane & 31, khalf = lane >> 5, tq = lane & 7, tc = lane >> 3;
   int toff[NS];
   bool tok[NS];
 #pragma unroll
   for (int s = 0; s < NS; ++s) {
-    const int p = (wv * NS + s) * 32 + 4 * tq;
+    const int p = (sub_base ? sub_base[s] : (wv * NS + s) * 32) + 4 * tq;
     const int n = n0 + p / (TW * TH), h = h0 + (p / TW) % TH, w = w0 + p % TW;
     tok[s] = FULL || (n < a.N && h < a.H && w < a.W);      // (W % 4 == 0: the four positions stand or fall together)
     toff[s] = tok[s] ? (n * a.H + h) * a.W + w : 0;
@@ -96,12 +99,13 @@ __device__ __forceinline__ void epilogue_vec_v(const Args& a, Acc (&acc)[NS][MSU
 template <int NS, int MSUB, int TN, int TH, int TW, class Args, class Acc>
 __device__ __forceinline__ void epilogue_vec(const Args& a, Acc (&acc)[NS][MSUB], const float (&bias_v)[MSUB],
                                              const float (&sh2_v)[MSUB], const float (&sc2_v)[MSUB], int b, int g, int co0,
-                                             int n0, int h0, int w0, int wv, int lane, long plane, float* T) {
+                                             int n0, int h0, int w0, int wv, int lane, long plane, float* T,
+                                             const int* sub_base = nullptr) {
   const bool full = n0 + TN <= a.N && h0 + TH <= a.H && w0 + TW <= a.W;
 #define TMDIFF_EPI(Y, R, Y2)                                                                                               \
   do {                                                                                                                     \
-    if (full) epilogue_vec_v<NS, MSUB, TH, TW, Y, R, Y2, true>(a, acc, bias_v, sh2_v, sc2_v, b, g, co0, n0, h0, w0, wv, lane, plane, T);  \
-    else epilogue_vec_v<NS, MSUB, TH, TW, Y, R, Y2, false>(a, acc, bias_v, sh2_v, sc2_v, b, g, co0, n0, h0, w0, wv, lane, plane, T);     \
+    if (full) epilogue_vec_v<NS, MSUB, TH, TW, Y, R, Y2, true>(a, acc, bias_v, sh2_v, sc2_v, b, g, co0, n0, h0, w0, wv, lane, plane, T, sub_base);  \
+    else epilogue_vec_v<NS, MSUB, TH, TW, Y, R, Y2, false>(a, acc, bias_v, sh2_v, sc2_v, b, g, co0, n0, h0, w0, wv, lane, plane, T, sub_base);     \
   } while (0)
   if (a.y) {
     if (a.residual) { if (a.y2) TMDIFF_EPI(true, true, true); else TMDIFF_EPI(true, true, false); }

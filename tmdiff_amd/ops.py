@@ -315,6 +315,67 @@ def conv3d_prologue(desc, shape):
     return xp
 
 
+def pack_conv_weight_wino(w, groups=1):
+    """[Cout, Cin/groups, 3, 3, 3] -> the transformed, packed weights of the Winograd F(2,3)-along-n convolution (conv3d_wino)."""
+    cout, cin = w.shape[0], w.shape[1] * groups
+    nb = lib.tmdiff_conv3d_wino_packed_bytes(cout, cin, groups)
+    if tuple(w.shape[2:]) != (3, 3, 3) or nb == 0:
+        raise ValueError(f"pack_conv_weight_wino: weight shape {tuple(w.shape)} (groups {groups}) not supported")
+    out = torch.empty(nb // 4, device=w.device, dtype=torch.float32)
+    check(lib.tmdiff_conv3d_wino_pack_weights(_chk(w.detach(), "w"), out.data_ptr(), cout, cin, groups, stream_ptr()),
+          "conv3d_wino_pack_weights")
+    return out
+
+
+_WINO_MIN_BLOCKS = int(os.environ.get("TMDIFF_WINO_MIN_BLOCKS", "256"))   # below: the direct kernels (split-K fills the chip)
+
+
+def wino_conv_supported(cout, cin, ksize=3, groups=1):
+    """Weight shapes tmdiff_conv3d_wino_fwd takes."""
+    return (ksize == 3 and groups in (1, 3) and cin % groups == 0 and cout % groups == 0 and (cin // groups) % 2 == 0 and
+            (cout // groups) % 32 == 0)
+
+
+def conv3d_wino(segs, w_packed, cout, emit=None, keep_y=True, fallback=None, groups=1, **kw):
+    """conv3d(segs, ...) (fp32, 3x3x3, groups 1) through the Winograd F(2,3)-along-n kernels (csrc/conv3d_wino.hip): an
+    input-transform pass (prologue and concatenation applied there) + a convolution with 1.5x fewer multiply-adds.
+    Same keyword arguments and return convention as conv3d; fallback = a callable that runs the direct convolution
+    instead when the shape is not taken or its grid would be too small (the kernel has no split-K)."""
+    b, _, n, h, w = segs[0].shape
+    dev = segs[0].device
+    if fallback is not None:         # unsupported extents, or a grid too small for a kernel without split-K (= tmdiff_conv3d_wino_blocks)
+        cg = cout // groups
+        blocks = b * groups * ((n // 2 + 1) // 2) * ((h + 7) // 8) * (((w + 7) // 8) * (cg // 64) if cg % 64 == 0 else ((w + 15) // 16) * (cg // 32))
+        if n % 2 or w % 4 or blocks < _WINO_MIN_BLOCKS:
+            return fallback()
+    y = torch.empty(b, cout, n, h, w, device=dev, dtype=torch.float32) if keep_y else None
+    y2 = None
+    if emit is not None:
+        y2 = torch.empty(b, cout, n, h, w, device=dev, dtype=torch.float32)
+        kw = dict(kw, y2_act=emit.get("act", False), y2_shift=emit.get("shift"), y2_scale=emit.get("scale"),
+                  y2_shift_stride=emit.get("shift_stride", 0), y2_scale_stride=emit.get("scale_stride", 0))
+    elif y is None:
+        raise ValueError("conv3d_wino: keep_y=False needs emit=")
+    d = make_conv_desc(segs, w_packed, cout, 3, y, y2=y2, groups=groups, **kw)
+    if not lib.tmdiff_conv3d_wino_supported(C.byref(d)):
+        raise ValueError("conv3d_wino: shape not supported")
+    ws = _workspace(dev, lib.tmdiff_conv3d_wino_workspace_bytes(C.byref(d)), "wino").data_ptr()
+    ret = y if y2 is None else ((y, y2) if y is not None else y2)
+    if TIMER is None:
+        check(lib.tmdiff_conv3d_wino_fwd(C.byref(d), ws, stream_ptr()), "conv3d_wino_fwd")
+        return ret
+    # timed: the input-transform pass (an HBM pass, recorded under ksize 0 with its bytes) and the convolution kernel apart
+    ev = [torch.cuda.Event(enable_timing=True) for _ in range(3)]
+    ev[0].record()
+    check(lib.tmdiff_conv3d_wino_fwd_stage(C.byref(d), ws, 1, stream_ptr()), "conv3d_wino_fwd (input transform)")
+    ev[1].record()
+    check(lib.tmdiff_conv3d_wino_fwd_stage(C.byref(d), ws, 2, stream_ptr()), "conv3d_wino_fwd")
+    ev[2].record()
+    TIMER.records.append((ev[0], ev[1], 12.0 * b * d.Cin * n * h * w, 0, "wino_input"))     # bytes: 4 B read + 8 B written
+    TIMER.records.append((ev[1], ev[2], 2.0 * b * cout * (d.Cin // groups) * 18 * n * h * w, 3, "conv3d_wino_fwd"))   # EXECUTED: 36 per pair
+    return ret
+
+
 def ll_conv_supported(cout, cin, ksize=3, groups=1):
     """Shapes tmdiff_conv3d_ll_fwd takes (conv3d_ll_halved below)."""
     return ksize == 3 and groups == 1 and cin % 2 == 0 and cout % 64 == 0

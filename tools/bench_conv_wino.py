@@ -1,0 +1,33 @@
+#!/usr/bin/env python3
+"""Winograd-along-n convolution (csrc/conv3d_wino.hip) beside the direct staged kernel, per layer shape of the bench
+workload, plain input.  Usage: python tools/bench_conv_wino.py [B] [reps]"""
+import os, sys
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+from tmdiff_amd import ops
+
+B = int(sys.argv[1]) if len(sys.argv) > 1 else 32
+REPS = int(sys.argv[2]) if len(sys.argv) > 2 else 5
+LAYERS = [("L0 32->32", 32, 32, 64), ("L0 32->64", 32, 64, 64), ("L0 64->64", 64, 64, 64), ("L1 64->128", 64, 128, 32),
+          ("L1 128->128", 128, 128, 32), ("L2 256->256", 256, 256, 16), ("L3 256->256", 256, 256, 8)]
+
+
+def t(fn):
+    fn(); torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(REPS): fn()
+    e1.record(); torch.cuda.synchronize()
+    return e0.elapsed_time(e1) / REPS
+
+
+for name, ci, co, h in LAYERS:
+    x = torch.randn(B, ci, 8, h, h, device="cuda")
+    w = torch.randn(co, ci, 3, 3, 3, device="cuda") / (ci * 27) ** 0.5
+    y = torch.empty(B, co, 8, h, h, device="cuda")
+    ww, wd = ops.pack_conv_weight_wino(w), ops.pack_conv_weight(w)
+    a = t(lambda: ops.conv3d_wino([x], ww, co))
+    b = t(lambda: ops.conv3d([x], wd, co, 3, out=y))
+    fl = 2.0 * B * co * ci * 27 * 8 * h * h
+    print(f"{name:12s} winograd {a:6.3f} ms ({fl / a / 1e9:6.1f} TFLOP/s in the direct count, {fl / 1.5 / a / 1e9:6.1f} executed) | "
+          f"direct {b:6.3f} ms ({fl / b / 1e9:6.1f} TFLOP/s)", flush=True)
