@@ -633,6 +633,15 @@ def test_conv3d_winograd_along_bands(ops, case):
     direct = ops.conv3d([cu(s_) for s_ in segs], ops.pack_conv_weight(cu(w), groups=groups), cout, 3, groups=groups, bias=cu(bias),
                         in_shift=cu(sh), in_scale=cu(sc), in_act=True, residual=cu(res), out_scale=0.7071)
     assert_close(y, direct.cpu(), 1e-5, 1e-6, "winograd vs the direct kernel")
+    # in-kernel dropout of the prologue output (finetune path): the same keep mask as the direct kernels, and x' kept
+    xp = torch.empty(B, cin, N, H, W, device="cuda")
+    yd = ops.conv3d_wino([cu(s_) for s_ in segs], wp, cout, in_shift=cu(sh), in_act=True, drop=(1234, 0.2), groups=groups, xp_out=xp)
+    staged = (cin // groups) % 4 == 0            # (the direct path keeps x' only on its staged kernel)
+    xp_d = torch.empty_like(xp) if staged else None
+    dd = ops.conv3d([cu(s_) for s_ in segs], ops.pack_conv_weight(cu(w), groups=groups), cout, 3, groups=groups, in_shift=cu(sh),
+                    in_act=True, drop=(1234, 0.2), xp_out=xp_d)
+    assert 0.1 < float((xp == 0).float().mean()) < 0.3 and (not staged or torch.equal(xp, xp_d))
+    assert_close(yd, dd.cpu(), 1e-5, 1e-6, "winograd vs the direct kernel, dropout")
     # a grid too small for the kernel (no split-K) or an odd band count goes to the fallback
     marker = object()
     assert ops.conv3d_wino([cu(s_[:, :, :N - 1]) for s_ in segs], wp, cout, groups=groups, fallback=lambda: marker) is marker

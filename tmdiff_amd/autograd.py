@@ -17,6 +17,7 @@ import os as _os
 # "1": the bias gradient is accumulated inside the weight-gradient kernel (tmdiff_conv3d_wgrad_bias) instead of a
 # tmdiff_channel_sum pass over g.  Measured on one box, same process pair: 43.4 vs 43.2 ms per finetune step -- the saved
 # pass (0.6 ms of launches) is paid back inside the MFMA stream -- so the separate pass stays the default.
+_WINOGRAD = _os.environ.get("TMDIFF_WINOGRAD", "1") != "0"     # experiments: "0" = direct kernels for every convolution
 _WGRAD_BIAS = _os.environ.get("TMDIFF_WGRAD_BIAS", "0") == "1"
 
 
@@ -52,9 +53,18 @@ class _FusedConv3d(torch.autograd.Function):
             cin = sum(s.shape[1] for s in segs)
             if cin % groups == 0 and (cin // groups) % 4 == 0 and (cout // groups) % 32 == 0:   # shapes the staged kernel takes
                 xp = torch.empty(b, cin, n, h, wd, device=segs[0].device, dtype=torch.float32)
-        y = ops.conv3d(segs, wp, cout, ksize, groups=groups, bias=bias, bias_scale=bias_scale, in_shift=shift,
-                       in_scale=scale, in_act=act, in_mask=mask, drop=drop, residual=residual, out_scale=out_scale,
-                       xp_out=xp)
+        direct = lambda: ops.conv3d(segs, wp, cout, ksize, groups=groups, bias=bias, bias_scale=bias_scale, in_shift=shift,
+                                    in_scale=scale, in_act=act, in_mask=mask, drop=drop, residual=residual,
+                                    out_scale=out_scale, xp_out=xp)
+        cin = sum(s.shape[1] for s in segs)
+        # 3x3x3 convolutions (in-kernel dropout included): Winograd F(2,3) along the band axis (1.5x fewer multiply-adds), where its grid
+        # fills the chip -- otherwise, and for everything else, the direct kernels
+        if _WINOGRAD and mask is None and ops.wino_conv_supported(cout, cin, ksize, groups):
+            y = ops.conv3d_wino(segs, None, cout, bias=bias, bias_scale=bias_scale, in_shift=shift, in_scale=scale,
+                                in_act=act, drop=drop, residual=residual, out_scale=out_scale, groups=groups, fallback=direct,
+                                xp_out=xp, w_packed_fn=lambda: ops.pack_conv_weight_wino(w, groups))
+        else:
+            y = direct()
         ctx.meta = meta
         ctx.nseg = len(segs)
         ctx.drop = drop
@@ -103,7 +113,12 @@ class _FusedConv3d(torch.autograd.Function):
         d_segs = [None] * len(segs)
         if need_x:
             wp_t = ctx.wp_dgrad if ctx.wp_dgrad is not None else ops.pack_conv_weight(w, groups=groups, mode=1)
-            gp = ops.conv3d([g], wp_t, cin, ksize, groups=groups)          # dL/dx'
+            direct = lambda: ops.conv3d([g], wp_t, cin, ksize, groups=groups)
+            if _WINOGRAD and ops.wino_conv_supported(cin, cout, ksize, groups):   # the data gradient is a 3x3x3 convolution too
+                gp = ops.conv3d_wino([g], None, cin, groups=groups, fallback=direct,
+                                     w_packed_fn=lambda: ops.pack_conv_weight_wino(w, groups, mode=1))
+            else:
+                gp = direct()                                                    # dL/dx'
             outs = [torch.empty_like(s) if need[7 + i] else None for i, s in enumerate(segs)]
             d_shift, d_scale = ops.conv3d_prologue_bwd(desc, gp, outs, [False] * len(segs),
                                                        has_shift and need[3], has_scale and need[4])

@@ -58,6 +58,10 @@ struct WinoInArgs {
   const float* in_scale;
   int shift_stride, scale_stride, in_act;
   float* v;
+  float* xp;                 // optional: the prologue output x' itself [B, Cin, N, H, W] (kept for the weight gradient)
+  uint64_t drop_seed;        // in-kernel dropout of x' (drop_inv > 0): common.h drop_keep, element index as in prologue_apply
+  uint32_t drop_thresh;
+  float drop_inv;
 };
 
 // one thread: one (b, c, t, h, w4) -- the four input bands of pair t (prologue applied), the four transformed planes out
@@ -71,7 +75,10 @@ __global__ void __launch_bounds__(256) wino_input_kernel(const WinoInArgs a) {
   const float* xs = (seg == 0 ? a.seg_x[0] : (seg == 1 ? a.seg_x[1] : a.seg_x[2])) + ((long)b * segc + cs) * a.N * hw;
   const float sh = a.in_shift ? a.in_shift[(long)b * a.shift_stride + c] : 0.f;
   const float sc = a.in_scale ? a.in_scale[(long)b * a.scale_stride + c] : 1.f;
-  const bool plain = !a.in_shift && !a.in_scale && !a.in_act;
+  const bool drop = a.drop_inv > 0.f;
+  const bool plain = !a.in_shift && !a.in_scale && !a.in_act && !drop;
+  const uint64_t ebase = (uint64_t)bc * (uint64_t)(a.N * hw);
+  float* xpp = a.xp ? a.xp + (long)bc * a.N * hw : nullptr;
   const int T = a.N / 2;
   float* vp = a.v + (long)bc * T * 4 * hw;
   const long quads = hw / 4;                         // (H * W % 4 == 0: checked by the entry point)
@@ -90,9 +97,13 @@ __global__ void __launch_bounds__(256) wino_input_kernel(const WinoInArgs a) {
           for (int e = 0; e < 4; ++e) {
             float u = d[k][e] + sh;
             const float ua = tmdiff::silu_f(u);
-            d[k][e] = (a.in_act ? ua : u) * sc;
+            u = (a.in_act ? ua : u) * sc;
+            if (drop) u *= tmdiff::drop_keep(a.drop_seed, ebase + (uint64_t)(n * hw + q + e), a.drop_thresh, a.drop_inv);
+            d[k][e] = u;
           }
         }
+        if (xpp && (k == 1 || k == 2))      // bands 2t and 2t+1: every element of x' exactly once
+          *reinterpret_cast<float4*>(xpp + n * hw + q) = make_float4(d[k][0], d[k][1], d[k][2], d[k][3]);
       } else {
         d[k][0] = d[k][1] = d[k][2] = d[k][3] = 0.f;   // zero padding of the convolution
       }
@@ -331,7 +342,7 @@ int launch(WinoArgs& a, hipStream_t st) {
 // packed[g][ci][tap9][k][col(co)] = (G g)[k] of w[g * cout_g + co][ci][.][dh][dw]   (ci, co inside the group)
 // (column order inside a 64-channel tile as tmdiff_conv3d_pack_weights: channel c at (c % 32) * 2 + c / 32)
 __global__ void __launch_bounds__(256) wino_pack_weights_kernel(const float* __restrict__ w, float* __restrict__ packed, int cout_g,
-                                                                int cin_g, long total) {
+                                                                int cin_g, int mode, long total) {
   for (long i = blockIdx.x * 256L + threadIdx.x; i < total; i += 256L * gridDim.x) {
     const int col = (int)(i % cout_g);
     long r = i / cout_g;
@@ -344,14 +355,21 @@ __global__ void __launch_bounds__(256) wino_pack_weights_kernel(const float* __r
       const int tile = col / 64, j = col % 64;
       co = tile * 64 + (j % 2) * 32 + j / 2;
     }
-    const float* wk = w + (((long)g * cout_g + co) * cin_g + ci) * 27 + tap9;   // [dn][dh][dw]: dn stride 9
-    const float g0 = wk[0], g1 = wk[9], g2 = wk[18];
+    float g0, g1, g2;
+    if (mode == 0) {
+      const float* wk = w + (((long)g * cout_g + co) * cin_g + ci) * 27 + tap9;   // [dn][dh][dw]: dn stride 9
+      g0 = wk[0], g1 = wk[9], g2 = wk[18];
+    } else {   // data-gradient form: this convolution's (co, ci) are the forward one's (ci, co), every tap mirrored
+      const float* wk = w + (((long)g * cin_g + ci) * cout_g + co) * 27 + (8 - tap9);
+      g0 = wk[18], g1 = wk[9], g2 = wk[0];
+    }
     packed[i] = k == 0 ? g0 : (k == 1 ? 0.5f * (g0 + g1 + g2) : (k == 2 ? 0.5f * (g0 - g1 + g2) : g2));
   }
 }
 
 bool wino_ok(const tmdiff_conv3d_desc* d) {
-  if (!d || d->ksize != 3 || (d->groups != 1 && d->groups != 3) || d->in_mask || d->drop_p > 0.f || d->x_bf16 || d->y2_bf16) return false;
+  if (!d || d->ksize != 3 || (d->groups != 1 && d->groups != 3) || d->in_mask || d->x_bf16 || d->y2_bf16) return false;
+  if (!(d->drop_p >= 0.f && d->drop_p < 1.f)) return false;
   if (d->nseg < 1 || d->nseg > 3 || d->Cin <= 0 || d->Cout <= 0 || d->Cin % d->groups || d->Cout % d->groups) return false;
   return (d->Cin / d->groups) % 2 == 0 && (d->Cout / d->groups) % 32 == 0 && d->N > 0 && d->N % 2 == 0 && d->H > 0 && d->W > 0 &&
          d->W % 4 == 0;
@@ -381,7 +399,7 @@ extern "C" size_t tmdiff_conv3d_wino_packed_bytes(int32_t Cout, int32_t Cin, int
 }
 
 extern "C" int tmdiff_conv3d_wino_pack_weights(const float* w, float* packed, int32_t Cout, int32_t Cin, int32_t groups,
-                                               tmdiff_stream_t stream) {
+                                               int32_t mode, tmdiff_stream_t stream) {
   using namespace tmdiff;
   TMDIFF_REQUIRE(w && packed && aligned16(packed), "conv3d_wino_pack_weights: NULL / unaligned pointer");
   TMDIFF_REQUIRE(groups >= 1 && Cout > 0 && Cin > 0 && Cout % groups == 0 && Cin % groups == 0 && (Cout / groups) % 32 == 0,
@@ -389,13 +407,15 @@ extern "C" int tmdiff_conv3d_wino_pack_weights(const float* w, float* packed, in
   const long total = (long)(Cin / groups) * W_TAPS * Cout;
   long blocks = (total + 255) / 256;
   if (blocks > 4096) blocks = 4096;
-  wino_pack_weights_kernel<<<(int)blocks, 256, 0, as_stream(stream)>>>(w, packed, Cout / groups, Cin / groups, total);
+  TMDIFF_REQUIRE(mode == 0 || mode == 1, "conv3d_wino_pack_weights: mode=%d", mode);
+  wino_pack_weights_kernel<<<(int)blocks, 256, 0, as_stream(stream)>>>(w, packed, Cout / groups, Cin / groups, mode, total);
   return check_launch("conv3d_wino_pack_weights");
 }
 
 // stage: 0 = input transform + convolution, 1 = the transform pass alone (fills the workspace), 2 = the convolution alone
 // (the workspace already holds this input's transform: a measurement, or several convolutions of one tensor)
-extern "C" int tmdiff_conv3d_wino_fwd_stage(const tmdiff_conv3d_desc* d, void* workspace, int32_t stage, tmdiff_stream_t stream) {
+extern "C" int tmdiff_conv3d_wino_fwd_xp(const tmdiff_conv3d_desc* d, void* workspace, int32_t stage, float* xp_out,
+                                         tmdiff_stream_t stream) {
   using namespace tmdiff;
   TMDIFF_REQUIRE(d != nullptr, "conv3d_wino_fwd: NULL descriptor");
   if (!wino_ok(d))
@@ -421,6 +441,10 @@ extern "C" int tmdiff_conv3d_wino_fwd_stage(const tmdiff_conv3d_desc* d, void* w
   q.shift_stride = d->in_shift_stride > 0 ? d->in_shift_stride : (d->in_shift_stride < 0 ? 0 : d->Cin);
   q.scale_stride = d->in_scale_stride > 0 ? d->in_scale_stride : (d->in_scale_stride < 0 ? 0 : d->Cin);
   q.v = static_cast<float*>(workspace);
+  q.xp = xp_out;
+  q.drop_seed = d->drop_seed; q.drop_thresh = drop_threshold(d->drop_p);
+  q.drop_inv = d->drop_p > 0.f ? 1.0f / (1.0f - d->drop_p) : 0.f;
+  TMDIFF_REQUIRE(!xp_out || aligned16(xp_out), "conv3d_wino_fwd: xp_out must be 16-byte aligned");
   TMDIFF_REQUIRE(stage >= 0 && stage <= 2, "conv3d_wino_fwd: stage=%d", stage);
   if (stage != 2) {
     long pb = ((long)(d->N / 2) * d->H * d->W / 4 + 255) / 256;
@@ -446,6 +470,10 @@ extern "C" int tmdiff_conv3d_wino_fwd_stage(const tmdiff_conv3d_desc* d, void* w
   return launch<2, 1, 2, 2, 8, 16>(a, st);
 }
 
+extern "C" int tmdiff_conv3d_wino_fwd_stage(const tmdiff_conv3d_desc* d, void* workspace, int32_t stage, tmdiff_stream_t stream) {
+  return tmdiff_conv3d_wino_fwd_xp(d, workspace, stage, nullptr, stream);
+}
+
 extern "C" int tmdiff_conv3d_wino_fwd(const tmdiff_conv3d_desc* d, void* workspace, tmdiff_stream_t stream) {
-  return tmdiff_conv3d_wino_fwd_stage(d, workspace, 0, stream);
+  return tmdiff_conv3d_wino_fwd_xp(d, workspace, 0, nullptr, stream);
 }

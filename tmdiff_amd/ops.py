@@ -315,14 +315,18 @@ def conv3d_prologue(desc, shape):
     return xp
 
 
-def pack_conv_weight_wino(w, groups=1):
-    """[Cout, Cin/groups, 3, 3, 3] -> the transformed, packed weights of the Winograd F(2,3)-along-n convolution (conv3d_wino)."""
+def pack_conv_weight_wino(w, groups=1, mode=0):
+    """[Cout, Cin/groups, 3, 3, 3] -> the transformed, packed weights of the Winograd F(2,3)-along-n convolution (conv3d_wino).
+    mode=1: the weights of the DATA-GRADIENT convolution (Cout -> Cin channels, transposed, taps mirrored) of the forward
+    convolution whose weight w is."""
     cout, cin = w.shape[0], w.shape[1] * groups
+    if mode:
+        cout, cin = cin, cout
     nb = lib.tmdiff_conv3d_wino_packed_bytes(cout, cin, groups)
     if tuple(w.shape[2:]) != (3, 3, 3) or nb == 0:
-        raise ValueError(f"pack_conv_weight_wino: weight shape {tuple(w.shape)} (groups {groups}) not supported")
+        raise ValueError(f"pack_conv_weight_wino: weight shape {tuple(w.shape)} (groups {groups}, mode {mode}) not supported")
     out = torch.empty(nb // 4, device=w.device, dtype=torch.float32)
-    check(lib.tmdiff_conv3d_wino_pack_weights(_chk(w.detach(), "w"), out.data_ptr(), cout, cin, groups, stream_ptr()),
+    check(lib.tmdiff_conv3d_wino_pack_weights(_chk(w.detach(), "w"), out.data_ptr(), cout, cin, groups, mode, stream_ptr()),
           "conv3d_wino_pack_weights")
     return out
 
@@ -336,11 +340,12 @@ def wino_conv_supported(cout, cin, ksize=3, groups=1):
             (cout // groups) % 32 == 0)
 
 
-def conv3d_wino(segs, w_packed, cout, emit=None, keep_y=True, fallback=None, groups=1, **kw):
+def conv3d_wino(segs, w_packed, cout, emit=None, keep_y=True, fallback=None, groups=1, w_packed_fn=None, xp_out=None, **kw):
     """conv3d(segs, ...) (fp32, 3x3x3, groups 1) through the Winograd F(2,3)-along-n kernels (csrc/conv3d_wino.hip): an
     input-transform pass (prologue and concatenation applied there) + a convolution with 1.5x fewer multiply-adds.
     Same keyword arguments and return convention as conv3d; fallback = a callable that runs the direct convolution
-    instead when the shape is not taken or its grid would be too small (the kernel has no split-K)."""
+    instead when the shape is not taken or its grid would be too small (the kernel has no split-K).  drop = (seed, p):
+    in-kernel dropout of the prologue output; xp_out: a [B, Cin, N, H, W] tensor that receives that output (finetune path)."""
     b, _, n, h, w = segs[0].shape
     dev = segs[0].device
     if fallback is not None:         # unsupported extents, or a grid too small for a kernel without split-K (= tmdiff_conv3d_wino_blocks)
@@ -348,6 +353,8 @@ def conv3d_wino(segs, w_packed, cout, emit=None, keep_y=True, fallback=None, gro
         blocks = b * groups * ((n // 2 + 1) // 2) * ((h + 7) // 8) * (((w + 7) // 8) * (cg // 64) if cg % 64 == 0 else ((w + 15) // 16) * (cg // 32))
         if n % 2 or w % 4 or blocks < _WINO_MIN_BLOCKS:
             return fallback()
+    if w_packed is None:             # (packed only once it is known that the kernel will run)
+        w_packed = w_packed_fn()
     y = torch.empty(b, cout, n, h, w, device=dev, dtype=torch.float32) if keep_y else None
     y2 = None
     if emit is not None:
@@ -361,8 +368,11 @@ def conv3d_wino(segs, w_packed, cout, emit=None, keep_y=True, fallback=None, gro
         raise ValueError("conv3d_wino: shape not supported")
     ws = _workspace(dev, lib.tmdiff_conv3d_wino_workspace_bytes(C.byref(d)), "wino").data_ptr()
     ret = y if y2 is None else ((y, y2) if y is not None else y2)
-    if TIMER is None:
-        check(lib.tmdiff_conv3d_wino_fwd(C.byref(d), ws, stream_ptr()), "conv3d_wino_fwd")
+    if xp_out is not None and not (xp_out.is_cuda and xp_out.is_contiguous() and xp_out.numel() == b * d.Cin * n * h * w):
+        raise ValueError("conv3d_wino: xp_out must be a contiguous fp32 [B, Cin, N, H, W] tensor")
+    if TIMER is None or xp_out is not None:
+        check(lib.tmdiff_conv3d_wino_fwd_xp(C.byref(d), ws, 0, xp_out.data_ptr() if xp_out is not None else None, stream_ptr()),
+              "conv3d_wino_fwd")
         return ret
     # timed: the input-transform pass (an HBM pass, recorded under ksize 0 with its bytes) and the convolution kernel apart
     ev = [torch.cuda.Event(enable_timing=True) for _ in range(3)]
