@@ -12,6 +12,7 @@ python3 tools/bench_wgrad.py 8 3 2>&1 | grep -v amdgpu > $O/wgrad_b8.txt
 python3 tools/bench_conv.py 32 3 fp32 2>&1 | grep -v amdgpu > $O/conv_layers_fp32.txt
 python3 tools/bench_conv.py 32 3 bf16 2>&1 | grep -v amdgpu > $O/conv_layers_bf16.txt
 python3 tools/bench_conv_ll.py 32 5 2>&1 | grep -v amdgpu > $O/conv_ll.txt
+python3 tools/bench_conv_wino.py 32 5 2>&1 | grep -v amdgpu > $O/conv_wino.txt
 python3 tools/bench_bf16_dma.py 32 10 2>&1 | grep -v amdgpu > $O/conv_bf16_packed.txt
 # (diagnostic build with s_memtime stamps: tools/build_variant.sh stamps "-DTMDIFF_BF16_STAMPS=1" conv3d_bf16, before the call)
 [ -f tools/lib_stamps.so ] && TMDIFF_HIP_LIB=tools/lib_stamps.so python3 tools/bf16_stamps.py 32 2>&1 | grep -v amdgpu > $O/conv_bf16_stamps.txt
@@ -19,6 +20,7 @@ bash tools/run_pmc.sh ${TAG}_final/pmc_wgrad "bench_wgrad.py 8 1"
 bash tools/run_pmc.sh ${TAG}_final/pmc_attention "bench_attention.py"
 bash tools/run_pmc.sh ${TAG}_final/pmc_conv_fp32 fp32
 bash tools/run_pmc.sh ${TAG}_final/pmc_conv_ll "bench_conv_ll.py 32 1"
+bash tools/run_pmc.sh ${TAG}_final/pmc_conv_wino "bench_conv_wino.py 32 1"
 cd /tmp && export TMPDIR=/tmp
 rocprofv3 --kernel-trace --stats -d $O/prof_train -o p --output-format csv -- python3 $R/bench.py --mode train --steps 6 --warmup 2 > /dev/null 2>&1; echo "train prof rc=$?"
 rocprofv3 --kernel-trace --stats -d $O/prof_bf16 -o p --output-format csv -- python3 $R/tools/prof_bf16_step.py 10 > /dev/null 2>&1; echo "bf16 prof rc=$?"

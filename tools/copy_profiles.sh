@@ -14,3 +14,4 @@ grep "^{" $R/train_2rank_gloo.json > profiles/${TAG}_train_2rank_gloo.json
 cp $R/conv_bf16_packed.txt profiles/${TAG}_conv_bf16_packed.txt; cp $R/conv_bf16_stamps.txt profiles/${TAG}_conv_bf16_stamps.txt
 cp $R/prof_bf16/p_kernel_stats.csv profiles/${TAG}_bf16_step_kernel_stats.csv
 cp $R/conv_ll.txt profiles/${TAG}_conv_ll.txt; cp $R/pmc_conv_ll.txt profiles/${TAG}_conv_ll_pmc.txt
+cp $R/conv_wino.txt profiles/${TAG}_conv_wino.txt; cp $R/pmc_conv_wino.txt profiles/${TAG}_conv_wino_pmc.txt
