@@ -138,7 +138,7 @@ __device__ __forceinline__ unsigned xcd_remap(unsigned bid, unsigned nwg) {
 
 constexpr int W_TAPS = 36;   // (dh, dw) x k
 
-template <int NS, int MSUB, int KC, int TT, int TH, int TW>
+template <int NS, int MSUB, int KC, int TT, int TH, int TW, bool XS>
 struct GeoW {
   static constexpr int CO = 32 * MSUB;
   static constexpr int HH = TH + 2, HW = TW + 2;
@@ -150,14 +150,18 @@ struct GeoW {
   static constexpr int W_UNITS = KC * W_TAPS * CO / 4;      // weight slab [KC][36][CO] in 16-byte units
   static constexpr int WP = (W_UNITS + 63) / 64;
   static constexpr int STAGE = X_FLOATS + WP * 256;
-  static_assert(TT * TH * TW == 4 * NS * 32, "workgroup tile = 4 waves x NS sub-tiles x 32 pair positions");
+  static_assert(TT * TH * TW == (XS ? 2 : 4) * NS * 32, "workgroup tile = 4 (XS: 2) waves x NS sub-tiles x 32 pair positions");
   static_assert(KC % 2 == 0, "K step is 2 channels");
   static_assert((TH * TW) % 32 == 0, "a sub-tile of 32 pair positions lies in one pair");
 };
 
-template <int NS, int MSUB, int KC, int TT, int TH, int TW>
+// XS ("plane split"): waves 0, 1 accumulate the planes k = 0, 1 and waves 2, 3 the planes k = 2, 3 of the SAME 2 x NS x 32
+// pair positions -- twice the register blocking per wave (one weight read and NS input reads feed NS x MSUB MFMAs of one
+// plane: 0.75 LDS reads per MFMA instead of 1) for one exchange of partial sums through LDS at the end of the tile.
+template <int NS, int MSUB, int KC, int TT, int TH, int TW, bool XS>
 __global__ void __launch_bounds__(256, 2) conv3d_wino_kernel(const WinoArgs a) {
-  using G = GeoW<NS, MSUB, KC, TT, TH, TW>;
+  using G = GeoW<NS, MSUB, KC, TT, TH, TW, XS>;
+  constexpr int NX = XS ? 2 : 4;                               // planes per wave
   constexpr int CO = G::CO;
   constexpr int XK = (G::XP + 3) / 4, WK = (G::WP + 3) / 4;  // pieces per wave
   __shared__ __attribute__((aligned(16))) float st0[G::STAGE];
@@ -221,14 +225,16 @@ __global__ void __launch_bounds__(256, 2) conv3d_wino_kernel(const WinoArgs a) {
   __builtin_amdgcn_sched_barrier(0);
 
   // ---- per-lane operand offsets (floats inside a stage) ----------------------------------------------------------
+  const int wpos = XS ? (wv & 1) : wv;                         // which positions of the tile this wave owns
+  const int xi_base = XS ? 2 * (wv >> 1) : 0;                  // ... and which planes (wave-uniform)
   int boff[NS];
 #pragma unroll
   for (int s = 0; s < NS; ++s) {
-    const int p = (wv * NS + s) * 32 + l31;
+    const int p = (wpos * NS + s) * 32 + l31;
     const int pw = p % TW, ph = (p / TW) % TH, pt = p / (TW * TH);
-    boff[s] = (pt * 4 * G::HH + ph) * G::HW + pw + khalf * G::TILE_ELEMS;
+    boff[s] = ((pt * 4 + xi_base) * G::HH + ph) * G::HW + pw + khalf * G::TILE_ELEMS;
   }
-  const int aoff = G::X_FLOATS + khalf * W_TAPS * CO + l31 * MSUB;  // slab rows hold the tile's channels as [l31][m]
+  const int aoff = G::X_FLOATS + khalf * W_TAPS * CO + xi_base * CO + l31 * MSUB;  // slab rows hold the tile's channels as [l31][m]
 
   float bias_v[MSUB], sh2_v[MSUB], sc2_v[MSUB];
 #pragma unroll
@@ -239,26 +245,27 @@ __global__ void __launch_bounds__(256, 2) conv3d_wino_kernel(const WinoArgs a) {
     sc2_v[m] = (a.y2 && a.y2_scale) ? a.y2_scale[(long)b * a.y2_scale_stride + col] : 1.f;
   }
 
-  f32x16 acc[4 * NS][MSUB];     // [k * NS + s][m]
+  f32x16 acc[NX * NS][MSUB];    // [(k - xi_base) * NS + s][m]
 #pragma unroll
-  for (int s = 0; s < 4 * NS; ++s)
+  for (int s = 0; s < NX * NS; ++s)
 #pragma unroll
     for (int m = 0; m < MSUB; ++m)
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[s][m][r] = 0.f;
 
   constexpr int MF = NS * MSUB;
-  constexpr int KSTEPS = (KC / 2) * W_TAPS;
+  constexpr int WT = 9 * NX;                                  // taps of this wave per channel pair
+  constexpr int KSTEPS = (KC / 2) * WT;
   constexpr int PSTRIDE = KSTEPS / NPIECE > 0 ? KSTEPS / NPIECE : 1;
   static_assert(NPIECE <= KSTEPS, "at most one piece per K-step");
   auto mfma_chunk = [&](const float* st, int c_next, float* st_next) __attribute__((always_inline)) {
     float av[2][MSUB], bv[2][NS];
     auto fetch = [&](auto ksc) __attribute__((always_inline)) {
       constexpr int ks = decltype(ksc)::value;
-      constexpr int kp = ks / W_TAPS, tap = ks % W_TAPS;
-      constexpr int xi = tap % 4, dh = (tap / 4) / 3, dw = (tap / 4) % 3;
+      constexpr int kp = ks / WT, tap = ks % WT;
+      constexpr int xi = tap % NX, dh = (tap / NX) / 3, dw = (tap / NX) % 3;
       constexpr int toff = (xi * G::HH + dh) * G::HW + dw;
-      const float* ap = st + aoff + (kp * 2 * W_TAPS + tap) * CO;
+      const float* ap = st + aoff + (kp * 2 * W_TAPS + (tap / NX) * 4 + xi) * CO;
       if constexpr (MSUB == 1) {
         av[ks & 1][0] = ap[0];
       } else {
@@ -271,7 +278,7 @@ __global__ void __launch_bounds__(256, 2) conv3d_wino_kernel(const WinoArgs a) {
     fetch(std::integral_constant<int, 0>{});
     static_for<0, KSTEPS>([&](auto ksc) __attribute__((always_inline)) {
       constexpr int ks = decltype(ksc)::value;
-      constexpr int xi = (ks % W_TAPS) % 4;
+      constexpr int xi = (ks % WT) % NX;
       static_for<0, MF>([&](auto jc) __attribute__((always_inline)) {
         constexpr int j = decltype(jc)::value;
         constexpr int s = j / MSUB, m = j % MSUB;
@@ -301,31 +308,68 @@ __global__ void __launch_bounds__(256, 2) conv3d_wino_kernel(const WinoArgs a) {
     }
   }
 
-  // ---- output transform in registers: bands 2t (m0 + m1 + m2) and 2t + 1 (m1 - m2 - m3) of every sub-tile ---------
-  f32x16 out[2 * NS][MSUB];      // [s * 2 + j][m]
-  int sub_base[2 * NS];          // linear position (over the 2 TT x TH x TW output tile) of the sub-tile's first position
-#pragma unroll
-  for (int s = 0; s < NS; ++s) {
-    const int pb = (wv * NS + s) * 32;
-    const int pt = pb / (TW * TH), rem = pb % (TW * TH);
-#pragma unroll
-    for (int j = 0; j < 2; ++j) sub_base[s * 2 + j] = (2 * pt + j) * (TW * TH) + rem;
-#pragma unroll
-    for (int m = 0; m < MSUB; ++m)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const float m0 = acc[0 * NS + s][m][r], m1 = acc[1 * NS + s][m][r], m2 = acc[2 * NS + s][m][r], m3 = acc[3 * NS + s][m][r];
-        out[s * 2][m][r] = m0 + m1 + m2;
-        out[s * 2 + 1][m][r] = m1 - m2 - m3;
-      }
-  }
-  // (the chunk loop ends with a barrier: nobody reads the stages any more)
   static_assert(sizeof(st0) >= 4 * 4096, "the epilogue borrows 4 KB of LDS per wave");
-  tmdiff::epilogue_vec<2 * NS, MSUB, 2 * TT, TH, TW>(a, out, bias_v, sh2_v, sc2_v, b, g, co0, 2 * t0, h0, w0, wv, lane, plane,
-                                                     st0 + wv * 1024, sub_base);
+  if constexpr (!XS) {
+    // ---- output transform in registers: bands 2t (m0 + m1 + m2) and 2t + 1 (m1 - m2 - m3) of every sub-tile -------
+    f32x16 out[2 * NS][MSUB];      // [s * 2 + j][m]
+    int sub_base[2 * NS];          // linear position (over the 2 TT x TH x TW output tile) of the sub-tile's first position
+#pragma unroll
+    for (int s = 0; s < NS; ++s) {
+      const int pb = (wv * NS + s) * 32;
+      const int pt = pb / (TW * TH), rem = pb % (TW * TH);
+#pragma unroll
+      for (int j = 0; j < 2; ++j) sub_base[s * 2 + j] = (2 * pt + j) * (TW * TH) + rem;
+#pragma unroll
+      for (int m = 0; m < MSUB; ++m)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const float m0 = acc[0 * NS + s][m][r], m1 = acc[1 * NS + s][m][r], m2 = acc[2 * NS + s][m][r], m3 = acc[3 * NS + s][m][r];
+          out[s * 2][m][r] = m0 + m1 + m2;
+          out[s * 2 + 1][m][r] = m1 - m2 - m3;
+        }
+    }
+    // (the chunk loop ends with a barrier: nobody reads the stages any more)
+    tmdiff::epilogue_vec<2 * NS, MSUB, 2 * TT, TH, TW>(a, out, bias_v, sh2_v, sc2_v, b, g, co0, 2 * t0, h0, w0, wv, lane, plane,
+                                                       st0 + wv * 1024, sub_base);
+  } else {
+    // ---- plane split: waves 0, 1 hold (m0, m1), waves 2, 3 hold (m2, m3) of the same positions.  y(2t) = (m0 + m1) + m2 is
+    // finished by the first pair of waves, y(2t+1) = m1 + (-m2 - m3) by the second: each wave hands ONE plane to its partner
+    // (wave ^ 2), one accumulator (1024 floats) per round through alternating stages, one barrier per round.
+    const int grp = wv >> 1;
+    f32x16 out[NS][MSUB];
+    int sub_base[NS];
+#pragma unroll
+    for (int s = 0; s < NS; ++s) {
+      const int pb = (wpos * NS + s) * 32;
+      const int pt = pb / (TW * TH), rem = pb % (TW * TH);
+      sub_base[s] = (2 * pt + grp) * (TW * TH) + rem;
+    }
+    int round = 0;
+#pragma unroll
+    for (int s = 0; s < NS; ++s)
+#pragma unroll
+      for (int m = 0; m < MSUB; ++m) {
+        float* buf = (round & 1) ? st1 : st0;
+        // send: the first pair sends m1 (its plane 1), the second pair sends m2 (its plane 0)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) buf[(wv * 16 + r) * 64 + lane] = grp ? acc[0 * NS + s][m][r] : acc[1 * NS + s][m][r];
+        __syncthreads();
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const float got = buf[((wv ^ 2) * 16 + r) * 64 + lane];
+          const float keep = grp ? -acc[0 * NS + s][m][r] - acc[1 * NS + s][m][r]      // -m2 - m3
+                                 : acc[0 * NS + s][m][r] + acc[1 * NS + s][m][r];      //  m0 + m1
+          out[s][m][r] = grp ? got + keep : keep + got;      // y(2t+1) = m1 + (-m2 - m3);  y(2t) = (m0 + m1) + m2
+        }
+        ++round;
+      }
+    __syncthreads();   // (the last round's reads are done before the epilogue reuses the stages)
+    tmdiff::epilogue_vec<NS, MSUB, 2 * TT, TH, TW>(a, out, bias_v, sh2_v, sc2_v, b, g, co0, 2 * t0, h0, w0, wv, lane, plane,
+                                                   st0 + wv * 1024, sub_base);
+  }
 }
 
-template <int NS, int MSUB, int KC, int TT, int TH, int TW>
+template <int NS, int MSUB, int KC, int TT, int TH, int TW, bool XS>
 int launch(WinoArgs& a, hipStream_t st) {
   constexpr int CO = 32 * MSUB;
   a.tiles_t = (a.N / 2 + TT - 1) / TT;
@@ -335,7 +379,7 @@ int launch(WinoArgs& a, hipStream_t st) {
   const long blocks = (long)a.B * a.groups * a.tiles_t * a.tiles_h * a.tiles_w * a.tiles_co;
   if (blocks <= 0 || blocks > 0x7fffffffL) return tmdiff::fail(TMDIFF_E_INVALID, "conv3d_wino_fwd: grid of %ld blocks", blocks);
   a.total_blocks = (unsigned)blocks;
-  conv3d_wino_kernel<NS, MSUB, KC, TT, TH, TW><<<(unsigned)blocks, 256, 0, st>>>(a);
+  conv3d_wino_kernel<NS, MSUB, KC, TT, TH, TW, XS><<<(unsigned)blocks, 256, 0, st>>>(a);
   return tmdiff::check_launch("conv3d_wino_fwd");
 }
 
@@ -466,8 +510,16 @@ extern "C" int tmdiff_conv3d_wino_fwd_xp(const tmdiff_conv3d_desc* d, void* work
   a.vec4 = 1;
   if (!(d->W % 4 == 0 && aligned16(d->y) && aligned16(d->y2) && aligned16(d->residual)))
     return fail(TMDIFF_E_UNSUPPORTED, "conv3d_wino_fwd: W %% 4 == 0 and 16-byte aligned outputs / residual");
-  if (a.cout_g % 64 == 0) return launch<1, 2, 2, 2, 8, 8>(a, st);
-  return launch<2, 1, 2, 2, 8, 16>(a, st);
+  static const bool xs = [] {
+    const char* e = getenv("TMDIFF_WINO_XSPLIT");      // experiments: "0" = every wave accumulates all four planes
+    return !(e && e[0] == '0');
+  }();
+  if (xs) {
+    if (a.cout_g % 64 == 0) return launch<2, 2, 2, 2, 8, 8, true>(a, st);
+    return launch<4, 1, 2, 2, 8, 16, true>(a, st);
+  }
+  if (a.cout_g % 64 == 0) return launch<1, 2, 2, 2, 8, 8, false>(a, st);
+  return launch<2, 1, 2, 2, 8, 16, false>(a, st);
 }
 
 extern "C" int tmdiff_conv3d_wino_fwd_stage(const tmdiff_conv3d_desc* d, void* workspace, int32_t stage, tmdiff_stream_t stream) {
