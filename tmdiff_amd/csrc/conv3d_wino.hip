@@ -8,8 +8,8 @@
 // the pair costs 4 x 9 = 36 multiply-adds per (ci, co) instead of 2 x 27 = 54: 1.5x fewer FLOPs on the matrix pipe.
 // fp32 error: a few 1e-7 relative (sums of three inputs / weights before the product, three products per output).
 //
-// Pieces: wino_input_kernel writes V[b][c][t][k][h][w] (prologue applied first, segments concatenated; 2x the bytes of
-// x, an HBM pass), tmdiff_conv3d_wino_pack_weights writes U as [ci][dh*3+dw][k][co], and conv3d_wino_kernel is the
+// Pieces: wino_input_kernel writes V[b][c][t][k][h+1][w+1] with a zero border (prologue applied first, segments concatenated;
+// 2x the bytes of x, an HBM pass), tmdiff_conv3d_wino_pack_weights writes U as [ci][dh*3+dw][k][co], and conv3d_wino_kernel is the
 // staged kernel (conv3d_dma.hip) over "taps" (dh, dw, k): the LDS box of an output tile holds, per channel, the TT x 4
 // planes (t, k) of its pairs with a one-pixel halo in (h, w); tap (dh, dw, k) multiplies plane k shifted by (dh, dw) into
 // accumulator k; the epilogue forms the two output bands in registers and hands them to the shared vector epilogue.
@@ -64,7 +64,11 @@ struct WinoInArgs {
   float drop_inv;
 };
 
-// one thread: one (b, c, t, h, w4) -- the four input bands of pair t (prologue applied), the four transformed planes out
+// V is stored with a zero border: plane (t, k) is (H + 2) x (W + 4) floats, element (h, w) at row h + 1, column w + 1, so that
+// the haloed box of a tile (rows h0 - 1 .., columns w0 - 1 ..; w0 a multiple of 8) starts on a 16-byte boundary and travels
+// to LDS in 16-byte pieces without bounds checks (a dword piece per 64 floats cost the kernel its matrix-pipe time).
+// one thread: one (b, c, t, h, quad j) -- source columns 4j-1 .. 4j+3 of the four input bands of pair t (prologue applied),
+// written as the padded quad 4j .. 4j+3 of the four transformed planes (+ the trailing quad of a row, + the border rows)
 __global__ void __launch_bounds__(256) wino_input_kernel(const WinoInArgs a) {
   const int bc = blockIdx.y, b = bc / a.Cin, c = bc % a.Cin;
   int cs = c, seg = 0;
@@ -79,42 +83,70 @@ __global__ void __launch_bounds__(256) wino_input_kernel(const WinoInArgs a) {
   const bool plain = !a.in_shift && !a.in_scale && !a.in_act && !drop;
   const uint64_t ebase = (uint64_t)bc * (uint64_t)(a.N * hw);
   float* xpp = a.xp ? a.xp + (long)bc * a.N * hw : nullptr;
-  const int T = a.N / 2;
-  float* vp = a.v + (long)bc * T * 4 * hw;
-  const long quads = hw / 4;                         // (H * W % 4 == 0: checked by the entry point)
+  const int T = a.N / 2, WP = a.W + 4, qrow = a.W / 4;
+  const long pplane = (long)(a.H + 2) * WP;                    // one padded plane
+  float* vp = a.v + (long)bc * T * 4 * pplane;
+  const long quads = hw / 4;
   for (long i = blockIdx.x * 256L + threadIdx.x; i < T * quads; i += 256L * gridDim.x) {
     const int t = (int)(i / quads);
-    const long q = (i % quads) * 4;
-    float d[4][4];
+    const long q = (i % quads) * 4;                            // offset of the source quad inside a band plane
+    const int h = (int)(q / a.W), j = (int)((q % a.W) / 4);
+    float d[4][5];                                             // [band][source column 4j-1 .. 4j+3]
+    auto prologue = [&](float x, long idx) __attribute__((always_inline)) {
+      float u = x + sh;
+      const float ua = tmdiff::silu_f(u);
+      u = (a.in_act ? ua : u) * sc;
+      if (drop) u *= tmdiff::drop_keep(a.drop_seed, ebase + (uint64_t)idx, a.drop_thresh, a.drop_inv);
+      return u;
+    };
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
       const int n = 2 * t - 1 + k;
       if (n >= 0 && n < a.N) {
         const float4 x4 = *reinterpret_cast<const float4*>(xs + n * hw + q);
-        d[k][0] = x4.x, d[k][1] = x4.y, d[k][2] = x4.z, d[k][3] = x4.w;
+        d[k][1] = x4.x, d[k][2] = x4.y, d[k][3] = x4.z, d[k][4] = x4.w;
         if (!plain) {
 #pragma unroll
-          for (int e = 0; e < 4; ++e) {
-            float u = d[k][e] + sh;
-            const float ua = tmdiff::silu_f(u);
-            u = (a.in_act ? ua : u) * sc;
-            if (drop) u *= tmdiff::drop_keep(a.drop_seed, ebase + (uint64_t)(n * hw + q + e), a.drop_thresh, a.drop_inv);
-            d[k][e] = u;
-          }
+          for (int e = 1; e < 5; ++e) d[k][e] = prologue(d[k][e], n * hw + q + e - 1);
         }
         if (xpp && (k == 1 || k == 2))      // bands 2t and 2t+1: every element of x' exactly once
-          *reinterpret_cast<float4*>(xpp + n * hw + q) = make_float4(d[k][0], d[k][1], d[k][2], d[k][3]);
+          *reinterpret_cast<float4*>(xpp + n * hw + q) = make_float4(d[k][1], d[k][2], d[k][3], d[k][4]);
       } else {
-        d[k][0] = d[k][1] = d[k][2] = d[k][3] = 0.f;   // zero padding of the convolution
+#pragma unroll
+        for (int e = 1; e < 5; ++e) d[k][e] = 0.f;             // zero padding of the convolution along the bands
+      }
+      // source column 4j - 1: the last value of the previous quad = the previous lane's (consecutive lanes hold consecutive
+      // quads of the same band; the first lane of a wave fetches it itself, the first quad of a row has the zero border)
+      float prev = __shfl_up(d[k][4], 1);
+      if ((threadIdx.x & 63) == 0 && j > 0 && n >= 0 && n < a.N) {
+        const float x = xs[n * hw + q - 1];
+        prev = plain ? x : prologue(x, n * hw + q - 1);
+      }
+      d[k][0] = j > 0 ? prev : 0.f;
+    }
+    float o[4][5];
+#pragma unroll
+    for (int e = 0; e < 5; ++e) {
+      o[0][e] = d[0][e] - d[2][e];
+      o[1][e] = d[1][e] + d[2][e];
+      o[2][e] = d[2][e] - d[1][e];
+      o[3][e] = d[1][e] - d[3][e];
+    }
+    const float4 z4 = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      float* row = vp + ((long)t * 4 + k) * pplane + (long)(h + 1) * WP;
+      *reinterpret_cast<float4*>(row + 4 * j) = make_float4(o[k][0], o[k][1], o[k][2], o[k][3]);
+      if (j == qrow - 1) *reinterpret_cast<float4*>(row + a.W) = make_float4(o[k][4], 0.f, 0.f, 0.f);
+      if (h == 0) {                                            // border rows
+        *reinterpret_cast<float4*>(row - WP + 4 * j) = z4;
+        if (j == qrow - 1) *reinterpret_cast<float4*>(row - WP + a.W) = z4;
+      }
+      if (h == a.H - 1) {
+        *reinterpret_cast<float4*>(row + WP + 4 * j) = z4;
+        if (j == qrow - 1) *reinterpret_cast<float4*>(row + WP + a.W) = z4;
       }
     }
-    float4 o[4];
-    o[0] = make_float4(d[0][0] - d[2][0], d[0][1] - d[2][1], d[0][2] - d[2][2], d[0][3] - d[2][3]);
-    o[1] = make_float4(d[1][0] + d[2][0], d[1][1] + d[2][1], d[1][2] + d[2][2], d[1][3] + d[2][3]);
-    o[2] = make_float4(d[2][0] - d[1][0], d[2][1] - d[1][1], d[2][2] - d[1][2], d[2][3] - d[1][3]);
-    o[3] = make_float4(d[1][0] - d[3][0], d[1][1] - d[3][1], d[1][2] - d[3][2], d[1][3] - d[3][3]);
-#pragma unroll
-    for (int k = 0; k < 4; ++k) *reinterpret_cast<float4*>(vp + ((long)t * 4 + k) * hw + q) = o[k];
   }
 }
 
@@ -141,12 +173,12 @@ constexpr int W_TAPS = 36;   // (dh, dw) x k
 template <int NS, int MSUB, int KC, int TT, int TH, int TW, bool XS>
 struct GeoW {
   static constexpr int CO = 32 * MSUB;
-  static constexpr int HH = TH + 2, HW = TW + 2;
+  static constexpr int HH = TH + 2, HW = TW + 4;            // rows of TW + 2 haloed columns, fetched as (TW + 4) / 4 quads
   static constexpr int PLANE = HH * HW;
   static constexpr int TILE_ELEMS = TT * 4 * PLANE;         // [TT pairs][4 planes][HH][HW] of one channel
   static constexpr int LDS_IN = KC * TILE_ELEMS;
-  static constexpr int XP = (LDS_IN + 63) / 64;             // dword pieces (64 floats each)
-  static constexpr int X_FLOATS = XP * 64;
+  static constexpr int XP = (LDS_IN / 4 + 63) / 64;         // 16-byte pieces (64 quads each)
+  static constexpr int X_FLOATS = XP * 256;
   static constexpr int W_UNITS = KC * W_TAPS * CO / 4;      // weight slab [KC][36][CO] in 16-byte units
   static constexpr int WP = (W_UNITS + 63) / 64;
   static constexpr int STAGE = X_FLOATS + WP * 256;
@@ -182,20 +214,21 @@ __global__ void __launch_bounds__(256, 2) conv3d_wino_kernel(const WinoArgs a) {
   const int co0 = co_tile * CO;
   const int T = a.N / 2;
   const long plane = (long)a.N * a.H * a.W;                    // output plane
-  const int plane_v = T * 4 * a.H * a.W;                       // one channel of V
+  const int plane_v = T * 4 * (a.H + 2) * (a.W + 4);           // one channel of V (planes with their zero border)
   const int nchunks = a.cin_g / KC;
 
   // ---- DMA sources of this lane (the same for every chunk) -----------------------------------------------------
-  int xsrc[XK];  // float offset from the chunk base, or -1 = zero word
+  int xsrc[XK];  // float offset (of a quad) from the chunk base, or -1 = zero quad
+  const int WP = a.W + 4, HP = a.H + 2;
 #pragma unroll
   for (int k = 0; k < XK; ++k) {
-    const int f = (wv + 4 * k) * 64 + lane;
+    const int f = ((wv + 4 * k) * 64 + lane) * 4;              // first float of this lane's quad inside the stage
     const int kc = f / G::TILE_ELEMS, e = f % G::TILE_ELEMS;
     const int tz = e / (4 * G::PLANE), xi = (e / G::PLANE) % 4, r = e % G::PLANE;
-    const int hz = r / G::HW, wz = r % G::HW;
-    const int t = t0 + tz, h = h0 + hz - 1, w = w0 + wz - 1;
-    const bool ok = f < G::LDS_IN && t < T && h >= 0 && h < a.H && w >= 0 && w < a.W;
-    xsrc[k] = ok ? kc * plane_v + ((t * 4 + xi) * a.H + h) * a.W + w : -1;
+    const int hz = r / G::HW, wq = r % G::HW;                  // (wq a multiple of 4)
+    const int t = t0 + tz, hp = h0 + hz, wp = w0 + wq;         // padded coordinates: row h + 1 = h0 - 1 + hz + 1, column w0 - 1 + wq + 1
+    const bool ok = f < G::LDS_IN && t < T && hp < HP && wp < WP;
+    xsrc[k] = ok ? kc * plane_v + ((t * 4 + xi) * HP + hp) * WP + wp : -1;
   }
   int wsrc[WK];  // float offset inside the chunk's rows, or -1
 #pragma unroll
@@ -213,7 +246,7 @@ __global__ void __launch_bounds__(256, 2) conv3d_wino_kernel(const WinoArgs a) {
     if constexpr (i < XK) {
       constexpr int k = i;
       const int q = wv + 4 * k;
-      if (G::XP % 4 == 0 || q < G::XP) dma_b32(xsrc[k] >= 0 ? xg + (long)c * KC * plane_v + xsrc[k] : zero, st + q * 64);
+      if (G::XP % 4 == 0 || q < G::XP) dma_b128(xsrc[k] >= 0 ? xg + (long)c * KC * plane_v + xsrc[k] : zero, st + q * 256);
     } else if constexpr (i < NPIECE) {
       constexpr int k = i - XK;
       const int q = wv + 4 * k;
@@ -434,7 +467,7 @@ extern "C" int64_t tmdiff_conv3d_wino_blocks(const tmdiff_conv3d_desc* d) {
 
 extern "C" size_t tmdiff_conv3d_wino_workspace_bytes(const tmdiff_conv3d_desc* d) {
   if (!wino_ok(d) || d->B <= 0) return 0;
-  return (size_t)d->B * d->Cin * (d->N / 2) * 4 * d->H * d->W * sizeof(float);
+  return (size_t)d->B * d->Cin * (d->N / 2) * 4 * (d->H + 2) * (d->W + 4) * sizeof(float);
 }
 
 extern "C" size_t tmdiff_conv3d_wino_packed_bytes(int32_t Cout, int32_t Cin, int32_t groups) {
@@ -468,7 +501,7 @@ extern "C" int tmdiff_conv3d_wino_fwd_xp(const tmdiff_conv3d_desc* d, void* work
   if (d->B == 0) return TMDIFF_OK;
   TMDIFF_REQUIRE(workspace && aligned16(workspace), "conv3d_wino_fwd: needs its workspace (tmdiff_conv3d_wino_workspace_bytes)");
   TMDIFF_REQUIRE(d->w_packed && (d->y || d->y2) && aligned16(d->w_packed), "conv3d_wino_fwd: NULL / unaligned weights or output");
-  TMDIFF_REQUIRE((long)d->Cin * (d->N / 2) * 4 * d->H * d->W < (1L << 31) / 2, "conv3d_wino_fwd: input too large for 32-bit offsets");
+  TMDIFF_REQUIRE((long)d->Cin * (d->N / 2) * 4 * (d->H + 2) * (d->W + 4) < (1L << 31) / 2, "conv3d_wino_fwd: input too large for 32-bit offsets");
   TMDIFF_REQUIRE((long)d->B * d->Cin <= 65535, "conv3d_wino_fwd: B*Cin = %ld exceeds the grid", (long)d->B * d->Cin);
   int csum = 0;
   for (int i = 0; i < d->nseg; ++i) {
