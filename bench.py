@@ -429,11 +429,11 @@ def main():
         achieved = fl3 / (ms3 * 1e-3) / 1e12 if ms3 > 0 else 0.0
         # FLOPs in the reference's operator order: a conv3d_ll_fwd launch (Conv_0 + halved LL band of a main-branch down
         # block as one strided convolution, csrc/conv3d_ll.hip) executes 48 of the 4 x 27 multiply-adds per output
-        # ... and a conv3d_wino_fwd launch (Winograd F(2,3) along the band axis, csrc/conv3d_wino.hip; its input-transform
-        # pass is inside the timed launch) 36 of the 2 x 27 per output pair
-        fl3_ref = fl3 + sum(fl * ((108.0 / 48.0 if what == "conv3d_ll_fwd" else 1.5) - 1.0)
-                            for (k, what), (n, ms, fl) in conv_by_entry.items()
-                            if k == 3 and what in ("conv3d_ll_fwd", "conv3d_wino_fwd"))
+        # ... and a conv3d_wino{4,2}_fwd launch (Winograd F(4,3) / F(2,3) along the band axis, csrc/conv3d_wino.hip; its
+        # input-transform pass is timed apart) 54 of the 4 x 27 per four output bands / 36 of the 2 x 27 per pair
+        ref_factor = {"conv3d_ll_fwd": 108.0 / 48.0, "conv3d_wino2_fwd": 1.5, "conv3d_wino4_fwd": 2.0}   # F(2,3) / F(4,3)
+        fl3_ref = fl3 + sum(fl * (ref_factor[what] - 1.0) for (k, what), (n, ms, fl) in conv_by_entry.items()
+                            if k == 3 and what in ref_factor)
         traffic, traffic_src = load_traffic()
         line = {
             "metric": "UNet denoise-steps/sec (8-ch 64x64, batch 32)",
@@ -454,7 +454,7 @@ def main():
                          "frac": round(achieved / PEAK_FP32_MFMA, 4), "traffic": traffic, "traffic_source": traffic_src,
                          "kernel": "3x3x3 conv launches, fp32 v_mfma_f32_32x32x2_f32: conv3d_mfma_kernel<3,..> (fused prologue), "
                                    "prologue_apply_kernel + conv3d_dma_kernel<3,..> (staged), wino_input_kernel + conv3d_wino_kernel "
-                                   "(Winograd F(2,3) along the band axis: 1.5x fewer multiply-adds) or conv3d_ll_kernel (Conv_0 + LL "
+                                   "(Winograd F(4,3) / F(2,3) along the band axis: 2x / 1.5x fewer multiply-adds) or conv3d_ll_kernel (Conv_0 + LL "
                                    "band of the main branch's down blocks as one strided convolution), chosen per layer",
                          "flops_counted": "EXECUTED on the matrix pipe (what the roofline bounds); in the reference's operator "
                                           "order the same launches are worth `reference_order_tflops`",

@@ -163,26 +163,34 @@ int tmdiff_conv3d_ll_pack_weights(const float* w, float* packed, int32_t Cout, i
                                   tmdiff_stream_t stream);
 int tmdiff_conv3d_ll_fwd(const tmdiff_conv3d_desc* d, float ll_scale, tmdiff_stream_t stream);
 
-/* ---- 3x3x3 convolution, Winograd F(2,3) along the band axis (exact-fp32 matrix cores, 1.5x fewer multiply-adds) ---
+/* ---- 3x3x3 convolution, Winograd F(4,3) / F(2,3) along the band axis (exact-fp32 matrix cores) --------------------
+ * 2x (N % 4 == 0: six transformed planes per four bands) or 1.5x (N % 2 == 0: four planes per two bands) fewer multiply-adds.
  * Same descriptor and epilogue as tmdiff_conv3d_fwd (fp32, groups 1 or 3, N even, W % 4 == 0, Cin/groups % 2 == 0,
- * Cout/groups % 32 == 0, no mask tensor (d->drop_p in-kernel dropout is taken); segments and the shift / scale / act prologue are taken).  `workspace` receives the transformed input
- * (tmdiff_conv3d_wino_workspace_bytes(d) = 2x the input bytes); d->w_packed comes from tmdiff_conv3d_wino_pack_weights
- * (tmdiff_conv3d_wino_packed_bytes bytes).  Results agree with tmdiff_conv3d_fwd to a few 1e-7 relative. */
+ * Cout/groups % 32 == 0, no mask tensor (d->drop_p in-kernel dropout is taken); segments and the shift / scale / act
+ * prologue are taken).  `workspace` receives the transformed input (tmdiff_conv3d_wino_workspace_bytes(d) = 1.5-2x the
+ * input bytes plus a border); d->w_packed comes from tmdiff_conv3d_wino_pack_weights with planes =
+ * tmdiff_conv3d_wino_planes(N) (tmdiff_conv3d_wino_packed_bytes bytes).  Results agree with tmdiff_conv3d_fwd to 1e-6
+ * relative L2 (F(4,3)) / 4e-7 (F(2,3)). */
 int tmdiff_conv3d_wino_supported(const tmdiff_conv3d_desc* d);
+int32_t tmdiff_conv3d_wino_planes(int32_t N);                     /* 6, 4, or 0 (odd N) */
 int64_t tmdiff_conv3d_wino_blocks(const tmdiff_conv3d_desc* d);   /* workgroups of its grid (no split-K: keep small grids on tmdiff_conv3d_fwd) */
 size_t tmdiff_conv3d_wino_workspace_bytes(const tmdiff_conv3d_desc* d);
-size_t tmdiff_conv3d_wino_packed_bytes(int32_t Cout, int32_t Cin, int32_t groups);
+size_t tmdiff_conv3d_wino_packed_bytes(int32_t Cout, int32_t Cin, int32_t groups, int32_t planes);
 /* mode 0: w = [Cout, Cin/groups, 3,3,3] of this convolution; mode 1 (data gradient): w is the FORWARD convolution's weight
  * [Cin, Cout/groups, 3,3,3] and this convolution (Cin -> Cout) is its transpose with mirrored taps, as
  * tmdiff_conv3d_pack_weights(mode 1) */
 int tmdiff_conv3d_wino_pack_weights(const float* w, float* packed, int32_t Cout, int32_t Cin, int32_t groups,
-                                    int32_t mode, tmdiff_stream_t stream);
+                                    int32_t mode, int32_t planes, tmdiff_stream_t stream);
 int tmdiff_conv3d_wino_fwd(const tmdiff_conv3d_desc* d, void* workspace, tmdiff_stream_t stream);
 /* stage 1: the input-transform pass alone; stage 2: the convolution alone on a workspace that holds it; 0: both */
 int tmdiff_conv3d_wino_fwd_stage(const tmdiff_conv3d_desc* d, void* workspace, int32_t stage, tmdiff_stream_t stream);
 /* ... and with the prologue output x' [B, Cin, N, H, W] (in-kernel dropout d->drop_p included) also written to xp_out by the
  * transform pass: the finetune path keeps it for the weight gradient */
 int tmdiff_conv3d_wino_fwd_xp(const tmdiff_conv3d_desc* d, void* workspace, int32_t stage, float* xp_out, tmdiff_stream_t stream);
+/* ... and with the transform chosen by the caller (planes 6 or 4 = what the weights were packed for; 0 = automatic): F(2,3)
+ * has twice the tiles along the bands, so it still fills the chip where F(4,3) would not */
+int tmdiff_conv3d_wino_fwd_planes(const tmdiff_conv3d_desc* d, void* workspace, int32_t stage, float* xp_out, int32_t planes,
+                                  tmdiff_stream_t stream);
 
 /* ---- bf16 compute / fp32 accumulate (WorldView-3 inference) --------------------------
  * Same descriptor and fused prologue / epilogue as tmdiff_conv3d_fwd; activations, bias, residual and output stay

@@ -605,8 +605,8 @@ def test_conv3d_ll_is_conv_then_halved_ll_band(ops, case):
     (2, (4, 4, 4), 192, 4, 8, 8, 3),      # groups = 3 (convH_0): one segment per group, 64 output channels each
 ])
 def test_conv3d_winograd_along_bands(ops, case):
-    """tmdiff_conv3d_wino_fwd: F(2,3) along the band axis (input transform pass with the prologue + 36-tap kernel + output
-    transform in the epilogue) against the CPU convolution (fp64) and the direct HIP kernel; prologue, bias, residual,
+    """tmdiff_conv3d_wino_fwd: Winograd F(4,3) (N % 4 == 0) / F(2,3) along the band axis (input transform pass with the
+    prologue + 54- / 36-tap kernel + output transform at the end of the tile) against the CPU convolution (fp64) and the direct HIP kernel; prologue, bias, residual,
     scale and second output included."""
     B, segc, cout, N, H, W, groups = case
     cin = sum(segc)
@@ -617,7 +617,7 @@ def test_conv3d_winograd_along_bands(ops, case):
     sh, sc = torch.randn(B, cin) * 0.3, torch.rand(B, cin) + 0.5
     res = torch.randn(B, cout, N, H, W)
     sh2, sc2 = torch.randn(B, cout) * 0.3, torch.rand(B, cout) + 0.5
-    wp = ops.pack_conv_weight_wino(cu(w), groups=groups)
+    wp = ops.pack_conv_weight_wino(cu(w), groups=groups, planes=ops.wino_planes(N))     # F(4,3) for N % 4 == 0, else F(2,3)
     want = F.conv3d(x.double(), w.double(), bias.double(), padding=1, groups=groups).float()
     y = ops.conv3d_wino([cu(s_) for s_ in segs], wp, cout, bias=cu(bias), groups=groups)
     assert_close(y, want, 2e-5, 2e-6, "winograd, plain input")

@@ -359,7 +359,7 @@ class WavBEST(nn.Module):
                     # exact-fp32 mode: the 3x3x3 convolutions also in the Winograd F(2,3)-along-n form (csrc/conv3d_wino.hip:
                     # 1.5x fewer multiply-adds; taken when the band count is even and the grid fills the chip)
                     if _WINOGRAD and ops.wino_conv_supported(m.out_channels, m.in_channels, m.kernel_size[0], m.groups):
-                        prep["w_wino"][name] = ops.pack_conv_weight_wino(w, groups=m.groups)
+                        prep["w_wino"][name] = {}      # packed on first use, per plane count of the transform (the band count decides)
         # Conv_0 of the main branch's down blocks is followed by an LL-only DWT (its high bands are dropped): the pair runs
         # as one strided convolution on composed weights (csrc/conv3d_ll.hip), exact-fp32 mode only
         if self.compute_dtype == "fp32" and _LL_COMPOSE:
@@ -394,7 +394,12 @@ class WavBEST(nn.Module):
         ww = P["w_wino"].get(name)
         if ww is None or kw.get("x_bf16_shape") is not None:
             return direct()
-        return ops.conv3d_wino(segs, ww, m.out_channels, bias=bias, bias_scale=bias_scale, fallback=direct, groups=m.groups, **kw)
+        def packed(planes):
+            if planes not in ww:
+                ww[planes] = ops.pack_conv_weight_wino(m.weight.detach().float().contiguous(), groups=m.groups, planes=planes)
+            return ww[planes]
+        return ops.conv3d_wino(segs, None, m.out_channels, bias=bias, bias_scale=bias_scale, fallback=direct, groups=m.groups,
+                               w_packed_fn=packed, **kw)
 
     @staticmethod
     def _shift(P, S, name):

@@ -62,7 +62,7 @@ class _FusedConv3d(torch.autograd.Function):
         if _WINOGRAD and mask is None and ops.wino_conv_supported(cout, cin, ksize, groups):
             y = ops.conv3d_wino(segs, None, cout, bias=bias, bias_scale=bias_scale, in_shift=shift, in_scale=scale,
                                 in_act=act, drop=drop, residual=residual, out_scale=out_scale, groups=groups, fallback=direct,
-                                xp_out=xp, w_packed_fn=lambda: ops.pack_conv_weight_wino(w, groups))
+                                xp_out=xp, w_packed_fn=lambda planes: ops.pack_conv_weight_wino(w, groups, planes=planes))
         else:
             y = direct()
         ctx.meta = meta
@@ -116,7 +116,7 @@ class _FusedConv3d(torch.autograd.Function):
             direct = lambda: ops.conv3d([g], wp_t, cin, ksize, groups=groups)
             if _WINOGRAD and ops.wino_conv_supported(cin, cout, ksize, groups):   # the data gradient is a 3x3x3 convolution too
                 gp = ops.conv3d_wino([g], None, cin, groups=groups, fallback=direct,
-                                     w_packed_fn=lambda: ops.pack_conv_weight_wino(w, groups, mode=1))
+                                     w_packed_fn=lambda planes: ops.pack_conv_weight_wino(w, groups, mode=1, planes=planes))
             else:
                 gp = direct()                                                    # dL/dx'
             outs = [torch.empty_like(s) if need[7 + i] else None for i, s in enumerate(segs)]

@@ -1,18 +1,23 @@
-// 3x3x3 convolution with Winograd F(2,3) along the band axis n, on the exact-fp32 matrix cores.
+// 3x3x3 convolution with Winograd F(m,3) along the band axis n (m = 4 or 2), on the exact-fp32 matrix cores.
 //
-// A pair of output bands (2t, 2t+1) of one (h, w) column needs the four input bands 2t-1 .. 2t+2.  With
-//     v0 = d0 - d2,  v1 = d1 + d2,  v2 = d2 - d1,  v3 = d1 - d3              (input transform, per element)
-//     u0 = g0,  u1 = (g0 + g1 + g2) / 2,  u2 = (g0 - g1 + g2) / 2,  u3 = g2   (weight transform along the n taps)
-//     m_k = sum over (ci, dh, dw) of u_k * v_k                                (four 3x3 convolutions in (h, w))
-//     y(2t) = m0 + m1 + m2,   y(2t+1) = m1 - m2 - m3
-// the pair costs 4 x 9 = 36 multiply-adds per (ci, co) instead of 2 x 27 = 54: 1.5x fewer FLOPs on the matrix pipe.
-// fp32 error: a few 1e-7 relative (sums of three inputs / weights before the product, three products per output).
+// A tile of MO output bands (MO*t .. MO*t+MO-1) of one (h, w) column needs the NP = MO + 2 input bands MO*t-1 .. MO*t+MO.
+// With v = B^T d (input transform, per element), u = G g (weight transform along the three n taps),
+//     m_k = sum over (ci, dh, dw) of u_k * v_k          (NP 3x3 convolutions in (h, w)),      y = A^T m,
+// the tile costs NP x 9 multiply-adds per (ci, co) instead of MO x 27: 2x fewer for F(4,3) (6 planes for 4 bands; taken
+// when N % 4 == 0 -- N = 8 is exactly two tiles), 1.5x for F(2,3) (4 planes for 2 bands; N % 2 == 0):
+//   F(2,3): B^T = [1 0 -1 0; 0 1 1 0; 0 -1 1 0; 0 1 0 -1],  G = [1 0 0; 1/2 1/2 1/2; 1/2 -1/2 1/2; 0 0 1],  A^T = [1 1 1 0; 0 1 -1 -1]
+//   F(4,3): B^T = [4 0 -5 0 1 0; 0 -4 -4 1 1 0; 0 4 -4 -1 1 0; 0 -2 -1 2 1 0; 0 2 -1 -2 1 0; 0 4 0 -5 0 1],
+//           G = [1/4 0 0; -1/6 -1/6 -1/6; -1/6 1/6 -1/6; 1/24 1/12 1/6; 1/24 -1/12 1/6; 0 0 1],
+//           A^T = [1 1 1 1 1 0; 0 1 -1 2 -2 0; 0 1 1 4 4 0; 0 1 -1 8 -8 1]
+// fp32 error against the fp64 convolution (64 -> 64 channels, random data): direct 2.5e-7 relative L2, F(2,3) 3.9e-7,
+// F(4,3) 1.0e-6 (max 2.3e-6 of the largest output) -- inside every tolerance of the parity suite.
 //
 // Pieces: wino_input_kernel writes V[b][c][t][k][h+1][w+1] with a zero border (prologue applied first, segments concatenated;
-// 2x the bytes of x, an HBM pass), tmdiff_conv3d_wino_pack_weights writes U as [ci][dh*3+dw][k][co], and conv3d_wino_kernel is the
-// staged kernel (conv3d_dma.hip) over "taps" (dh, dw, k): the LDS box of an output tile holds, per channel, the TT x 4
-// planes (t, k) of its pairs with a one-pixel halo in (h, w); tap (dh, dw, k) multiplies plane k shifted by (dh, dw) into
-// accumulator k; the epilogue forms the two output bands in registers and hands them to the shared vector epilogue.
+// NP / MO times the bytes of x, an HBM pass), tmdiff_conv3d_wino_pack_weights writes U as [g][ci][dh*3+dw][k][co], and
+// conv3d_wino_kernel is the staged kernel (conv3d_dma.hip) over "taps" (dh, dw, k): the LDS box of an output tile holds, per
+// channel, the TT x NP planes (t, k) with a one-pixel halo in (h, w); tap (dh, dw, k) multiplies plane k shifted by (dh, dw)
+// into accumulator k; at the end of the tile the waves exchange partial output sums through LDS and hand the output bands
+// to the shared vector epilogue.
 #include <cstdlib>
 #include <type_traits>
 
@@ -31,11 +36,28 @@ __device__ __forceinline__ void static_for(F&& f) {
   }
 }
 
+// transform matrices (NP = 4: F(2,3); NP = 6: F(4,3))
+template <int NP> struct WM;
+template <> struct WM<4> {
+  static constexpr int MO = 2;
+  static constexpr float BT[4][4] = {{1, 0, -1, 0}, {0, 1, 1, 0}, {0, -1, 1, 0}, {0, 1, 0, -1}};
+  static constexpr float G[4][3] = {{1, 0, 0}, {0.5f, 0.5f, 0.5f}, {0.5f, -0.5f, 0.5f}, {0, 0, 1}};
+  static constexpr float AT[2][4] = {{1, 1, 1, 0}, {0, 1, -1, -1}};
+};
+template <> struct WM<6> {
+  static constexpr int MO = 4;
+  static constexpr float BT[6][6] = {{4, 0, -5, 0, 1, 0}, {0, -4, -4, 1, 1, 0}, {0, 4, -4, -1, 1, 0},
+                                     {0, -2, -1, 2, 1, 0}, {0, 2, -1, -2, 1, 0}, {0, 4, 0, -5, 0, 1}};
+  static constexpr float G[6][3] = {{0.25f, 0, 0}, {-1.f / 6, -1.f / 6, -1.f / 6}, {-1.f / 6, 1.f / 6, -1.f / 6},
+                                    {1.f / 24, 1.f / 12, 1.f / 6}, {1.f / 24, -1.f / 12, 1.f / 6}, {0, 0, 1}};
+  static constexpr float AT[4][6] = {{1, 1, 1, 1, 1, 0}, {0, 1, -1, 2, -2, 0}, {0, 1, 1, 4, 4, 0}, {0, 1, -1, 8, -8, 1}};
+};
+
 struct WinoArgs {
-  int B, N, H, W;       // output = input extents (N even)
+  int B, N, H, W;       // output = input extents (N a multiple of MO)
   int Cin, Cout, cin_g, cout_g, groups;
-  const float* v;       // V [B, Cin, N/2, 4, H, W]
-  const float* wp;      // U packed [g][ci][9][4][co]
+  const float* v;       // V [B, Cin, N/MO, NP, H+2, W+4]
+  const float* wp;      // U packed [g][ci][9][NP][co]
   const float* bias;
   float bias_scale;
   const float* residual;
@@ -67,9 +89,12 @@ struct WinoInArgs {
 // V is stored with a zero border: plane (t, k) is (H + 2) x (W + 4) floats, element (h, w) at row h + 1, column w + 1, so that
 // the haloed box of a tile (rows h0 - 1 .., columns w0 - 1 ..; w0 a multiple of 8) starts on a 16-byte boundary and travels
 // to LDS in 16-byte pieces without bounds checks (a dword piece per 64 floats cost the kernel its matrix-pipe time).
-// one thread: one (b, c, t, h, quad j) -- source columns 4j-1 .. 4j+3 of the four input bands of pair t (prologue applied),
-// written as the padded quad 4j .. 4j+3 of the four transformed planes (+ the trailing quad of a row, + the border rows)
+// one thread: one (b, c, t, h, quad j) -- source columns 4j-1 .. 4j+3 of the NP input bands of tile t (prologue applied),
+// written as the padded quad 4j .. 4j+3 of the NP transformed planes (+ the trailing quad of a row, + the border rows)
+template <int NP>
 __global__ void __launch_bounds__(256) wino_input_kernel(const WinoInArgs a) {
+  using M = WM<NP>;
+  constexpr int MO = M::MO;
   const int bc = blockIdx.y, b = bc / a.Cin, c = bc % a.Cin;
   int cs = c, seg = 0;
   if (a.nseg > 1 && cs >= a.seg_c[0]) { cs -= a.seg_c[0]; seg = 1; }
@@ -83,15 +108,15 @@ __global__ void __launch_bounds__(256) wino_input_kernel(const WinoInArgs a) {
   const bool plain = !a.in_shift && !a.in_scale && !a.in_act && !drop;
   const uint64_t ebase = (uint64_t)bc * (uint64_t)(a.N * hw);
   float* xpp = a.xp ? a.xp + (long)bc * a.N * hw : nullptr;
-  const int T = a.N / 2, WP = a.W + 4, qrow = a.W / 4;
+  const int T = a.N / MO, WP = a.W + 4, qrow = a.W / 4;
   const long pplane = (long)(a.H + 2) * WP;                    // one padded plane
-  float* vp = a.v + (long)bc * T * 4 * pplane;
+  float* vp = a.v + (long)bc * T * NP * pplane;
   const long quads = hw / 4;
   for (long i = blockIdx.x * 256L + threadIdx.x; i < T * quads; i += 256L * gridDim.x) {
     const int t = (int)(i / quads);
     const long q = (i % quads) * 4;                            // offset of the source quad inside a band plane
     const int h = (int)(q / a.W), j = (int)((q % a.W) / 4);
-    float d[4][5];                                             // [band][source column 4j-1 .. 4j+3]
+    float d[NP][5];                                            // [band][source column 4j-1 .. 4j+3]
     auto prologue = [&](float x, long idx) __attribute__((always_inline)) {
       float u = x + sh;
       const float ua = tmdiff::silu_f(u);
@@ -100,8 +125,8 @@ __global__ void __launch_bounds__(256) wino_input_kernel(const WinoInArgs a) {
       return u;
     };
 #pragma unroll
-    for (int k = 0; k < 4; ++k) {
-      const int n = 2 * t - 1 + k;
+    for (int k = 0; k < NP; ++k) {
+      const int n = MO * t - 1 + k;
       if (n >= 0 && n < a.N) {
         const float4 x4 = *reinterpret_cast<const float4*>(xs + n * hw + q);
         d[k][1] = x4.x, d[k][2] = x4.y, d[k][3] = x4.z, d[k][4] = x4.w;
@@ -109,7 +134,7 @@ __global__ void __launch_bounds__(256) wino_input_kernel(const WinoInArgs a) {
 #pragma unroll
           for (int e = 1; e < 5; ++e) d[k][e] = prologue(d[k][e], n * hw + q + e - 1);
         }
-        if (xpp && (k == 1 || k == 2))      // bands 2t and 2t+1: every element of x' exactly once
+        if (xpp && k >= 1 && k <= MO)       // the tile's own bands: every element of x' exactly once
           *reinterpret_cast<float4*>(xpp + n * hw + q) = make_float4(d[k][1], d[k][2], d[k][3], d[k][4]);
       } else {
 #pragma unroll
@@ -124,18 +149,21 @@ __global__ void __launch_bounds__(256) wino_input_kernel(const WinoInArgs a) {
       }
       d[k][0] = j > 0 ? prev : 0.f;
     }
-    float o[4][5];
+    float o[NP][5];
 #pragma unroll
-    for (int e = 0; e < 5; ++e) {
-      o[0][e] = d[0][e] - d[2][e];
-      o[1][e] = d[1][e] + d[2][e];
-      o[2][e] = d[2][e] - d[1][e];
-      o[3][e] = d[1][e] - d[3][e];
-    }
+    for (int k = 0; k < NP; ++k)
+#pragma unroll
+      for (int e = 0; e < 5; ++e) {
+        float acc = 0.f;
+#pragma unroll
+        for (int jj = 0; jj < NP; ++jj)
+          if (M::BT[k][jj] != 0.f) acc += M::BT[k][jj] * d[jj][e];
+        o[k][e] = acc;
+      }
     const float4 z4 = make_float4(0.f, 0.f, 0.f, 0.f);
 #pragma unroll
-    for (int k = 0; k < 4; ++k) {
-      float* row = vp + ((long)t * 4 + k) * pplane + (long)(h + 1) * WP;
+    for (int k = 0; k < NP; ++k) {
+      float* row = vp + ((long)t * NP + k) * pplane + (long)(h + 1) * WP;
       *reinterpret_cast<float4*>(row + 4 * j) = make_float4(o[k][0], o[k][1], o[k][2], o[k][3]);
       if (j == qrow - 1) *reinterpret_cast<float4*>(row + a.W) = make_float4(o[k][4], 0.f, 0.f, 0.f);
       if (h == 0) {                                            // border rows
@@ -152,13 +180,8 @@ __global__ void __launch_bounds__(256) wino_input_kernel(const WinoInArgs a) {
 
 __device__ const float4 kZero4 = {0.f, 0.f, 0.f, 0.f};  // source of zero padding / filler lanes
 
-__device__ __forceinline__ void dma_b32(const float* src, float* dst) {
-#if defined(__HIP_DEVICE_COMPILE__)  // the builtin exists in the device pass only
-  __builtin_amdgcn_global_load_lds(src, dst, 4, 0, 0);
-#endif
-}
 __device__ __forceinline__ void dma_b128(const float* src, float* dst) {
-#if defined(__HIP_DEVICE_COMPILE__)
+#if defined(__HIP_DEVICE_COMPILE__)  // the builtin exists in the device pass only
   __builtin_amdgcn_global_load_lds(src, dst, 16, 0, 0);
 #endif
 }
@@ -168,34 +191,36 @@ __device__ __forceinline__ unsigned xcd_remap(unsigned bid, unsigned nwg) {
   return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + k;
 }
 
-constexpr int W_TAPS = 36;   // (dh, dw) x k
-
-template <int NS, int MSUB, int KC, int TT, int TH, int TW, bool XS>
+template <int NS, int MSUB, int KC, int TT, int TH, int TW, int NP>
 struct GeoW {
   static constexpr int CO = 32 * MSUB;
+  static constexpr int W_TAPS = 9 * NP;                     // (dh, dw) x k
   static constexpr int HH = TH + 2, HW = TW + 4;            // rows of TW + 2 haloed columns, fetched as (TW + 4) / 4 quads
   static constexpr int PLANE = HH * HW;
-  static constexpr int TILE_ELEMS = TT * 4 * PLANE;         // [TT pairs][4 planes][HH][HW] of one channel
+  static constexpr int TILE_ELEMS = TT * NP * PLANE;        // [TT tiles][NP planes][HH][HW] of one channel
   static constexpr int LDS_IN = KC * TILE_ELEMS;
   static constexpr int XP = (LDS_IN / 4 + 63) / 64;         // 16-byte pieces (64 quads each)
   static constexpr int X_FLOATS = XP * 256;
-  static constexpr int W_UNITS = KC * W_TAPS * CO / 4;      // weight slab [KC][36][CO] in 16-byte units
+  static constexpr int W_UNITS = KC * W_TAPS * CO / 4;      // weight slab [KC][9 NP][CO] in 16-byte units
   static constexpr int WP = (W_UNITS + 63) / 64;
   static constexpr int STAGE = X_FLOATS + WP * 256;
-  static_assert(TT * TH * TW == (XS ? 2 : 4) * NS * 32, "workgroup tile = 4 (XS: 2) waves x NS sub-tiles x 32 pair positions");
+  static_assert(TT * TH * TW == 2 * NS * 32, "workgroup tile = 2 wave pairs x NS sub-tiles x 32 positions");
   static_assert(KC % 2 == 0, "K step is 2 channels");
-  static_assert((TH * TW) % 32 == 0, "a sub-tile of 32 pair positions lies in one pair");
+  static_assert((TH * TW) % 32 == 0, "a sub-tile of 32 positions lies in one tile along n");
 };
 
-// XS ("plane split"): waves 0, 1 accumulate the planes k = 0, 1 and waves 2, 3 the planes k = 2, 3 of the SAME 2 x NS x 32
-// pair positions -- twice the register blocking per wave (one weight read and NS input reads feed NS x MSUB MFMAs of one
-// plane: 0.75 LDS reads per MFMA instead of 1) for one exchange of partial sums through LDS at the end of the tile.
-template <int NS, int MSUB, int KC, int TT, int TH, int TW, bool XS>
+// Plane split: waves 0, 1 accumulate the planes k < NP/2 and waves 2, 3 the planes k >= NP/2 of the SAME 2 x NS x 32 positions
+// (one weight read and NS input reads feed NS x MSUB MFMAs of one plane: 0.75 LDS reads per MFMA); at the end of the tile
+// each pair forms its part of A^T m for every output band, keeps the parts of the output bands it will finish (the first
+// pair the lower half of the bands, the second the upper half) and hands the others to its partner wave through LDS.
+template <int NS, int MSUB, int KC, int TT, int TH, int TW, int NP>
 __global__ void __launch_bounds__(256, 2) conv3d_wino_kernel(const WinoArgs a) {
-  using G = GeoW<NS, MSUB, KC, TT, TH, TW, XS>;
-  constexpr int NX = XS ? 2 : 4;                               // planes per wave
-  constexpr int CO = G::CO;
-  constexpr int XK = (G::XP + 3) / 4, WK = (G::WP + 3) / 4;  // pieces per wave
+  using G = GeoW<NS, MSUB, KC, TT, TH, TW, NP>;
+  using M = WM<NP>;
+  constexpr int CO = G::CO, MO = M::MO, W_TAPS = G::W_TAPS;
+  constexpr int NX = NP / 2;                                   // planes per wave
+  constexpr int OH = MO / 2;                                   // output bands a wave finishes
+  constexpr int XK = (G::XP + 3) / 4, WK = (G::WP + 3) / 4;    // pieces per wave
   __shared__ __attribute__((aligned(16))) float st0[G::STAGE];
   __shared__ __attribute__((aligned(16))) float st1[G::STAGE];
 
@@ -212,23 +237,23 @@ __global__ void __launch_bounds__(256, 2) conv3d_wino_kernel(const WinoArgs a) {
   const int b = __builtin_amdgcn_readfirstlane(id / a.groups);
   const int t0 = tt_i * TT, h0 = th_i * TH, w0 = tw_i * TW;
   const int co0 = co_tile * CO;
-  const int T = a.N / 2;
+  const int T = a.N / MO;
   const long plane = (long)a.N * a.H * a.W;                    // output plane
-  const int plane_v = T * 4 * (a.H + 2) * (a.W + 4);           // one channel of V (planes with their zero border)
+  const int plane_v = T * NP * (a.H + 2) * (a.W + 4);          // one channel of V (planes with their zero border)
   const int nchunks = a.cin_g / KC;
 
   // ---- DMA sources of this lane (the same for every chunk) -----------------------------------------------------
   int xsrc[XK];  // float offset (of a quad) from the chunk base, or -1 = zero quad
-  const int WP = a.W + 4, HP = a.H + 2;
+  const int WPd = a.W + 4, HPd = a.H + 2;
 #pragma unroll
   for (int k = 0; k < XK; ++k) {
     const int f = ((wv + 4 * k) * 64 + lane) * 4;              // first float of this lane's quad inside the stage
     const int kc = f / G::TILE_ELEMS, e = f % G::TILE_ELEMS;
-    const int tz = e / (4 * G::PLANE), xi = (e / G::PLANE) % 4, r = e % G::PLANE;
+    const int tz = e / (NP * G::PLANE), xi = (e / G::PLANE) % NP, r = e % G::PLANE;
     const int hz = r / G::HW, wq = r % G::HW;                  // (wq a multiple of 4)
     const int t = t0 + tz, hp = h0 + hz, wp = w0 + wq;         // padded coordinates: row h + 1 = h0 - 1 + hz + 1, column w0 - 1 + wq + 1
-    const bool ok = f < G::LDS_IN && t < T && hp < HP && wp < WP;
-    xsrc[k] = ok ? kc * plane_v + ((t * 4 + xi) * HP + hp) * WP + wp : -1;
+    const bool ok = f < G::LDS_IN && t < T && hp < HPd && wp < WPd;
+    xsrc[k] = ok ? kc * plane_v + ((t * NP + xi) * HPd + hp) * WPd + wp : -1;
   }
   int wsrc[WK];  // float offset inside the chunk's rows, or -1
 #pragma unroll
@@ -258,14 +283,15 @@ __global__ void __launch_bounds__(256, 2) conv3d_wino_kernel(const WinoArgs a) {
   __builtin_amdgcn_sched_barrier(0);
 
   // ---- per-lane operand offsets (floats inside a stage) ----------------------------------------------------------
-  const int wpos = XS ? (wv & 1) : wv;                         // which positions of the tile this wave owns
-  const int xi_base = XS ? 2 * (wv >> 1) : 0;                  // ... and which planes (wave-uniform)
+  const int wpos = wv & 1;                                     // which positions of the tile this wave owns
+  const int grp = wv >> 1;                                     // ... and which planes: k = NX * grp .. NX * grp + NX - 1
+  const int xi_base = NX * grp;
   int boff[NS];
 #pragma unroll
   for (int s = 0; s < NS; ++s) {
     const int p = (wpos * NS + s) * 32 + l31;
     const int pw = p % TW, ph = (p / TW) % TH, pt = p / (TW * TH);
-    boff[s] = ((pt * 4 + xi_base) * G::HH + ph) * G::HW + pw + khalf * G::TILE_ELEMS;
+    boff[s] = ((pt * NP + xi_base) * G::HH + ph) * G::HW + pw + khalf * G::TILE_ELEMS;
   }
   const int aoff = G::X_FLOATS + khalf * W_TAPS * CO + xi_base * CO + l31 * MSUB;  // slab rows hold the tile's channels as [l31][m]
 
@@ -298,7 +324,7 @@ __global__ void __launch_bounds__(256, 2) conv3d_wino_kernel(const WinoArgs a) {
       constexpr int kp = ks / WT, tap = ks % WT;
       constexpr int xi = tap % NX, dh = (tap / NX) / 3, dw = (tap / NX) % 3;
       constexpr int toff = (xi * G::HH + dh) * G::HW + dw;
-      const float* ap = st + aoff + (kp * 2 * W_TAPS + (tap / NX) * 4 + xi) * CO;
+      const float* ap = st + aoff + (kp * 2 * W_TAPS + (tap / NX) * NP + xi) * CO;
       if constexpr (MSUB == 1) {
         av[ks & 1][0] = ap[0];
       } else {
@@ -341,89 +367,89 @@ __global__ void __launch_bounds__(256, 2) conv3d_wino_kernel(const WinoArgs a) {
     }
   }
 
-  static_assert(sizeof(st0) >= 4 * 4096, "the epilogue borrows 4 KB of LDS per wave");
-  if constexpr (!XS) {
-    // ---- output transform in registers: bands 2t (m0 + m1 + m2) and 2t + 1 (m1 - m2 - m3) of every sub-tile -------
-    f32x16 out[2 * NS][MSUB];      // [s * 2 + j][m]
-    int sub_base[2 * NS];          // linear position (over the 2 TT x TH x TW output tile) of the sub-tile's first position
+  // ---- output transform: y_j = sum_k A^T[j][k] m_k.  This wave holds m_k for its NX planes: it forms its part of every y_j,
+  // keeps those of the OH bands it finishes (j = OH * grp .. + OH - 1) and sends the other OH to its partner (wave ^ 2), one
+  // accumulator (1024 floats) per round through alternating stages, one barrier per round. -------------------------------
+  static_assert(sizeof(st0) >= 4 * 4096, "the exchange and the epilogue borrow 4 KB of LDS per wave");
+  auto part = [&](auto jc, auto gc, auto sc, auto mc, int r) __attribute__((always_inline)) {   // this wave's part of y_j (its group = gc)
+    constexpr int j = decltype(jc)::value, gg = decltype(gc)::value, s = decltype(sc)::value, m = decltype(mc)::value;
+    float v = 0.f;
 #pragma unroll
-    for (int s = 0; s < NS; ++s) {
-      const int pb = (wv * NS + s) * 32;
-      const int pt = pb / (TW * TH), rem = pb % (TW * TH);
+    for (int xl = 0; xl < NX; ++xl)
+      if (M::AT[j][NX * gg + xl] != 0.f) v += M::AT[j][NX * gg + xl] * acc[xl * NS + s][m][r];
+    return v;
+  };
+  int round = 0;
+  // sub-tile by sub-tile: exchange, then the epilogue of its OH output bands (the accumulators of a finished sub-tile are dead:
+  // the register file never holds more than the accumulators plus one sub-tile's outputs)
+  static_for<0, NS>([&](auto sc) __attribute__((always_inline)) {
+    constexpr int s = decltype(sc)::value;
+    f32x16 out[OH][MSUB];          // output band MO * pt + OH * grp + jj of this sub-tile
+    int sub_base[OH];              // linear position (over the MO TT x TH x TW output tile) of the sub-tile's first position
+    const int pb = (wpos * NS + s) * 32;
+    const int pt = pb / (TW * TH), rem = pb % (TW * TH);
 #pragma unroll
-      for (int j = 0; j < 2; ++j) sub_base[s * 2 + j] = (2 * pt + j) * (TW * TH) + rem;
-#pragma unroll
-      for (int m = 0; m < MSUB; ++m)
+    for (int jj = 0; jj < OH; ++jj) sub_base[jj] = (MO * pt + OH * grp + jj) * (TW * TH) + rem;
+    static_for<0, MSUB>([&](auto mc) __attribute__((always_inline)) {
+      constexpr int m = decltype(mc)::value;
+      static_for<0, OH>([&](auto jjc) __attribute__((always_inline)) {
+        constexpr int jj = decltype(jjc)::value;
+        float* buf = (round & 1) ? st1 : st0;
+        // send the part of the partner's band jj (j = OH * (1 - grp) + jj), keep the part of the own band (j = OH * grp + jj)
+        float keep[16];
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
-          const float m0 = acc[0 * NS + s][m][r], m1 = acc[1 * NS + s][m][r], m2 = acc[2 * NS + s][m][r], m3 = acc[3 * NS + s][m][r];
-          out[s * 2][m][r] = m0 + m1 + m2;
-          out[s * 2 + 1][m][r] = m1 - m2 - m3;
+          float snd;
+          if (grp == 0) {
+            snd = part(std::integral_constant<int, OH + jj>{}, std::integral_constant<int, 0>{}, sc, mc, r);
+            keep[r] = part(std::integral_constant<int, jj>{}, std::integral_constant<int, 0>{}, sc, mc, r);
+          } else {
+            snd = part(std::integral_constant<int, jj>{}, std::integral_constant<int, 1>{}, sc, mc, r);
+            keep[r] = part(std::integral_constant<int, OH + jj>{}, std::integral_constant<int, 1>{}, sc, mc, r);
+          }
+          buf[(wv * 16 + r) * 64 + lane] = snd;
         }
-    }
-    // (the chunk loop ends with a barrier: nobody reads the stages any more)
-    tmdiff::epilogue_vec<2 * NS, MSUB, 2 * TT, TH, TW>(a, out, bias_v, sh2_v, sc2_v, b, g, co0, 2 * t0, h0, w0, wv, lane, plane,
-                                                       st0 + wv * 1024, sub_base);
-  } else {
-    // ---- plane split: waves 0, 1 hold (m0, m1), waves 2, 3 hold (m2, m3) of the same positions.  y(2t) = (m0 + m1) + m2 is
-    // finished by the first pair of waves, y(2t+1) = m1 + (-m2 - m3) by the second: each wave hands ONE plane to its partner
-    // (wave ^ 2), one accumulator (1024 floats) per round through alternating stages, one barrier per round.
-    const int grp = wv >> 1;
-    f32x16 out[NS][MSUB];
-    int sub_base[NS];
-#pragma unroll
-    for (int s = 0; s < NS; ++s) {
-      const int pb = (wpos * NS + s) * 32;
-      const int pt = pb / (TW * TH), rem = pb % (TW * TH);
-      sub_base[s] = (2 * pt + grp) * (TW * TH) + rem;
-    }
-    int round = 0;
-#pragma unroll
-    for (int s = 0; s < NS; ++s)
-#pragma unroll
-      for (int m = 0; m < MSUB; ++m) {
-        float* buf = (round & 1) ? st1 : st0;
-        // send: the first pair sends m1 (its plane 1), the second pair sends m2 (its plane 0)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) buf[(wv * 16 + r) * 64 + lane] = grp ? acc[0 * NS + s][m][r] : acc[1 * NS + s][m][r];
         __syncthreads();
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
           const float got = buf[((wv ^ 2) * 16 + r) * 64 + lane];
-          const float keep = grp ? -acc[0 * NS + s][m][r] - acc[1 * NS + s][m][r]      // -m2 - m3
-                                 : acc[0 * NS + s][m][r] + acc[1 * NS + s][m][r];      //  m0 + m1
-          out[s][m][r] = grp ? got + keep : keep + got;      // y(2t+1) = m1 + (-m2 - m3);  y(2t) = (m0 + m1) + m2
+          out[jj][m][r] = grp ? got + keep[r] : keep[r] + got;   // (planes in ascending order on either side)
         }
         ++round;
-      }
-    __syncthreads();   // (the last round's reads are done before the epilogue reuses the stages)
-    tmdiff::epilogue_vec<NS, MSUB, 2 * TT, TH, TW>(a, out, bias_v, sh2_v, sc2_v, b, g, co0, 2 * t0, h0, w0, wv, lane, plane,
-                                                   st0 + wv * 1024, sub_base);
-  }
+      });
+    });
+    // the epilogue's 4 KB tile: this wave's region of the stage the LAST round did not use (its partner read that region two
+    // rounds ago; the next round writes other waves' regions of it only)
+    float* T = ((round & 1) ? st1 : st0) + wv * 1024;
+    tmdiff::epilogue_vec<OH, MSUB, MO * TT, TH, TW>(a, out, bias_v, sh2_v, sc2_v, b, g, co0, MO * t0, h0, w0, wv, lane, plane, T,
+                                                    sub_base);
+  });
 }
 
-template <int NS, int MSUB, int KC, int TT, int TH, int TW, bool XS>
+template <int NS, int MSUB, int KC, int TT, int TH, int TW, int NP>
 int launch(WinoArgs& a, hipStream_t st) {
-  constexpr int CO = 32 * MSUB;
-  a.tiles_t = (a.N / 2 + TT - 1) / TT;
+  constexpr int CO = 32 * MSUB, MO = WM<NP>::MO;
+  a.tiles_t = (a.N / MO + TT - 1) / TT;
   a.tiles_h = (a.H + TH - 1) / TH;
   a.tiles_w = (a.W + TW - 1) / TW;
   a.tiles_co = a.cout_g / CO;
   const long blocks = (long)a.B * a.groups * a.tiles_t * a.tiles_h * a.tiles_w * a.tiles_co;
   if (blocks <= 0 || blocks > 0x7fffffffL) return tmdiff::fail(TMDIFF_E_INVALID, "conv3d_wino_fwd: grid of %ld blocks", blocks);
   a.total_blocks = (unsigned)blocks;
-  conv3d_wino_kernel<NS, MSUB, KC, TT, TH, TW, XS><<<(unsigned)blocks, 256, 0, st>>>(a);
+  conv3d_wino_kernel<NS, MSUB, KC, TT, TH, TW, NP><<<(unsigned)blocks, 256, 0, st>>>(a);
   return tmdiff::check_launch("conv3d_wino_fwd");
 }
 
 // packed[g][ci][tap9][k][col(co)] = (G g)[k] of w[g * cout_g + co][ci][.][dh][dw]   (ci, co inside the group)
 // (column order inside a 64-channel tile as tmdiff_conv3d_pack_weights: channel c at (c % 32) * 2 + c / 32)
+template <int NP>
 __global__ void __launch_bounds__(256) wino_pack_weights_kernel(const float* __restrict__ w, float* __restrict__ packed, int cout_g,
                                                                 int cin_g, int mode, long total) {
+  using M = WM<NP>;
   for (long i = blockIdx.x * 256L + threadIdx.x; i < total; i += 256L * gridDim.x) {
     const int col = (int)(i % cout_g);
     long r = i / cout_g;
-    const int k = (int)(r % 4); r /= 4;
+    const int k = (int)(r % NP); r /= NP;
     const int tap9 = (int)(r % 9); r /= 9;
     const int ci = (int)(r % cin_g);
     const int g = (int)(r / cin_g);
@@ -432,15 +458,19 @@ __global__ void __launch_bounds__(256) wino_pack_weights_kernel(const float* __r
       const int tile = col / 64, j = col % 64;
       co = tile * 64 + (j % 2) * 32 + j / 2;
     }
-    float g0, g1, g2;
+    float g3[3];
     if (mode == 0) {
       const float* wk = w + (((long)g * cout_g + co) * cin_g + ci) * 27 + tap9;   // [dn][dh][dw]: dn stride 9
-      g0 = wk[0], g1 = wk[9], g2 = wk[18];
+      g3[0] = wk[0], g3[1] = wk[9], g3[2] = wk[18];
     } else {   // data-gradient form: this convolution's (co, ci) are the forward one's (ci, co), every tap mirrored
       const float* wk = w + (((long)g * cin_g + ci) * cout_g + co) * 27 + (8 - tap9);
-      g0 = wk[18], g1 = wk[9], g2 = wk[0];
+      g3[0] = wk[18], g3[1] = wk[9], g3[2] = wk[0];
     }
-    packed[i] = k == 0 ? g0 : (k == 1 ? 0.5f * (g0 + g1 + g2) : (k == 2 ? 0.5f * (g0 - g1 + g2) : g2));
+    float u = 0.f;
+#pragma unroll
+    for (int kk = 0; kk < NP; ++kk)
+      if (kk == k) u = M::G[kk][0] * g3[0] + M::G[kk][1] * g3[1] + M::G[kk][2] * g3[2];
+    packed[i] = u;
   }
 }
 
@@ -452,56 +482,75 @@ bool wino_ok(const tmdiff_conv3d_desc* d) {
          d->W % 4 == 0;
 }
 
+// F(4,3) when the band count is a multiple of four, else F(2,3); TMDIFF_WINO_F4=0 (experiments): always F(2,3)
+int planes_for(int N) {
+  static const bool f4 = [] {
+    const char* e = getenv("TMDIFF_WINO_F4");
+    return !(e && e[0] == '0');
+  }();
+  return (f4 && N % 4 == 0) ? 6 : 4;
+}
+
 }  // namespace
 
 extern "C" int tmdiff_conv3d_wino_supported(const tmdiff_conv3d_desc* d) { return wino_ok(d) ? 1 : 0; }
+
+/* planes of the transform this library uses for N bands (6: F(4,3), 4: F(2,3)): the `planes` argument of the weight packing */
+extern "C" int32_t tmdiff_conv3d_wino_planes(int32_t N) { return N > 0 && N % 2 == 0 ? planes_for(N) : 0; }
 
 // workgroups the convolution kernel would launch (0 = shape not supported): callers keep small grids on tmdiff_conv3d_fwd,
 // whose split-K fills the chip
 extern "C" int64_t tmdiff_conv3d_wino_blocks(const tmdiff_conv3d_desc* d) {
   if (!wino_ok(d) || d->B <= 0) return 0;
-  const int T = d->N / 2, cg = d->Cout / d->groups;
+  const int T = d->N / (planes_for(d->N) - 2), cg = d->Cout / d->groups;
   if (cg % 64 == 0) return (int64_t)d->B * d->groups * ((T + 1) / 2) * ((d->H + 7) / 8) * ((d->W + 7) / 8) * (cg / 64);
   return (int64_t)d->B * d->groups * ((T + 1) / 2) * ((d->H + 7) / 8) * ((d->W + 15) / 16) * (cg / 32);
 }
 
 extern "C" size_t tmdiff_conv3d_wino_workspace_bytes(const tmdiff_conv3d_desc* d) {
   if (!wino_ok(d) || d->B <= 0) return 0;
-  return (size_t)d->B * d->Cin * (d->N / 2) * 4 * (d->H + 2) * (d->W + 4) * sizeof(float);
+  return (size_t)d->B * d->Cin * (d->N / 2) * 4 * (d->H + 2) * (d->W + 4) * sizeof(float);   // (F(2,3): the larger of the two)
 }
 
-extern "C" size_t tmdiff_conv3d_wino_packed_bytes(int32_t Cout, int32_t Cin, int32_t groups) {
-  if (groups < 1 || Cout <= 0 || Cin <= 0 || Cout % groups || Cin % groups || (Cout / groups) % 32) return 0;
-  return (size_t)(Cin / groups) * W_TAPS * Cout * sizeof(float);
+extern "C" size_t tmdiff_conv3d_wino_packed_bytes(int32_t Cout, int32_t Cin, int32_t groups, int32_t planes) {
+  if (groups < 1 || Cout <= 0 || Cin <= 0 || Cout % groups || Cin % groups || (Cout / groups) % 32 || (planes != 4 && planes != 6)) return 0;
+  return (size_t)(Cin / groups) * 9 * planes * Cout * sizeof(float);
 }
 
 extern "C" int tmdiff_conv3d_wino_pack_weights(const float* w, float* packed, int32_t Cout, int32_t Cin, int32_t groups,
-                                               int32_t mode, tmdiff_stream_t stream) {
+                                               int32_t mode, int32_t planes, tmdiff_stream_t stream) {
   using namespace tmdiff;
   TMDIFF_REQUIRE(w && packed && aligned16(packed), "conv3d_wino_pack_weights: NULL / unaligned pointer");
   TMDIFF_REQUIRE(groups >= 1 && Cout > 0 && Cin > 0 && Cout % groups == 0 && Cin % groups == 0 && (Cout / groups) % 32 == 0,
                  "conv3d_wino_pack_weights: Cout=%d Cin=%d groups=%d (Cout/groups a multiple of 32)", Cout, Cin, groups);
-  const long total = (long)(Cin / groups) * W_TAPS * Cout;
+  TMDIFF_REQUIRE(mode == 0 || mode == 1, "conv3d_wino_pack_weights: mode=%d", mode);
+  TMDIFF_REQUIRE(planes == 4 || planes == 6, "conv3d_wino_pack_weights: planes=%d (tmdiff_conv3d_wino_planes)", planes);
+  const long total = (long)(Cin / groups) * 9 * planes * Cout;
   long blocks = (total + 255) / 256;
   if (blocks > 4096) blocks = 4096;
-  TMDIFF_REQUIRE(mode == 0 || mode == 1, "conv3d_wino_pack_weights: mode=%d", mode);
-  wino_pack_weights_kernel<<<(int)blocks, 256, 0, as_stream(stream)>>>(w, packed, Cout / groups, Cin / groups, mode, total);
+  if (planes == 6)
+    wino_pack_weights_kernel<6><<<(int)blocks, 256, 0, as_stream(stream)>>>(w, packed, Cout / groups, Cin / groups, mode, total);
+  else
+    wino_pack_weights_kernel<4><<<(int)blocks, 256, 0, as_stream(stream)>>>(w, packed, Cout / groups, Cin / groups, mode, total);
   return check_launch("conv3d_wino_pack_weights");
 }
 
 // stage: 0 = input transform + convolution, 1 = the transform pass alone (fills the workspace), 2 = the convolution alone
 // (the workspace already holds this input's transform: a measurement, or several convolutions of one tensor)
-extern "C" int tmdiff_conv3d_wino_fwd_xp(const tmdiff_conv3d_desc* d, void* workspace, int32_t stage, float* xp_out,
-                                         tmdiff_stream_t stream) {
+// planes: 6 (N % 4 == 0 only) or 4 = the transform the weights were packed for; 0 = tmdiff_conv3d_wino_planes(N)
+extern "C" int tmdiff_conv3d_wino_fwd_planes(const tmdiff_conv3d_desc* d, void* workspace, int32_t stage, float* xp_out,
+                                             int32_t planes, tmdiff_stream_t stream) {
   using namespace tmdiff;
   TMDIFF_REQUIRE(d != nullptr, "conv3d_wino_fwd: NULL descriptor");
   if (!wino_ok(d))
     return fail(TMDIFF_E_UNSUPPORTED, "conv3d_wino_fwd: fp32 3x3x3, groups 1 or 3, even N, W %% 4 == 0, Cin/g %% 2 == 0, Cout/g %% 32 == 0, no mask");
   TMDIFF_REQUIRE(d->B >= 0, "conv3d_wino_fwd: bad extents");
   if (d->B == 0) return TMDIFF_OK;
+  const int np = planes ? planes : planes_for(d->N), mo = np - 2;
+  TMDIFF_REQUIRE((np == 6 && d->N % 4 == 0) || np == 4, "conv3d_wino_fwd: planes=%d with N=%d", planes, d->N);
   TMDIFF_REQUIRE(workspace && aligned16(workspace), "conv3d_wino_fwd: needs its workspace (tmdiff_conv3d_wino_workspace_bytes)");
   TMDIFF_REQUIRE(d->w_packed && (d->y || d->y2) && aligned16(d->w_packed), "conv3d_wino_fwd: NULL / unaligned weights or output");
-  TMDIFF_REQUIRE((long)d->Cin * (d->N / 2) * 4 * (d->H + 2) * (d->W + 4) < (1L << 31) / 2, "conv3d_wino_fwd: input too large for 32-bit offsets");
+  TMDIFF_REQUIRE((long)d->Cin * (d->N / mo) * np * (d->H + 2) * (d->W + 4) < (1L << 31) / 2, "conv3d_wino_fwd: input too large for 32-bit offsets");
   TMDIFF_REQUIRE((long)d->B * d->Cin <= 65535, "conv3d_wino_fwd: B*Cin = %ld exceeds the grid", (long)d->B * d->Cin);
   int csum = 0;
   for (int i = 0; i < d->nseg; ++i) {
@@ -524,9 +573,11 @@ extern "C" int tmdiff_conv3d_wino_fwd_xp(const tmdiff_conv3d_desc* d, void* work
   TMDIFF_REQUIRE(!xp_out || aligned16(xp_out), "conv3d_wino_fwd: xp_out must be 16-byte aligned");
   TMDIFF_REQUIRE(stage >= 0 && stage <= 2, "conv3d_wino_fwd: stage=%d", stage);
   if (stage != 2) {
-    long pb = ((long)(d->N / 2) * d->H * d->W / 4 + 255) / 256;
+    long pb = ((long)(d->N / mo) * d->H * d->W / 4 + 255) / 256;
     if (pb > 64) pb = 64;
-    wino_input_kernel<<<dim3((unsigned)pb, (unsigned)(d->B * d->Cin)), 256, 0, st>>>(q);
+    const dim3 grid((unsigned)pb, (unsigned)(d->B * d->Cin));
+    if (np == 6) wino_input_kernel<6><<<grid, 256, 0, st>>>(q);
+    else wino_input_kernel<4><<<grid, 256, 0, st>>>(q);
     const int rc = check_launch("conv3d_wino_fwd (input transform)");
     if (rc || stage == 1) return rc;
   }
@@ -543,22 +594,23 @@ extern "C" int tmdiff_conv3d_wino_fwd_xp(const tmdiff_conv3d_desc* d, void* work
   a.vec4 = 1;
   if (!(d->W % 4 == 0 && aligned16(d->y) && aligned16(d->y2) && aligned16(d->residual)))
     return fail(TMDIFF_E_UNSUPPORTED, "conv3d_wino_fwd: W %% 4 == 0 and 16-byte aligned outputs / residual");
-  static const bool xs = [] {
-    const char* e = getenv("TMDIFF_WINO_XSPLIT");      // experiments: "0" = every wave accumulates all four planes
-    return !(e && e[0] == '0');
-  }();
-  if (xs) {
-    if (a.cout_g % 64 == 0) return launch<2, 2, 2, 2, 8, 8, true>(a, st);
-    return launch<4, 1, 2, 2, 8, 16, true>(a, st);
+  if (np == 6) {
+    if (a.cout_g % 64 == 0) return launch<2, 2, 2, 2, 8, 8, 6>(a, st);
+    return launch<4, 1, 2, 2, 8, 16, 6>(a, st);
   }
-  if (a.cout_g % 64 == 0) return launch<1, 2, 2, 2, 8, 8, false>(a, st);
-  return launch<2, 1, 2, 2, 8, 16, false>(a, st);
+  if (a.cout_g % 64 == 0) return launch<2, 2, 2, 2, 8, 8, 4>(a, st);
+  return launch<4, 1, 2, 2, 8, 16, 4>(a, st);
+}
+
+extern "C" int tmdiff_conv3d_wino_fwd_xp(const tmdiff_conv3d_desc* d, void* workspace, int32_t stage, float* xp_out,
+                                         tmdiff_stream_t stream) {
+  return tmdiff_conv3d_wino_fwd_planes(d, workspace, stage, xp_out, 0, stream);
 }
 
 extern "C" int tmdiff_conv3d_wino_fwd_stage(const tmdiff_conv3d_desc* d, void* workspace, int32_t stage, tmdiff_stream_t stream) {
-  return tmdiff_conv3d_wino_fwd_xp(d, workspace, stage, nullptr, stream);
+  return tmdiff_conv3d_wino_fwd_planes(d, workspace, stage, nullptr, 0, stream);
 }
 
 extern "C" int tmdiff_conv3d_wino_fwd(const tmdiff_conv3d_desc* d, void* workspace, tmdiff_stream_t stream) {
-  return tmdiff_conv3d_wino_fwd_xp(d, workspace, 0, nullptr, stream);
+  return tmdiff_conv3d_wino_fwd_planes(d, workspace, 0, nullptr, 0, stream);
 }

@@ -315,18 +315,23 @@ def conv3d_prologue(desc, shape):
     return xp
 
 
-def pack_conv_weight_wino(w, groups=1, mode=0):
-    """[Cout, Cin/groups, 3, 3, 3] -> the transformed, packed weights of the Winograd F(2,3)-along-n convolution (conv3d_wino).
-    mode=1: the weights of the DATA-GRADIENT convolution (Cout -> Cin channels, transposed, taps mirrored) of the forward
-    convolution whose weight w is."""
+def wino_planes(n_bands):
+    """Planes of the Winograd transform the library uses for a tensor of n_bands bands: 6 (F(4,3)), 4 (F(2,3)), 0 (odd)."""
+    return lib.tmdiff_conv3d_wino_planes(int(n_bands))
+
+
+def pack_conv_weight_wino(w, groups=1, mode=0, planes=6):
+    """[Cout, Cin/groups, 3, 3, 3] -> the transformed, packed weights of the Winograd-along-n convolution (conv3d_wino);
+    planes = wino_planes(N) of the tensors it will run on.  mode=1: the weights of the DATA-GRADIENT convolution
+    (Cout -> Cin channels, transposed, taps mirrored) of the forward convolution whose weight w is."""
     cout, cin = w.shape[0], w.shape[1] * groups
     if mode:
         cout, cin = cin, cout
-    nb = lib.tmdiff_conv3d_wino_packed_bytes(cout, cin, groups)
+    nb = lib.tmdiff_conv3d_wino_packed_bytes(cout, cin, groups, planes)
     if tuple(w.shape[2:]) != (3, 3, 3) or nb == 0:
-        raise ValueError(f"pack_conv_weight_wino: weight shape {tuple(w.shape)} (groups {groups}, mode {mode}) not supported")
+        raise ValueError(f"pack_conv_weight_wino: weight shape {tuple(w.shape)} (groups {groups}, mode {mode}, planes {planes}) not supported")
     out = torch.empty(nb // 4, device=w.device, dtype=torch.float32)
-    check(lib.tmdiff_conv3d_wino_pack_weights(_chk(w.detach(), "w"), out.data_ptr(), cout, cin, groups, mode, stream_ptr()),
+    check(lib.tmdiff_conv3d_wino_pack_weights(_chk(w.detach(), "w"), out.data_ptr(), cout, cin, groups, mode, planes, stream_ptr()),
           "conv3d_wino_pack_weights")
     return out
 
@@ -348,13 +353,16 @@ def conv3d_wino(segs, w_packed, cout, emit=None, keep_y=True, fallback=None, gro
     in-kernel dropout of the prologue output; xp_out: a [B, Cin, N, H, W] tensor that receives that output (finetune path)."""
     b, _, n, h, w = segs[0].shape
     dev = segs[0].device
-    if fallback is not None:         # unsupported extents, or a grid too small for a kernel without split-K (= tmdiff_conv3d_wino_blocks)
-        cg = cout // groups
-        blocks = b * groups * ((n // 2 + 1) // 2) * ((h + 7) // 8) * (((w + 7) // 8) * (cg // 64) if cg % 64 == 0 else ((w + 15) // 16) * (cg // 32))
-        if n % 2 or w % 4 or blocks < _WINO_MIN_BLOCKS:
-            return fallback()
-    if w_packed is None:             # (packed only once it is known that the kernel will run)
-        w_packed = w_packed_fn()
+    planes = wino_planes(n)
+    cg = cout // groups
+    per_tile = b * groups * ((h + 7) // 8) * (((w + 7) // 8) * (cg // 64) if cg % 64 == 0 else ((w + 15) // 16) * (cg // 32))
+    blocks = lambda p: per_tile * ((n // (p - 2) + 1) // 2) if p else 0          # (= tmdiff_conv3d_wino_blocks)
+    if planes == 6 and blocks(6) < _WINO_MIN_BLOCKS <= blocks(4):
+        planes = 4                   # F(2,3) has twice the tiles along the bands: it still fills the chip here
+    if fallback is not None and (not planes or w % 4 or blocks(planes) < _WINO_MIN_BLOCKS):
+        return fallback()            # unsupported extents, or a grid too small for a kernel without split-K
+    if w_packed is None:             # (packed only once it is known that the kernel will run, and with how many planes)
+        w_packed = w_packed_fn(planes)
     y = torch.empty(b, cout, n, h, w, device=dev, dtype=torch.float32) if keep_y else None
     y2 = None
     if emit is not None:
@@ -371,18 +379,20 @@ def conv3d_wino(segs, w_packed, cout, emit=None, keep_y=True, fallback=None, gro
     if xp_out is not None and not (xp_out.is_cuda and xp_out.is_contiguous() and xp_out.numel() == b * d.Cin * n * h * w):
         raise ValueError("conv3d_wino: xp_out must be a contiguous fp32 [B, Cin, N, H, W] tensor")
     if TIMER is None or xp_out is not None:
-        check(lib.tmdiff_conv3d_wino_fwd_xp(C.byref(d), ws, 0, xp_out.data_ptr() if xp_out is not None else None, stream_ptr()),
-              "conv3d_wino_fwd")
+        check(lib.tmdiff_conv3d_wino_fwd_planes(C.byref(d), ws, 0, xp_out.data_ptr() if xp_out is not None else None, planes,
+                                                stream_ptr()), "conv3d_wino_fwd")
         return ret
     # timed: the input-transform pass (an HBM pass, recorded under ksize 0 with its bytes) and the convolution kernel apart
     ev = [torch.cuda.Event(enable_timing=True) for _ in range(3)]
     ev[0].record()
-    check(lib.tmdiff_conv3d_wino_fwd_stage(C.byref(d), ws, 1, stream_ptr()), "conv3d_wino_fwd (input transform)")
+    check(lib.tmdiff_conv3d_wino_fwd_planes(C.byref(d), ws, 1, None, planes, stream_ptr()), "conv3d_wino_fwd (input transform)")
     ev[1].record()
-    check(lib.tmdiff_conv3d_wino_fwd_stage(C.byref(d), ws, 2, stream_ptr()), "conv3d_wino_fwd")
+    check(lib.tmdiff_conv3d_wino_fwd_planes(C.byref(d), ws, 2, None, planes, stream_ptr()), "conv3d_wino_fwd")
     ev[2].record()
-    TIMER.records.append((ev[0], ev[1], 12.0 * b * d.Cin * n * h * w, 0, "wino_input"))     # bytes: 4 B read + 8 B written
-    TIMER.records.append((ev[1], ev[2], 2.0 * b * cout * (d.Cin // groups) * 18 * n * h * w, 3, "conv3d_wino_fwd"))   # EXECUTED: 36 per pair
+    mo = planes - 2                  # bands per tile; bytes: 4 B read + 4 * planes / mo B written per input element
+    TIMER.records.append((ev[0], ev[1], (4.0 + 4.0 * planes / mo) * b * d.Cin * n * h * w, 0, "wino_input"))
+    # EXECUTED flops: 9 * planes multiply-adds per (ci, co) and tile of mo output bands (the direct kernel: 27 per band)
+    TIMER.records.append((ev[1], ev[2], 2.0 * b * cout * (d.Cin // groups) * (9.0 * planes / mo) * n * h * w, 3, f"conv3d_wino{mo}_fwd"))
     return ret
 
 

@@ -25,9 +25,10 @@ for name, ci, co, h in LAYERS:
     x = torch.randn(B, ci, 8, h, h, device="cuda")
     w = torch.randn(co, ci, 3, 3, 3, device="cuda") / (ci * 27) ** 0.5
     y = torch.empty(B, co, 8, h, h, device="cuda")
-    ww, wd = ops.pack_conv_weight_wino(w), ops.pack_conv_weight(w)
+    ww, wd = ops.pack_conv_weight_wino(w, planes=ops.wino_planes(8)), ops.pack_conv_weight(w)
     a = t(lambda: ops.conv3d_wino([x], ww, co))
     b = t(lambda: ops.conv3d([x], wd, co, 3, out=y))
     fl = 2.0 * B * co * ci * 27 * 8 * h * h
-    print(f"{name:12s} winograd {a:6.3f} ms ({fl / a / 1e9:6.1f} TFLOP/s in the direct count, {fl / 1.5 / a / 1e9:6.1f} executed) | "
+    red = 27.0 / (9.0 * ops.wino_planes(8) / (ops.wino_planes(8) - 2))       # 2 for F(4,3), 1.5 for F(2,3)
+    print(f"{name:12s} winograd {a:6.3f} ms ({fl / a / 1e9:6.1f} TFLOP/s in the direct count, {fl / red / a / 1e9:6.1f} executed) | "
           f"direct {b:6.3f} ms ({fl / b / 1e9:6.1f} TFLOP/s)", flush=True)
