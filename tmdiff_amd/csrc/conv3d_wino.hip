@@ -482,13 +482,18 @@ bool wino_ok(const tmdiff_conv3d_desc* d) {
          d->W % 4 == 0;
 }
 
-// F(4,3) when the band count is a multiple of four, else F(2,3); TMDIFF_WINO_F4=0 (experiments): always F(2,3)
+// F(4,3) when the band count is a multiple of four and its tiles fill the kernel's pairs of tiles at least as well as F(2,3)'s
+// would (a workgroup covers TT = 2 tiles along the bands: with N = 4 the second F(4,3) tile would be empty -- 2 x 13.5
+// multiply-adds per output against F(2,3)'s 18), else F(2,3); TMDIFF_WINO_F4=0 (experiments): always F(2,3)
 int planes_for(int N) {
   static const bool f4 = [] {
     const char* e = getenv("TMDIFF_WINO_F4");
     return !(e && e[0] == '0');
   }();
-  return (f4 && N % 4 == 0) ? 6 : 4;
+  if (!f4 || N % 4) return 4;
+  const int t6 = N / 4, t4 = N / 2;
+  const double cost6 = 13.5 * (2 * ((t6 + 1) / 2)) / t6, cost4 = 18.0 * (2 * ((t4 + 1) / 2)) / t4;
+  return cost6 <= cost4 ? 6 : 4;
 }
 
 }  // namespace
