@@ -343,3 +343,18 @@ def test_driver_dataset_sampling():
     assert train.sample_dataset(p, 0.49) == "train_qb" and train.sample_dataset(p, 0.5) == "train_gf2"
     assert train.sample_dataset(p, 0.7499) == "train_gf2" and train.sample_dataset(p, 0.75) == "train_wv3"
     assert train.sample_dataset(train.dataset_probabilities({"train_wv3": 3}), 0.1) == "train_wv3"
+
+
+def test_winograd_transform_choice_and_sizes():
+    """Host-side rules of the Winograd-along-the-bands convolution (no GPU work): F(4,3) for band counts whose tiles fill
+    the kernel's pairs of tiles (8, 12, 16), F(2,3) for the other even counts (a single F(4,3) tile would leave half of
+    every workgroup idle), nothing for odd counts; packed weights hold 9 x planes values per (ci, co)."""
+    from tmdiff_amd import _lib
+    lib = _lib.lib
+    assert [lib.tmdiff_conv3d_wino_planes(n) for n in (2, 3, 4, 6, 8, 12, 16)] == [4, 0, 4, 4, 6, 6, 6]
+    assert lib.tmdiff_conv3d_wino_packed_bytes(64, 32, 1, 6) == 32 * 54 * 64 * 4
+    assert lib.tmdiff_conv3d_wino_packed_bytes(64, 32, 1, 4) == 32 * 36 * 64 * 4
+    assert lib.tmdiff_conv3d_wino_packed_bytes(96, 192, 3, 6) == 64 * 54 * 96 * 4        # groups = 3: Cin / groups rows
+    assert lib.tmdiff_conv3d_wino_packed_bytes(48, 32, 1, 6) == 0                          # Cout / groups not a multiple of 32
+    assert lib.tmdiff_conv3d_wino_packed_bytes(64, 32, 1, 5) == 0                          # planes is 4 or 6
+    assert lib.tmdiff_conv3d_ll_packed_bytes(64, 32) == 32 * 48 * 64 * 4
