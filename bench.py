@@ -46,14 +46,41 @@ GFLOP_PER_SAMPLE = 172.39          # algorithmic conv FLOPs per sam
 PEAK_FP32_MFMA = 157.3             # TFLOP/s, MI355X_MICROARCH.md
 
 
-def launch_ranks(args):
-    """Parent of a launcher-less multi-GPU run: start one worker per GPU and wait.  Nothing here touches the GPU
-    (torch.cuda.device_count() does not initialise HIP on this image; it is only read to fail early and loudly)."""
+def visible_gpus():
+    """Number of GPUs this process tree may use, WITHOUT loading any GPU runtime (the launcher parent must stay GPU-free
+    by construction: a process that has initialised HIP must not be the one that forks the ranks): the *_VISIBLE_DEVICES
+    lists if set, else the KFD topology's nodes with SIMDs (CPU nodes have simd_count 0).  None = cannot tell."""
+    counts = []
+    for var in ("ROCR_VISIBLE_DEVICES", "HIP_VISIBLE_DEVICES", "CUDA_VISIBLE_DEVICES"):
+        v = os.environ.get(var)
+        if v is not None:
+            counts.append(len([t for t in v.split(",") if t.strip() != ""]))
+    if counts:
+        return min(counts)
+    root = "/sys/class/kfd/kfd/topology/nodes"
+    try:
+        n = 0
+        for node in os.listdir(root):
+            try:
+                with open(os.path.join(root, node, "properties")) as fh:
+                    props = dict(l.split()[:2] for l in fh if len(l.split()) >= 2)
+            except OSError:
+                continue
+            n += int(props.get("simd_count", "0")) > 0
+        return n
+    except OSError:
+        return None
+
+
+def launch_ranks(args, timeout_s=3000.0):
+    """Parent of a launcher-less multi-GPU run: start one worker per GPU, poll them, and on the first failure (or the
+    overall timeout) stop the others -- a rank that died leaves its peers blocked in a collective, so waiting for them in
+    order would never return.  Nothing here imports torch or touches the GPU.  Returns the exit status for the parent:
+    0 only if every rank exited 0."""
     n = args.gpus
     if not args.rehearse and os.environ.get("TMDIFF_BENCH_BACKEND", "nccl") == "nccl":   # (gloo: ranks may share a GPU)
-        import torch
-        ndev = torch.cuda.device_count()
-        if ndev < n:
+        ndev = visible_gpus()
+        if ndev is not None and ndev < n:
             raise SystemExit(f"bench.py --gpus {n}: only {ndev} GPU(s) visible")
     with socket.socket() as sk:
         sk.bind(("127.0.0.1", 0))
@@ -63,8 +90,32 @@ def launch_ranks(args):
         env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n),
                    MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0")
         procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env))
-    rcs = [p.wait() for p in procs]
-    return max(abs(rc) for rc in rcs)
+    deadline = time.monotonic() + float(os.environ.get("TMDIFF_BENCH_LAUNCH_TIMEOUT", timeout_s))
+    status, reason = 0, None
+    while True:
+        rcs = [p.poll() for p in procs]
+        bad = [(r, rc) for r, rc in enumerate(rcs) if rc not in (None, 0)]
+        if bad:
+            status, reason = max(abs(rc) for _, rc in bad) or 1, f"rank {bad[0][0]} exited with status {bad[0][1]}"
+            break
+        if all(rc == 0 for rc in rcs):
+            return 0
+        if time.monotonic() > deadline:
+            status, reason = 124, "ranks still running at the launcher's timeout"
+            break
+        time.sleep(0.2)
+    print(f"[bench] launcher: {reason}; stopping the remaining ranks", file=sys.stderr, flush=True)
+    for p in procs:                       # exactly the PIDs this function started
+        if p.poll() is None:
+            p.terminate()
+    t_end = time.monotonic() + 10.0
+    for p in procs:
+        try:
+            p.wait(timeout=max(0.1, t_end - time.monotonic()))
+        except subprocess.TimeoutExpired:
+            p.kill()
+            p.wait()
+    return status
 
 
 def log(msg):
@@ -162,6 +213,8 @@ def rehearse(world, rank, args):
         import torch.distributed as dist
         dist.init_process_group("gloo")
     x = torch.ones(64, 64)
+    if os.environ.get("TMDIFF_BENCH_REHEARSE_FAIL_RANK") == str(rank):     # (tests: a rank that dies before the collective)
+        os._exit(7)
     barrier = (lambda: dist.barrier()) if dist is not None else (lambda: None)
     barrier()
     t0 = time.perf_counter()
@@ -505,11 +558,15 @@ def main():
         import threading
 
         def bail():
+            # a stuck collective must not read as success: the headline line (measured before this leg) is still printed
+            # by rank 0, then EVERY rank exits non-zero
             if rank == 0:
                 line["train_step"] = {"error": "finetune leg did not finish within 240 s (collective stuck?); "
-                                               "headline fields above were measured before it"}
+                                               "headline fields above were measured before it; exit status 3"}
                 print(json.dumps(line), flush=True)
-            os._exit(0)
+            sys.stderr.write(f"[bench] rank {rank}: finetune leg watchdog fired, exiting with status 3\n")
+            sys.stderr.flush()
+            os._exit(3)
 
         dog = threading.Timer(240.0, bail)
         dog.daemon = True

@@ -36,3 +36,28 @@ def test_under_a_launcher_world_size_wins():
     assert p.returncode == 0, p.stderr[-2000:]
     lines = [l for l in p.stdout.splitlines() if l.startswith("{")]
     assert len(lines) == 1 and json.loads(lines[0])["n_gpus"] == 2
+
+
+def test_a_dead_rank_stops_the_launcher_with_its_status():
+    """the parent used to wait() for the ranks in order with no timeout -- one dead rank left the others in the
+    collective and the parent never returned.  Now it polls, stops the survivors and reports the failure."""
+    import time
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT")}
+    env["TMDIFF_BENCH_REHEARSE_FAIL_RANK"] = "1"
+    t0 = time.monotonic()
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--rehearse", "--steps", "1"],
+                       capture_output=True, text=True, env=env, timeout=300)
+    assert p.returncode == 7, (p.returncode, p.stderr[-2000:])
+    assert "rank 1 exited with status 7" in p.stderr
+    assert time.monotonic() - t0 < 120
+    assert not [l for l in p.stdout.splitlines() if l.startswith("{")]          # no result line from a failed run
+
+
+def test_visible_gpus_needs_no_gpu_runtime():
+    """The launcher parent counts devices from the environment / the KFD topology: it never imports torch."""
+    code = ("import sys, os; sys.argv=['bench.py']; os.environ['HIP_VISIBLE_DEVICES']='0,1,2'; "
+            f"sys.path.insert(0, {ROOT!r}); import bench; assert bench.visible_gpus() == 3; "
+            "os.environ['ROCR_VISIBLE_DEVICES']='4'; assert bench.visible_gpus() == 1; "
+            "assert 'torch' not in sys.modules; print('ok')")
+    p = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=120)
+    assert p.returncode == 0 and p.stdout.strip() == "ok", p.stderr[-2000:]

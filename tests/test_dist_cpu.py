@@ -168,4 +168,83 @@ def test_ranks_draw_different_randomness():
         draws.append((random.random(), np.random.randint(1, 1001, size=8).tolist(), torch.randn(4).tolist()))
     assert draws[0][0] == draws[1][0]
     assert draws[0][1] != draws[1][1] and draws[0][2] != draws[1][2]
-    assert per_rank_batch(64, 8) == 8 and per_rank_batch(4, 8) == 1 and per_rank_batch(32, 1) == 32
+    assert per_rank_batch(64, 8) == 8 and per_rank_batch(32, 1) == 32
+    import pytest
+    for bad in ((4, 8), (30, 8), (0, 2)):          # a global batch the ranks cannot share evenly is refused, not rounded
+        with pytest.raises(ValueError):
+            per_rank_batch(*bad)
+
+
+def _replica_worker(rank, world, port, q):
+    os.environ.update({"MASTER_ADDR": "127.0.0.1", "MASTER_PORT": str(port), "RANK": str(rank),
+                       "WORLD_SIZE": str(world)})
+    from tmdiff_amd import dist as D
+    from tmdiff_amd import model as Model
+    from tmdiff_amd.train import build_replica, seed_all
+    assert D.init_from_env("gloo") == world
+    opt = {"phase": "train", "gpu_ids": None, "distributed": world > 1, "path": {"resume": None},
+           "model": {"unet": {"channel_multiplier": [4, 8, 16, 32]}, "diffusion": {"loss_type": "l1"}, "init_type": "orthogonal"},
+           "train": {"optimizer": {"lr": 1e-4}, "max_iter": 100}}
+    seed_all(rank=rank)                                    # what train.main does before the loaders are built
+    m = build_replica(lambda: Model.create_model(opt), rank, world)
+    sd = {k: v.numpy().copy() for k, v in m.netG.state_dict().items()}
+    draw = torch.randn(4).tolist()                         # after the build the ranks' generators differ again
+    # broadcast_module alone repairs replicas that were built under different seeds (seed + rank before create_model)
+    torch.manual_seed(100 + rank)
+    lin = torch.nn.Sequential(torch.nn.Linear(5, 7), torch.nn.BatchNorm1d(7))
+    before = lin[0].weight.detach().numpy().copy()
+    n = D.broadcast_module(lin, src=0)
+    q.put((rank, sd, draw, before, lin[0].weight.detach().numpy().copy(), n))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_replicas_start_identical_world2():
+    """train.main seeded torch with seed + rank BEFORE create_model, so every rank trained its own
+    random initialisation with a shared gradient.  build_replica: model under the shared seed + broadcast from rank 0,
+    rank offset only afterwards."""
+    world, port = 2, _free_port()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_replica_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = sorted((q.get(timeout=240) for _ in range(world)), key=lambda t: t[0])
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    (_, sd0, draw0, before0, after0, n0), (_, sd1, draw1, before1, after1, n1) = res
+    assert sd0.keys() == sd1.keys() and len(sd0) >= 272
+    for k in sd0:
+        assert (sd0[k] == sd1[k]).all(), k
+    assert any(abs(v).max() > 0 for k, v in sd0.items() if k.endswith("conv20.weight"))
+    assert draw0 != draw1
+    assert (before0 != before1).any() and (after0 == after1).all() and (after0 == before0).all()
+    assert n0 == n1 and n0 >= 6          # weight, bias, BN affine + running stats
+
+
+def test_grad_reducer_survives_replaced_grads():
+    """optimizer.zero_grad(set_to_none=True) / an assigned .grad used to leave the hooks reducing a stale
+    bucket.  The hook now notices that p.grad is no longer its bucket view, copies the gradient in and re-points it."""
+    from tmdiff_amd import dist as D
+    port = _free_port()
+    os.environ.update({"MASTER_ADDR": "127.0.0.1", "MASTER_PORT": str(port), "RANK": "0", "WORLD_SIZE": "1"})
+    dist.init_process_group("gloo", rank=0, world_size=1)
+    try:
+        torch.manual_seed(0)
+        net = torch.nn.Sequential(torch.nn.Linear(6, 5), torch.nn.Linear(5, 3))
+        red = D.GradReducer(net, op="sum", bucket_bytes=64, min_world=1)
+        x = torch.randn(4, 6)
+        for step in range(3):
+            if step == 2:
+                net.zero_grad(set_to_none=True)            # drops the bucket views
+            net(x).abs().mean().backward()
+            red.finish()
+            want = torch.autograd.grad(net(x).abs().mean(), list(net.parameters()))
+            for p, w in zip(net.parameters(), want):
+                assert torch.allclose(p.grad, w, atol=1e-7)
+                bk = red._bucket_of[id(p)]
+                assert p.grad.data_ptr() == bk["views"][id(p)].data_ptr()      # a view of its bucket again
+            red.zero_grad()
+    finally:
+        dist.destroy_process_group()

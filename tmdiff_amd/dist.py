@@ -53,6 +53,41 @@ def shard_batch(x_in, rank=None, world=None):
     return out
 
 
+def broadcast_module(module, src=0, group=None):
+    """Make every rank's parameters and buffers those of rank ``src`` (a few flat broadcasts).  The data-parallel
+    replicas must start identical: gradients are only ever SUM-reduced, never the weights (reference: DataParallel
+    replicates device 0's module every step, networks.py:88-91).  Returns the number of tensors synchronised."""
+    if not dist.is_initialized() or dist.get_world_size(group) == 1:
+        return 0
+    tensors = [t.data for t in list(module.parameters()) + list(module.buffers()) if t.numel() > 0]
+    by_kind = {}
+    for t in tensors:
+        by_kind.setdefault((t.dtype, t.device), []).append(t)
+    for ts in by_kind.values():
+        cur, cur_bytes = [], 0
+        chunks = []
+        for t in ts:
+            nb = t.numel() * t.element_size()
+            if cur and cur_bytes + nb > (64 << 20):
+                chunks.append(cur)
+                cur, cur_bytes = [], 0
+            cur.append(t)
+            cur_bytes += nb
+        if cur:
+            chunks.append(cur)
+        for ch in chunks:
+            flat = torch.cat([t.reshape(-1) for t in ch])
+            dist.broadcast(flat, src=src, group=group)
+            off = 0
+            for t in ch:
+                t.copy_(flat[off:off + t.numel()].view_as(t))
+                off += t.numel()
+    inval = getattr(getattr(module, "denoise_fn", module), "invalidate_prepared", None)
+    if inval is not None:            # packed weights / projection banks were built from the old values
+        inval()
+    return len(tensors)
+
+
 def allreduce_gradients(module, op="sum", bucket_bytes=64 << 20, group=None):
     """Sum (or average) ``p.grad`` over ranks with a few flat-bucket all-reduces.  Returns #buckets."""
     if op not in ("sum", "mean"):
@@ -127,6 +162,12 @@ class GradReducer:
         if bk is None:               # a parameter outside the recorded layout got a gradient: rebuild after this step
             self._order.append(p)
             return
+        view = bk["views"][id(p)]
+        if p.grad.data_ptr() != view.data_ptr():
+            # something replaced p.grad (optimizer.zero_grad(set_to_none=True), module.zero_grad(), an assignment): the
+            # bucket slot would be reduced stale and the real gradient not at all -- copy it in and re-point p.grad
+            view.copy_(p.grad)
+            p.grad = view
         bk["pending"] -= 1
         if bk["pending"] == 0:
             self._handles.append(dist.all_reduce(bk["flat"], op=dist.ReduceOp.SUM, group=self.group, async_op=True))
@@ -154,12 +195,14 @@ class GradReducer:
         for ps in groups:
             flat = torch.zeros(sum(p.numel() for p in ps), device=ps[0].device, dtype=torch.float32)
             off = 0
+            views = {}
             for p in ps:
                 view = flat[off:off + p.numel()].view_as(p)
                 view.copy_(p.grad)
                 p.grad = view
+                views[id(p)] = view
                 off += p.numel()
-            bk = {"flat": flat, "params": ps, "pending": len(ps)}
+            bk = {"flat": flat, "params": ps, "pending": len(ps), "views": views}
             self.buckets.append(bk)
             for p in ps:
                 self._bucket_of[id(p)] = bk

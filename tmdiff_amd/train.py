@@ -28,12 +28,14 @@ TRAIN_SETS = (("train_qb", "QB", 4), ("train_gf2", "GF2", 4), ("train_wv3", "WV3
 VAL_SETS = (("val_QB", "QB"), ("val_GF2", "GF2"), ("val_WV3", "WV3"))
 
 
-def seed_all(seed=3407, rank=0):
+def seed_all(seed=3407, rank=0, reseed_python=True):
     """reference seed_torch (:24-33).  ``random`` (the per-iteration choice of the training set, shared by all ranks)
     is seeded identically everywhere; NumPy (the timesteps of p_losses_dynamic), torch and the device generator
     (noise, dropout masks) are offset by the rank, so that the ranks draw different (t, eps, mask) like the
-    reference's DataParallel replicas do."""
-    random.seed(seed)
+    reference's DataParallel replicas do.  The MODEL must be built under rank 0's seeds (``build_replica``): the
+    replicas of a data-parallel run start from identical weights."""
+    if reseed_python:
+        random.seed(seed)
     os.environ["PYTHONHASHSEED"] = str(seed)
     np.random.seed(seed + rank)
     torch.manual_seed(seed + rank)
@@ -41,10 +43,31 @@ def seed_all(seed=3407, rank=0):
         torch.cuda.manual_seed_all(seed + rank)
 
 
+def build_replica(create, rank, world, seed=3407):
+    """Build this rank's model replica so that every rank holds the SAME weights (the reference's nn.DataParallel
+    re-broadcasts device 0's parameters every step, networks.py:88-91; one process per GPU must start identical and
+    stay identical through identical SUM-reduced gradients): the constructor and ``init_weights`` run under the
+    shared seed (rank offset 0), then -- belt and braces against a ``strict=False`` checkpoint load or any
+    rank-dependent initialisation -- every parameter and buffer is broadcast from rank 0, and only then are NumPy /
+    torch / the device generator re-seeded with the rank offset (timesteps, noise, dropout masks differ per replica).
+    ``create`` is a zero-argument callable returning an object with a ``netG`` module (model.DDPM) or a module."""
+    seed_all(seed, rank=0)
+    model = create()
+    if world > 1:
+        tdist.broadcast_module(getattr(model, "netG", model), src=0)
+    seed_all(seed, rank=rank, reseed_python=False)
+    return model
+
+
 def per_rank_batch(batch_size, world):
     """The option file's ``batch_size`` is the GLOBAL batch: nn.DataParallel (reference networks.py:88-91) scatters it
-    over the GPUs, so one process per GPU takes batch_size // world (at least 1)."""
-    return max(1, int(batch_size) // max(1, world))
+    over the GPUs, so one process per GPU takes batch_size // world.  A global batch that the ranks cannot share evenly
+    would silently change the effective batch, so it is refused."""
+    batch_size, world = int(batch_size), max(1, int(world))
+    if batch_size % world or batch_size < world:
+        raise ValueError(f"global batch_size {batch_size} is not a positive multiple of the world size {world}: every "
+                         f"rank takes batch_size // world items (nn.DataParallel scatter, reference networks.py:88-91)")
+    return batch_size // world
 
 
 def dataset_probabilities(lengths):
@@ -100,7 +123,8 @@ def main(argv=None):
             gens[name] = Data.get_data_generator(loaders[name])
     logger.info("Initial Dataset Finished")
 
-    diffusion = Model.create_model(opt)
+    # (seed_all(rank=rank) above only matters for the loaders; the model is built under the shared seed and synchronised)
+    diffusion = build_replica(lambda: Model.create_model(opt), rank, world)
     logger.info("Initial Model Finished")
     step = diffusion.begin_step
     diffusion.set_new_noise_schedule(opt["model"]["beta_schedule"][opt["phase"]], schedule_phase=opt["phase"])
