@@ -484,7 +484,7 @@ def main():
         # block as one strided convolution, csrc/conv3d_ll.hip) executes 48 of the 4 x 27 multiply-adds per output
         # ... and a conv3d_wino{4,2}_fwd launch (Winograd F(4,3) / F(2,3) along the band axis, csrc/conv3d_wino.hip; its
         # input-transform pass is timed apart) 54 of the 4 x 27 per four output bands / 36 of the 2 x 27 per pair
-        ref_factor = {"conv3d_ll_fwd": 108.0 / 48.0, "conv3d_wino2_fwd": 1.5, "conv3d_wino4_fwd": 2.0}   # F(2,3) / F(4,3)
+        ref_factor = {"conv3d_ll_fwd": 108.0 / 48.0, "conv3d_wino2_fwd": 1.5, "conv3d_wino4_fwd": 2.0, "conv3d_wf_fwd": 2.0}   # F(2,3) / F(4,3)
         fl3_ref = fl3 + sum(fl * (ref_factor[what] - 1.0) for (k, what), (n, ms, fl) in conv_by_entry.items()
                             if k == 3 and what in ref_factor)
         traffic, traffic_src = load_traffic()

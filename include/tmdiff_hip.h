@@ -23,7 +23,7 @@
 extern "C" {
 #endif
 
-#define TMDIFF_ABI_VERSION 3
+#define TMDIFF_ABI_VERSION 4
 
 #define TMDIFF_OK 0
 #define TMDIFF_E_INVALID (-1)     /* bad argument / shape */
@@ -176,9 +176,10 @@ int32_t tmdiff_conv3d_wino_planes(int32_t N);                     /* 6, 4, or 0 
 int64_t tmdiff_conv3d_wino_blocks(const tmdiff_conv3d_desc* d);   /* workgroups of its grid (no split-K: keep small grids on tmdiff_conv3d_fwd) */
 size_t tmdiff_conv3d_wino_workspace_bytes(const tmdiff_conv3d_desc* d);
 size_t tmdiff_conv3d_wino_packed_bytes(int32_t Cout, int32_t Cin, int32_t groups, int32_t planes);
-/* mode 0: w = [Cout, Cin/groups, 3,3,3] of this convolution; mode 1 (data gradient): w is the FORWARD convolution's weight
- * [Cin, Cout/groups, 3,3,3] and this convolution (Cin -> Cout) is its transpose with mirrored taps, as
- * tmdiff_conv3d_pack_weights(mode 1) */
+/* mode bit 0 clear: w = [Cout, Cin/groups, 3,3,3] of this convolution; set (data gradient): w is the FORWARD convolution's
+ * weight [Cin, Cout/groups, 3,3,3] and this convolution (Cin -> Cout) is its transpose with mirrored taps, as
+ * tmdiff_conv3d_pack_weights(mode 1).  mode bit 1 (value 2): natural column order (tmdiff_conv3d_wf_fwd) instead of the
+ * interleaved 64-channel tiles of tmdiff_conv3d_wino_fwd */
 int tmdiff_conv3d_wino_pack_weights(const float* w, float* packed, int32_t Cout, int32_t Cin, int32_t groups,
                                     int32_t mode, int32_t planes, tmdiff_stream_t stream);
 int tmdiff_conv3d_wino_fwd(const tmdiff_conv3d_desc* d, void* workspace, tmdiff_stream_t stream);
@@ -191,6 +192,21 @@ int tmdiff_conv3d_wino_fwd_xp(const tmdiff_conv3d_desc* d, void* workspace, int3
  * has twice the tiles along the bands, so it still fills the chip where F(4,3) would not */
 int tmdiff_conv3d_wino_fwd_planes(const tmdiff_conv3d_desc* d, void* workspace, int32_t stage, float* xp_out, int32_t planes,
                                   tmdiff_stream_t stream);
+
+/* ---- 3x3x3 convolution, Winograd F(4,3) along the band axis with the input transform INSIDE the kernel -----------
+ * (csrc/conv3d_wf.hip).  The whole band axis lies in one workgroup (N = 8: two tiles, N = 4: one), the kernel reads the plain
+ * convolution input and forms v = B^T d in LDS between its MFMAs: no transformed copy of the input in HBM, no transform
+ * pass.  Same descriptor and epilogue as tmdiff_conv3d_fwd (fp32, groups 1 or 3, N = 8 or 4, W % 4 == 0, Cin/groups % 2 == 0,
+ * Cout/groups % 32 == 0, no mask tensor).  An input that is ONE plain tensor (no prologue / dropout: every convolution whose
+ * producer applied the consumer's prologue, every data-gradient convolution) needs no workspace; otherwise `workspace`
+ * (tmdiff_conv3d_wf_workspace_bytes(d) = the input's bytes) receives the prologue output x' first (one elementwise pass,
+ * as tmdiff_conv3d_fwd_staged).  d->w_packed = tmdiff_conv3d_wino_pack_weights(..., mode | 2, planes 6): the same
+ * transformed weights in natural column order.  Replaces, for the Python reference, the F.conv3d / nn.Conv3d calls of
+ * GeneralModel/Hyper_unet_general.py:51-77, :161-164, :224-227, :344-361 on 8- and 4-band tensors. */
+int tmdiff_conv3d_wf_supported(const tmdiff_conv3d_desc* d);
+int64_t tmdiff_conv3d_wf_blocks(const tmdiff_conv3d_desc* d);     /* workgroups of its grid (no split-K: keep small grids on tmdiff_conv3d_fwd) */
+size_t tmdiff_conv3d_wf_workspace_bytes(const tmdiff_conv3d_desc* d);
+int tmdiff_conv3d_wf_fwd(const tmdiff_conv3d_desc* d, void* workspace, tmdiff_stream_t stream);
 
 /* ---- bf16 compute / fp32 accumulate (WorldView-3 inference) --------------------------
  * Same descriptor and fused prologue / epilogue as tmdiff_conv3d_fwd; activations, bias, residual and output stay

@@ -102,6 +102,17 @@ class GeneralDiffusionRef(nn.Module):
         return self.q_posterior(x0, x, t)
 
     @torch.no_grad()
+    def p_mean_variance_xo(self, x, t, clip_denoised=True, x_in=None, prompt="QB", guidance=1.0):
+        """x0-parameterised twin (reference diffusion_general.py:173-190; called by nothing there): the network output is
+        x_0 itself -- clamp, then the posterior."""
+        b = x.shape[0]
+        time_in = torch.full((b, 1), t + 1, device=x.device, dtype=torch.long)
+        x0 = self.denoise_fn(x, time_in, x_in["PAN"], x_in["MS"], prompt)
+        if clip_denoised:
+            x0 = x0.clamp(-1.0, 1.0)
+        return self.q_posterior(x0, x, t)
+
+    @torch.no_grad()
     def p_sample(self, x, t, clip_denoised=True, condition_x=None, prompt="QB", guidance=1.0):
         mean, logvar = self.p_mean_variance(x, t, clip_denoised, condition_x, prompt, guidance)
         noise = self.noise_fn(x) if t > 0 else torch.zeros_like(x)

@@ -252,6 +252,20 @@ def main():
         arrs[f"T{T}_last_only"] = diff.p_sample_loop(d, continous=False, prompt="WV3")
     save("ddpm", **arrs)
 
+    # ---- (9a) one reverse step through p_mean_variance and its x0-parameterised twin p_mean_variance_xo (:154-190) ------
+    diff = RD.GeneralDiffusion(net, loss_type="l1")
+    diff.set_new_noise_schedule({"schedule": "cosine", "n_timestep": 50}, "cpu")
+    d = case_inputs(160, 2, 8, 16)
+    arrs = {}
+    for t in (0, 17, 49):
+        m, lv = diff.p_mean_variance(d["x_t"].clone(), t, clip_denoised=True, x_in=d, prompt="WV3")
+        arrs[f"t{t}_mean"], arrs[f"t{t}_logvar"] = m, lv
+        m, lv = diff.p_mean_variance_xo(d["x_t"].clone(), t, clip_denoised=True, x_in=d, prompt="WV3")
+        arrs[f"t{t}_xo_mean"], arrs[f"t{t}_xo_logvar"] = m, lv
+    m, _ = diff.p_mean_variance_xo(d["x_t"].clone() * 3.0, 17, clip_denoised=False, x_in=d, prompt="GF2")
+    arrs["t17_xo_mean_unclipped"] = m
+    save("ddpm_xo", **arrs)
+
     # ---- (9b) the full T = 1000 chain of BASELINE config 2 (one tile; ~2 min of reference CPU time) -----------------
     if not ONLY or "ddpm1000" in ONLY:
         diff = RD.GeneralDiffusion(net, loss_type="l1")
@@ -259,6 +273,34 @@ def main():
         d = case_inputs(77, 1, 8, 16)
         torch.manual_seed(1000)
         save("ddpm1000", last_only=diff.p_sample_loop(d, continous=False, prompt="WV3"))
+
+    # ---- (9c) FULL-width chains (ch 32-256): the widths at which the production kernels of the HIP path engage (Winograd
+    # along the bands needs Cout % 32 == 0, the composed Conv_0 + LL convolution Cout % 64 == 0 -- the TINY-width chains
+    # above can only reach the direct kernels).  T = 50 on two 8x32x32 tiles, T = 1000 and the 31-NFE DPM-Solver++ on one
+    # 8x16x16 tile: ~4 min of reference CPU time. ------------------------------------------------------------------------
+    if not ONLY or "chains_full" in ONLY:
+        arrs = {}
+        netF = fill_weights_(RU.WavBEST(channels=FULL)).eval()
+        diff = RD.GeneralDiffusion(netF, loss_type="l1")
+        diff.set_new_noise_schedule({"schedule": "cosine", "n_timestep": 50}, "cpu")
+        d = case_inputs(171, 2, 8, 32)
+        torch.manual_seed(50)
+        arrs["T50_last_only"] = diff.p_sample_loop(d, continous=False, prompt="WV3")
+        torch.manual_seed(50)
+        stack = diff.super_resolution(d, False, "WV3", 3.0)       # prompt slip: runs "QB", returns the stack
+        arrs["T50_stack_shape"], arrs["T50_stack_final"] = np.asarray(stack.shape), stack[-2:]
+        print("chains_full: T=50 done", flush=True)
+        diff = RD.GeneralDiffusion(netF, loss_type="l1")
+        diff.set_new_noise_schedule({"schedule": "cosine", "n_timestep": 1000}, "cpu")
+        d = case_inputs(172, 1, 8, 16)
+        torch.manual_seed(1001)
+        arrs["T1000_last_only"] = diff.p_sample_loop(d, continous=False, prompt="WV3")
+        print("chains_full: T=1000 done", flush=True)
+        d = case_inputs(173, 1, 8, 16)
+        torch.manual_seed(11)
+        arrs["dpm_out"] = diff.sample_by_dpmsolver(d, "WV3")
+        save("chains_full", **arrs)
+        del netF
 
     # ---- (10) DPM-Solver++ ------------------------------------------------------------------
     arrs = {}

@@ -252,3 +252,77 @@ def test_ragged_tile_sizes_vs_oracle(channels, b, c, h, w):
         y_ref = ora.p_sample(d["x_t"], 57, condition_x=d, prompt="QB")
     y = diff.p_sample(dc["x_t"], 57, condition_x=dc, prompt="QB").cpu()
     assert_close(y, y_ref, 1e-4, 1e-5, "DDPM step on a ragged tile")
+
+
+def test_config4_finetune_step_vs_oracle_autograd():
+    """the full-size training check above is a property (batch-8 gradient == mean of half-batch
+    gradients) and had to use the L2 loss.  This is the direct measurement: local batch 8 of 8x64x64 tiles, ch 32-256,
+    dropout off, the SAME timesteps and noise on both sides -- the loss under the config's L1 (1e-5) and, under L2 (whose
+    gradient is continuous in the residual), named parameter gradients ELEMENTWISE against the oracle's CPU autograd
+    (reference Hyper_unet_general.py:334-414, diffusion_general.py:349-370).  At this size the forward and data-gradient
+    convolutions run on the Winograd kernels, Conv_0 + LL on the composed kernel."""
+    import collections
+    from tmdiff_amd import ops
+    from tmdiff_amd.diffusion_general import GeneralDiffusion
+    B = 8
+    ref_net = U.fill_weights_(U.WavBESTRef(channels=FULL)).eval()
+    net = _hip_net(FULL)
+    net.eval()
+    d = case_inputs(3420, B, 8, 64)
+    noise = randn(3421, B, 8, 64, 64)
+    times = np.random.RandomState(7).randint(1, 1001, size=B)
+    orig = np.random.randint
+    np.random.randint = lambda lo, hi, size: times
+    names = ["up1.up1.convH_0.0.weight", "down1.down.Conv_0.weight", "final.conv24.weight", "conv2.conv21.weight",
+             "down2_1.conv20.conv21.weight", "down3.down.Conv_1.weight", "middle1.conv20.weight", "up2.conv20.conv20.weight",
+             "up3.up1.Conv_2.weight", "final.conv21.conv20.bias", "down1.conv20.dense1.dense.weight", "embed.2.weight",
+             "final.dense2.dense.weight"]
+    try:
+        res = {}
+        for loss_type in ("l1", "l2"):
+            ora = GeneralDiffusionRef(ref_net, loss_type, noise_fn=lambda like: noise)
+            ora.set_loss("cpu")
+            ora.set_new_noise_schedule({"schedule": "cosine", "n_timestep": 1000}, "cpu")
+            ref_net.zero_grad()
+            lo = ora(d, "WV3")
+            if loss_type == "l2":
+                lo.backward()
+            diff = GeneralDiffusion(net, loss_type, noise_fn=lambda like: cu(noise)).cuda()
+            diff.set_loss("cuda")
+            diff.set_new_noise_schedule({"schedule": "cosine", "n_timestep": 1000}, "cuda")
+            net.zero_grad()
+            counts = ops.COUNTS = collections.Counter()
+            try:
+                lh = diff({k: cu(v) for k, v in d.items()}, "WV3")
+                if loss_type == "l2":
+                    lh.backward()
+            finally:
+                ops.COUNTS = None
+            res[loss_type] = (float(lo), float(lh), dict(counts))
+    finally:
+        np.random.randint = orig
+    for lt, (lo, lh, _) in res.items():
+        assert abs(lo - lh) <= 1e-5 * abs(lo), (lt, lo, lh)
+    cnt = res["l2"][2]
+    assert (cnt.get("conv3d_wf_fwd", 0) + cnt.get("conv3d_wino4_fwd", 0) + cnt.get("conv3d_wino2_fwd", 0) >= 40 and
+            cnt.get("conv3d_ll_fwd", 0) == 3), cnt
+    ref_g = dict(ref_net.named_parameters())
+    hip_g = dict(net.named_parameters())
+    report = []
+    for k in names:
+        m, l2 = rel_err(hip_g[k].grad, ref_g[k].grad)
+        report.append((m, l2, k))
+    print("full-size L2 gradients vs the oracle's autograd (max-rel, rel-L2):")
+    for m, l2, k in sorted(report, reverse=True):
+        print(f"  {m:.2e} {l2:.2e} {k}")
+    assert max(r[0] for r in report) <= 3e-5 and max(r[1] for r in report) <= 3e-5, sorted(report, reverse=True)[:3]
+    # and every other gradient by its sums (all 216)
+    n = 0
+    for k, p in hip_g.items():
+        if p.grad is None:
+            assert ref_g[k].grad is None, k
+            continue
+        n += 1
+        m, l2 = rel_err(p.grad, ref_g[k].grad)
+        assert l2 <= 1e-4, (k, m, l2)
+    assert n == 272 - 56

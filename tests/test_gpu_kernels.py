@@ -603,6 +603,14 @@ def test_conv3d_ll_is_conv_then_halved_ll_band(ops, case):
     (1, (6,), 32, 4, 12, 20, 1),          # 32-channel tiles, ragged in t / h / w, odd chunk count
     (1, (8, 8, 8), 96, 6, 8, 12, 1),      # three segments (concat-free), Cout = 96, three pairs (ragged in t)
     (2, (4, 4, 4), 192, 4, 8, 8, 3),      # groups = 3 (convH_0): one segment per group, 64 output channels each
+    # F(4,3) (N % 4 == 0, at least two tiles along the bands):
+    (1, (8,), 32, 8, 16, 32, 1),          # the 32-channel tile (8 x 16 positions), whole tiles
+    (1, (6,), 32, 8, 12, 20, 1),          # 32-channel tile, ragged in h and w, odd chunk count
+    (1, (6,), 64, 8, 12, 20, 1),          # 64-channel tile, ragged in h and w
+    (1, (8, 8, 8), 64, 8, 8, 12, 1),      # three segments (the up path's conv20)
+    (2, (4, 4, 4), 192, 8, 8, 8, 3),      # groups = 3 at N = 8 (convH_0 of a WV3 batch)
+    (1, (4,), 64, 12, 8, 8, 1),           # N = 12: three tiles, the second tile of the last workgroup is empty
+    (1, (4,), 32, 16, 8, 16, 1),          # N = 16: two workgroups along the bands
 ])
 def test_conv3d_winograd_along_bands(ops, case):
     """tmdiff_conv3d_wino_fwd: Winograd F(4,3) (N % 4 == 0) / F(2,3) along the band axis (input transform pass with the
@@ -645,6 +653,99 @@ def test_conv3d_winograd_along_bands(ops, case):
     # a grid too small for the kernel (no split-K) or an odd band count goes to the fallback
     marker = object()
     assert ops.conv3d_wino([cu(s_[:, :, :N - 1]) for s_ in segs], wp, cout, groups=groups, fallback=lambda: marker) is marker
+
+
+@pytest.mark.parametrize("case", [
+    # B, segs, Cout, N, H, W, groups
+    (2, (8,), 64, 8, 16, 16, 1),          # whole tiles (8 x 16 positions x 2 band tiles), two channel tiles
+    (1, (6,), 32, 8, 12, 20, 1),          # ragged in h and w (W = 20: the second tile has one quad), odd chunk count
+    (1, (2,), 32, 8, 8, 16, 1),           # a single chunk
+    (1, (8, 8, 8), 96, 8, 8, 12, 1),      # three segments (prologue pass = the concatenation), three channel tiles
+    (2, (4, 4, 4), 192, 8, 8, 16, 3),     # groups = 3 (convH_0)
+    (2, (8,), 64, 4, 32, 32, 1),          # N = 4 (GF-2 / QuickBird): one band tile, 16 x 16 positions
+    (1, (6,), 32, 4, 20, 24, 1),          # N = 4, ragged
+    (1, (4, 4, 4), 96, 4, 16, 16, 3),     # N = 4, groups = 3
+    (3, (64,), 64, 8, 32, 32, 1),         # 32 chunks, several workgroups per image
+])
+def test_conv3d_winograd_in_kernel_transform(ops, case):
+    """tmdiff_conv3d_wf_fwd: Winograd F(4,3) along the bands with the input transform inside the kernel (no transformed
+    copy of the input): plain input, prologue / segments (through the prologue pass), bias, residual, scale and second
+    output, against the CPU convolution (fp64), the direct HIP kernel and the transform-pass Winograd kernel; the
+    data-gradient weights against CPU autograd."""
+    B, segc, cout, N, H, W, groups = case
+    cin = sum(segc)
+    torch.manual_seed(77 + cout + N)
+    segs = [torch.randn(B, c, N, H, W) for c in segc]
+    x = torch.cat(segs, 1)
+    w, bias = torch.randn(cout, cin // groups, 3, 3, 3) / (cin // groups * 27) ** 0.5, torch.randn(cout)
+    sh, sc = torch.randn(B, cin) * 0.3, torch.rand(B, cin) + 0.5
+    res = torch.randn(B, cout, N, H, W)
+    sh2, sc2 = torch.randn(B, cout) * 0.3, torch.rand(B, cout) + 0.5
+    wp = ops.pack_conv_weight_wino(cu(w), groups=groups, mode=2, planes=6)
+    want = F.conv3d(x.double(), w.double(), bias.double(), padding=1, groups=groups).float()
+    y = ops.conv3d_wf([cu(x)], wp, cout, bias=cu(bias), groups=groups)                     # one plain tensor: no pass at all
+    assert_close(y, want, 2e-5, 2e-6, "wf, plain input")
+    y = ops.conv3d_wf([cu(s_) for s_ in segs], wp, cout, bias=cu(bias), groups=groups)     # segments: prologue pass
+    assert_close(y, want, 2e-5, 2e-6, "wf, segments")
+    xs = x.double() + sh[:, :, None, None, None].double()
+    xs = xs * torch.sigmoid(xs) * sc[:, :, None, None, None].double()
+    want = ((F.conv3d(xs, w.double(), bias.double(), padding=1, groups=groups) + res.double()) * 0.7071).float()
+    v = want + sh2[:, :, None, None, None]
+    want2 = v * torch.sigmoid(v) * sc2[:, :, None, None, None]
+    kw = dict(bias=cu(bias), in_shift=cu(sh), in_scale=cu(sc), in_act=True, residual=cu(res), out_scale=0.7071, groups=groups)
+    y, y2 = ops.conv3d_wf([cu(s_) for s_ in segs], wp, cout, emit=dict(act=True, shift=cu(sh2), scale=cu(sc2)), **kw)
+    assert_close(y, want, 2e-5, 2e-6, "wf, prologue + residual")
+    assert_close(y2, want2, 2e-5, 2e-6, "wf, second output")
+    only = ops.conv3d_wf([cu(s_) for s_ in segs], wp, cout, emit=dict(act=True, shift=cu(sh2), scale=cu(sc2)), keep_y=False, **kw)
+    assert torch.equal(only, y2)
+    direct = ops.conv3d([cu(s_) for s_ in segs], ops.pack_conv_weight(cu(w), groups=groups), cout, 3, **kw)
+    assert_close(y, direct.cpu(), 1e-5, 2e-6, "wf vs the direct kernel")
+    old = ops.conv3d_wino([cu(s_) for s_ in segs], ops.pack_conv_weight_wino(cu(w), groups=groups, planes=ops.wino_planes(N)), cout, **kw)
+    assert_close(y, old.cpu(), 1e-5, 2e-6, "wf vs the transform-pass Winograd kernel")
+    # in-kernel dropout of the prologue output (finetune path) and the kept x'
+    xp = torch.empty(B, cin, N, H, W, device="cuda")
+    yd = ops.conv3d_wf([cu(s_) for s_ in segs], wp, cout, in_shift=cu(sh), in_act=True, drop=(1234, 0.2), groups=groups, xp_out=xp)
+    dd = ops.conv3d([cu(s_) for s_ in segs], ops.pack_conv_weight(cu(w), groups=groups), cout, 3, groups=groups, in_shift=cu(sh),
+                    in_act=True, drop=(1234, 0.2))
+    assert 0.1 < float((xp == 0).float().mean()) < 0.3
+    assert_close(yd, dd.cpu(), 1e-5, 2e-6, "wf vs the direct kernel, dropout")
+    # data-gradient weights (mode bit 0) in natural column order
+    g = torch.randn(B, cout, N, H, W)
+    with torch.enable_grad():
+        xg = x.double().requires_grad_(True)
+        F.conv3d(xg, w.double(), None, padding=1, groups=groups).backward(g.double())
+    if (cout // groups) % 2 == 0 and (cin // groups) % 32 == 0:
+        dx = ops.conv3d_wf([cu(g)], ops.pack_conv_weight_wino(cu(w), groups=groups, mode=3, planes=6), cin, groups=groups)
+        assert_close(dx, xg.grad.float(), 2e-5, 2e-6, "wf data gradient vs CPU autograd")
+    # an odd band count / a mask tensor goes to the fallback
+    marker = object()
+    assert ops.conv3d_wf([cu(x[:, :, :N - 1])], wp, cout, groups=groups, fallback=lambda: marker) is marker
+
+
+@pytest.mark.parametrize("case", [
+    # B, Cin, Cout, N, H, W, groups   (of the FORWARD convolution whose data gradient is taken)
+    (2, 32, 64, 8, 16, 16, 1),            # F(4,3), 32-channel tile of the gradient convolution (Cin = 32 outputs)
+    (1, 64, 32, 8, 12, 20, 1),            # F(4,3), 64-channel tile, ragged
+    (1, 64, 64, 4, 8, 16, 1),             # F(2,3)
+    (1, 96, 192, 8, 8, 8, 3),             # groups = 3
+])
+def test_conv3d_winograd_data_gradient_weights(ops, case):
+    """mode-1 packing of tmdiff_conv3d_wino_pack_weights: the Winograd weights of the DATA-GRADIENT convolution (transposed,
+    taps mirrored) straight from the forward weight -- against CPU autograd's grad_input (fp64) and the direct kernel on
+    the direct data-gradient packing."""
+    B, cin, cout, N, H, W, groups = case
+    torch.manual_seed(5 + cin + cout)
+    x = torch.randn(B, cin, N, H, W, dtype=torch.float64, requires_grad=True)
+    w = torch.randn(cout, cin // groups, 3, 3, 3) / (cin // groups * 27) ** 0.5
+    g = torch.randn(B, cout, N, H, W)
+    with torch.enable_grad():             # (the module's fixture runs every test under no_grad)
+        F.conv3d(x, w.double(), None, padding=1, groups=groups).backward(g.double())
+    want = x.grad.float()
+    wp1 = ops.pack_conv_weight_wino(cu(w), groups=groups, mode=1, planes=ops.wino_planes(N))
+    dx = ops.conv3d_wino([cu(g)], wp1, cin, groups=groups)
+    assert_close(dx, want, 2e-5, 2e-6, "winograd data gradient vs CPU autograd")
+    direct = ops.conv3d([cu(g)], ops.pack_conv_weight(cu(w), groups=groups, mode=1), cin, 3, groups=groups)
+    assert_close(dx, direct.cpu(), 1e-5, 2e-6, "winograd data gradient vs the direct kernel")   # (F(4,3): 1e-6 vs fp64 by itself)
 
 
 def test_conv3d_large_plane_config3_shape(ops):

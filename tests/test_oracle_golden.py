@@ -217,6 +217,37 @@ def test_ddpm_sampling(golden, tiny_net, T):
     assert_close(diff.p_sample_loop(d, continous=False, prompt="WV3"), g[f"T{T}_last_only"], 2e-4, 2e-4, "last")
 
 
+def test_p_mean_variance_and_its_x0_twin(golden, tiny_net):
+    """One reverse step through p_mean_variance and p_mean_variance_xo (reference diffusion_general.py:154-190)."""
+    g = golden("ddpm_xo")
+    diff = GeneralDiffusionRef(tiny_net, "l1")
+    diff.set_new_noise_schedule({"schedule": "cosine", "n_timestep": 50}, "cpu")
+    d = case_inputs(160, 2, 8, 16)
+    for t in (0, 17, 49):
+        m, lv = diff.p_mean_variance(d["x_t"].clone(), t, clip_denoised=True, x_in=d, prompt="WV3")
+        assert_close(m, g[f"t{t}_mean"], 5e-5, 3e-6, f"mean t={t}")      # (t = T - 1 amplifies eps by sqrt(1/acp - 1) ~ 1e3 before the clamp)
+        assert np.allclose(np.asarray(lv), g[f"t{t}_logvar"], rtol=1e-6)
+        m, lv = diff.p_mean_variance_xo(d["x_t"].clone(), t, clip_denoised=True, x_in=d, prompt="WV3")
+        assert_close(m, g[f"t{t}_xo_mean"], 5e-5, 3e-6, f"xo mean t={t}")
+        assert np.allclose(np.asarray(lv), g[f"t{t}_xo_logvar"], rtol=1e-6)
+    m, _ = diff.p_mean_variance_xo(d["x_t"].clone() * 3.0, 17, clip_denoised=False, x_in=d, prompt="GF2")
+    assert_close(m, g["t17_xo_mean_unclipped"], 3e-6, 3e-6, "xo mean, unclipped")
+
+
+def test_full_width_chains_vs_reference(golden):
+    """The oracle against the reference's full-width (ch 32-256) chains of section 9c: T = 50 on two 8x32x32 tiles."""
+    from tmdiff_amd.util import psnr
+    g = golden("chains_full")
+    net = U.fill_weights_(U.WavBESTRef(channels=[32, 64, 128, 256])).eval()
+    diff = GeneralDiffusionRef(net, "l1")
+    diff.set_new_noise_schedule({"schedule": "cosine", "n_timestep": 50}, "cpu")
+    torch.manual_seed(50)
+    with torch.no_grad():
+        got = diff.p_sample_loop(case_inputs(171, 2, 8, 32), continous=False, prompt="WV3")
+    want = torch.tensor(g["T50_last_only"])
+    assert (got - want).abs().max() <= 2e-4 and psnr(got, want) >= 70.0, ((got - want).abs().max(), psnr(got, want))
+
+
 def test_ddpm_1000_step_chain(golden, tiny_net):
     """The oracle against the reference's full T = 1000 chain (one tile, ~1 min of CPU): the amplification of per-step
     rounding near t = T that SURVEY 8(d) budgets 50 dB for is ~1e-5 between two CPU implementations."""

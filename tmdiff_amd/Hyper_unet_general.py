@@ -398,8 +398,16 @@ class WavBEST(nn.Module):
             if planes not in ww:
                 ww[planes] = ops.pack_conv_weight_wino(m.weight.detach().float().contiguous(), groups=m.groups, planes=planes)
             return ww[planes]
-        return ops.conv3d_wino(segs, None, m.out_channels, bias=bias, bias_scale=bias_scale, fallback=direct, groups=m.groups,
-                               w_packed_fn=packed, **kw)
+        def packed_wf():          # the F(4,3) weights in natural column order (conv3d_wf's 32-channel tiles)
+            if "wf" not in ww:
+                ww["wf"] = ops.pack_conv_weight_wino(m.weight.detach().float().contiguous(), groups=m.groups, mode=2, planes=6)
+            return ww["wf"]
+        wino = lambda: ops.conv3d_wino(segs, None, m.out_channels, bias=bias, bias_scale=bias_scale, fallback=direct,
+                                       groups=m.groups, w_packed_fn=packed, **kw)
+        # 8- / 4-band tensors: the Winograd kernel that transforms its input in LDS (no transform pass); other even band
+        # counts: transform pass + kernel; small grids and odd band counts: the direct kernels
+        return ops.conv3d_wf(segs, None, m.out_channels, bias=bias, bias_scale=bias_scale, fallback=wino, groups=m.groups,
+                             w_packed_fn=packed_wf, **kw)
 
     @staticmethod
     def _shift(P, S, name):

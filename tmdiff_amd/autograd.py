@@ -60,9 +60,14 @@ class _FusedConv3d(torch.autograd.Function):
         # 3x3x3 convolutions (in-kernel dropout included): Winograd F(2,3) along the band axis (1.5x fewer multiply-adds), where its grid
         # fills the chip -- otherwise, and for everything else, the direct kernels
         if _WINOGRAD and mask is None and ops.wino_conv_supported(cout, cin, ksize, groups):
-            y = ops.conv3d_wino(segs, None, cout, bias=bias, bias_scale=bias_scale, in_shift=shift, in_scale=scale,
-                                in_act=act, drop=drop, residual=residual, out_scale=out_scale, groups=groups, fallback=direct,
-                                xp_out=xp, w_packed_fn=lambda planes: ops.pack_conv_weight_wino(w, groups, planes=planes))
+            kw = dict(bias=bias, bias_scale=bias_scale, in_shift=shift, in_scale=scale, in_act=act, drop=drop, residual=residual,
+                      out_scale=out_scale, groups=groups, xp_out=xp)
+            wino = lambda: ops.conv3d_wino(segs, None, cout, fallback=direct,
+                                           w_packed_fn=lambda planes: ops.pack_conv_weight_wino(w, groups, planes=planes), **kw)
+            # 8- / 4-band tensors: the kernel that transforms its input in LDS (its prologue pass writes x' where the weight
+            # gradient will read it); other even band counts: transform pass + kernel
+            y = ops.conv3d_wf(segs, None, cout, fallback=wino,
+                              w_packed_fn=lambda: ops.pack_conv_weight_wino(w, groups, mode=2, planes=6), **kw)
         else:
             y = direct()
         ctx.meta = meta
@@ -115,8 +120,10 @@ class _FusedConv3d(torch.autograd.Function):
             wp_t = ctx.wp_dgrad if ctx.wp_dgrad is not None else ops.pack_conv_weight(w, groups=groups, mode=1)
             direct = lambda: ops.conv3d([g], wp_t, cin, ksize, groups=groups)
             if _WINOGRAD and ops.wino_conv_supported(cin, cout, ksize, groups):   # the data gradient is a 3x3x3 convolution too
-                gp = ops.conv3d_wino([g], None, cin, groups=groups, fallback=direct,
-                                     w_packed_fn=lambda planes: ops.pack_conv_weight_wino(w, groups, mode=1, planes=planes))
+                wino = lambda: ops.conv3d_wino([g], None, cin, groups=groups, fallback=direct,
+                                               w_packed_fn=lambda planes: ops.pack_conv_weight_wino(w, groups, mode=1, planes=planes))
+                gp = ops.conv3d_wf([g], None, cin, groups=groups, fallback=wino,      # (a plain input: no pass at all)
+                                   w_packed_fn=lambda: ops.pack_conv_weight_wino(w, groups, mode=3, planes=6))
             else:
                 gp = direct()                                                    # dL/dx'
             outs = [torch.empty_like(s) if need[7 + i] else None for i, s in enumerate(segs)]

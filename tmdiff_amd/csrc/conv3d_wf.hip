@@ -1,0 +1,466 @@
+// 3x3x3 convolution, Winograd F(4,3) along the band axis, with the INPUT TRANSFORM INSIDE THE KERNEL ("wf"): the kernel
+// reads the plain convolution input x' (prologue already applied by its producer) -- there is no transformed copy V of the
+// input in HBM and no transform pass in front of the convolution (conv3d_wino.hip has both: 4 B read + 6.6 B written per
+// input element and launch, 10 % of the benchmark step).
+//
+// Mathematics as conv3d_wino.hip: for a tile of 4 output bands and its 6 input bands d (one band of halo either side, zero
+// outside the image), v = B^T d per element, u = G g per (ci, co, dh, dw), m_k = sum_{ci,dh,dw} u_k v_k (six 3x3 convolutions
+// in (h, w)), y = A^T m: 54 instead of 4 x 27 multiply-adds.  The whole band axis lies inside one workgroup (N = 8: two
+// tiles; N = 4: one), so the band halo never crosses workgroups.
+//
+// Workgroup = 256 threads = 4 waves, 256 output positions (TT tiles x TH x TW) x 32 output channels; two workgroups per CU.
+// Every wave holds ALL six planes of its 64 positions (2 sub-tiles of 32) = 12 accumulators, so the output transform
+// y = A^T m happens in registers: no exchange between waves, no barrier after the last chunk, every wave runs the shared
+// dwordx4 epilogue on its own.
+//
+// Per chunk of KC = 2 input channels, LDS holds
+//   raw  [region (kc, row)][band][RW]   the haloed box of x' itself: rows h0-1 .. h0+TH, columns w0-4 .. w0+TW+3 (the aligned
+//                                       superset of w0-1 .. w0+TW: 16-byte LDS-DMA pieces, whole quads inside or outside
+//                                       the image, no bounds checks inside a quad), ONE buffer;
+//   V    [kc][tile][plane][row][PW]     its transform (columns w0-1 .. w0+TW), two stages;
+//   U    [kc][(dh,dw)][plane][32]       the weight slab, two stages (LDS-DMA).
+// While the MFMAs of chunk c run from stage c % 2, each wave (1) transforms the regions of raw(c+1) that IT fetched into V of
+// the other stage -- 6 ds_read_b128, ~90 VALU operations and 24 ds_write_b32 per wave and chunk, placed between the MFMAs --
+// then (2) requests raw(c+2) into the same regions, and (3) requests the weights of chunk c+1.  A region is written (DMA) and
+// read (transform) by one wave only, so the single raw buffer needs no barrier of its own: one barrier per chunk.
+#include <cstdlib>
+#include <type_traits>
+
+#include "common.h"
+#include "epilogue.h"
+
+#ifndef TMDIFF_WF_STAMPS
+#define TMDIFF_WF_STAMPS 0       // diagnostic build: per-wave s_memrealtime stamps (tools/wino_stamps.py)
+#endif
+
+namespace {
+
+using f32x16 = __attribute__((ext_vector_type(16))) float;
+
+template <int B, int E, class F>
+__device__ __forceinline__ void static_for(F&& f) {
+  if constexpr (B < E) {
+    f(std::integral_constant<int, B>{});
+    static_for<B + 1, E>(f);
+  }
+}
+
+struct WfArgs {
+  int B, N, H, W;
+  int Cin, Cout, cin_g, cout_g, groups;
+  const float* x;       // x' [B, Cin, N, H, W]
+  const float* wp;      // U packed [g][ci][9][6][co], natural column order (tmdiff_conv3d_wino_pack_weights, mode | 2)
+  const float* bias;
+  float bias_scale;
+  const float* residual;
+  float out_scale;
+  float* y;
+  float* y2;
+  const float* y2_shift;
+  const float* y2_scale;
+  int y2_shift_stride, y2_scale_stride, y2_act;
+  int tiles_h, tiles_w, tiles_co;
+  unsigned total_blocks;
+  int vec4;
+  unsigned long long* stamps;
+  int stagger;
+  unsigned first_round;
+};
+
+// LDS-DMA through a buffer descriptor: 16 bytes per lane from base + voff (bytes) to dst + 16 * lane.  An offset at or beyond
+// the descriptor's size -- kOutside -- reads as zero: the zero padding of the convolution costs a select, not a second
+// source pointer (the address is one 32-bit register per lane; the base lives in scalar registers).
+constexpr unsigned kOutside = 0xFFFFFFF0u;
+// The compiler hoists every address that does not change from chunk to chunk out of the chunk loop and then, with 192 of the
+// 256 registers holding accumulators, spills it -- a scratch reload (and its vmcnt(0), which also waits for the LDS-DMA in
+// flight) in the middle of the MFMA stream.  opaque() hides a value's loop invariance: the few VALU operations that derive an
+// address from it are redone where they are used.
+template <class T>
+__device__ __forceinline__ T opaque(T v) {
+  asm volatile("" : "+v"(v));
+  return v;
+}
+#if defined(__HIP_DEVICE_COMPILE__)  // the builtins exist in the device pass only
+using buf_rsrc = __amdgpu_buffer_rsrc_t;
+__device__ __forceinline__ buf_rsrc make_rsrc(const float* base, unsigned bytes) {
+  return __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(base), 0, bytes, 0x00020000);
+}
+__device__ __forceinline__ void dma_b128(buf_rsrc r, unsigned voff, float* dst) {
+  __builtin_amdgcn_raw_ptr_buffer_load_lds(r, dst, 16, voff, 0, 0, 0);
+}
+#else
+struct buf_rsrc {};
+__device__ __forceinline__ buf_rsrc make_rsrc(const float*, unsigned) { return {}; }
+__device__ __forceinline__ void dma_b128(buf_rsrc, unsigned, float*) {}
+#endif
+
+__device__ __forceinline__ unsigned xcd_remap(unsigned bid, unsigned nwg) {
+  const unsigned q = nwg / 8, r = nwg % 8, xcd = bid % 8, k = bid / 8;
+  return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + k;
+}
+
+// see conv3d_wino.hip: the second resident workgroup of a CU (LDS allocation not at 0) may wait once (experiments)
+__device__ __forceinline__ void stagger_start(int cycles, unsigned first_round) {
+  if (cycles <= 0 || blockIdx.x >= first_round) return;
+  const unsigned lds_alloc = __builtin_amdgcn_s_getreg(6 | (0 << 6) | (11 << 11));
+  if (lds_alloc == 0) return;
+  const unsigned long long t0 = __builtin_amdgcn_s_memtime();
+  while ((long long)(__builtin_amdgcn_s_memtime() - t0) < (long long)cycles) __builtin_amdgcn_s_sleep(32);
+}
+
+template <int TT, int TH, int TW>
+struct GeoF {
+  static constexpr int NP = 6, MO = 4, NB = TT * MO, KC = 2, CO = 32, NS = 2;
+  static constexpr int HH = TH + 2;
+  static constexpr int RW = TW + 8, RQ = RW / 4;          // raw row: columns w0-4 .. w0+TW+3 as RQ aligned quads
+  static constexpr int PW = TW + 2;                       // V row: columns w0-1 .. w0+TW
+  static constexpr int REG_QUADS = NB * RQ;               // one region = (kc, row): every band's raw row
+  static constexpr int RPP = 48 / REG_QUADS;              // regions per 48-lane DMA piece
+  static constexpr int NREG = KC * HH;
+  static constexpr int XP = (NREG + RPP - 1) / RPP;       // raw pieces per chunk
+  static constexpr int XK = (XP + 3) / 4;                 // ... per wave
+  static constexpr int PSTRIDE = 196;                     // floats between pieces (192 + 4: consecutive pieces of a wave 16 banks apart)
+  static constexpr int RAW_FLOATS = XP * PSTRIDE;
+  static constexpr int V_ELEMS = TT * NP * HH * PW;       // one channel
+  static constexpr int V_FLOATS = KC * V_ELEMS;
+  static constexpr int W_TAPS = 9 * NP;
+  static constexpr int W_FLOATS = KC * W_TAPS * CO;
+  static constexpr int W_UNITS = W_FLOATS / 4;
+  static constexpr int WP = (W_UNITS + 63) / 64, WK = (WP + 3) / 4;
+  static constexpr int STAGE = V_FLOATS + WP * 256;
+  static constexpr int TASKS = 12;                        // transform tasks per piece: RPP regions x TT tiles x RQ quads
+  static_assert(REG_QUADS * RPP == 48, "a piece is 48 lanes of whole regions");
+  static_assert(RPP * TT * RQ == TASKS && XK * TASKS <= 64, "one transform task per lane");
+  static_assert(TT * TH * TW == 4 * NS * 32, "4 waves x NS sub-tiles x 32 positions");
+  static_assert(TW == 16, "a sub-tile is two rows of 16 positions");
+  static_assert(V_FLOATS % 4 == 0, "stage alignment");
+};
+
+template <int TT, int TH, int TW>
+__global__ void __launch_bounds__(256, 2) conv3d_wf_kernel(const WfArgs a) {
+  using G = GeoF<TT, TH, TW>;
+  constexpr int NP = G::NP, MO = G::MO, NB = G::NB, KC = G::KC, CO = G::CO, NS = G::NS, HH = G::HH, RQ = G::RQ, PW = G::PW;
+  constexpr int W_TAPS = G::W_TAPS;
+  __shared__ __attribute__((aligned(16))) float lds[2 * G::STAGE + G::RAW_FLOATS + 64];
+  float* const st0 = lds;
+  float* const st1 = lds + G::STAGE;
+  float* const raw = lds + 2 * G::STAGE;
+  float* const dummy = raw + G::RAW_FLOATS;      // 64 floats nobody reads: where a lane's out-of-range transform results go
+  static_assert(2 * G::STAGE + G::RAW_FLOATS >= 4 * 4096, "the epilogue borrows 16 KB of LDS per wave");
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63, wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int l31 = lane & 31, khalf = lane >> 5;
+#if TMDIFF_WF_STAMPS
+  unsigned long long stamp_t[6];
+  const unsigned long long stamp_c0 = __builtin_amdgcn_s_memtime();
+  stamp_t[0] = __builtin_amdgcn_s_memrealtime();
+#define WF_STAMP(i) stamp_t[i] = __builtin_amdgcn_s_memrealtime()
+#else
+#define WF_STAMP(i)
+#endif
+  stagger_start(a.stagger, a.first_round);
+  WF_STAMP(1);
+
+  unsigned id = xcd_remap(blockIdx.x, a.total_blocks);
+  const int co_tile = __builtin_amdgcn_readfirstlane(id % a.tiles_co); id /= a.tiles_co;
+  const int tw_i = __builtin_amdgcn_readfirstlane(id % a.tiles_w); id /= a.tiles_w;
+  const int th_i = __builtin_amdgcn_readfirstlane(id % a.tiles_h); id /= a.tiles_h;
+  const int g = __builtin_amdgcn_readfirstlane(id % a.groups);
+  const int b = __builtin_amdgcn_readfirstlane(id / a.groups);
+  const int h0 = th_i * TH, w0 = tw_i * TW;
+  const int co0 = co_tile * CO;
+  const int hw = a.H * a.W;
+  const long plane = (long)a.N * hw;                           // one channel of x' / y
+  const int nchunks = a.cin_g / KC;
+  const float* xg = a.x + ((long)b * a.Cin + (long)g * a.cin_g) * plane;
+  const float* wg = a.wp + (long)g * a.cin_g * W_TAPS * a.cout_g + co0;
+
+  // ---- DMA: raw pieces (48 lanes: RPP regions of NB bands x RQ quads) and weight pieces ------------------------------
+  // descriptors per chunk: the chunk's KC channels of x' (everything outside reads as zero) / its KC * 54 weight rows
+  const unsigned xbytes = (unsigned)(KC * plane * 4), wbytes = (unsigned)(KC * W_TAPS * a.cout_g * 4);
+  const int xq = lane % G::REG_QUADS, xsub = lane / G::REG_QUADS;          // (lanes >= 48 issue nothing)
+  const int xwq = w0 - 4 + 4 * (xq % RQ);
+  const unsigned xlane_off = (lane < 48 && xwq >= 0 && xwq < a.W) ? (unsigned)(((xq / RQ) * hw + xwq) * 4) : kOutside;
+  auto issue_raw = [&](auto kc_, int c) __attribute__((always_inline)) {
+    constexpr int k = decltype(kc_)::value;
+    const int p = wv + 4 * k;
+    if (G::XP % 4 == 0 || p < G::XP) {
+      const buf_rsrc r = make_rsrc(xg + (long)c * KC * plane, xbytes);
+      const int region = p * G::RPP + (G::RPP > 1 ? xsub : 0);
+      const int kc = region / HH, row = region - kc * HH;
+      const int h = h0 - 1 + row;
+      const bool ok = h >= 0 && h < a.H && region < G::NREG;
+      const unsigned lo = opaque(xlane_off);
+      const unsigned voff = ok ? lo + (unsigned)((kc * (int)plane + h * a.W) * 4) : kOutside;
+      if (lane < 48) dma_b128(r, lo >= kOutside ? kOutside : voff, raw + p * G::PSTRIDE);
+    }
+  };
+  const unsigned wlane_off = (unsigned)(((lane >> 3) * a.cout_g + (lane & 7) * 4) * 4);
+  auto issue_w = [&](auto kc_, int c, float* st) __attribute__((always_inline)) {
+    constexpr int k = decltype(kc_)::value;
+    const int q = wv + 4 * k;
+    if (G::WP % 4 == 0 || q < G::WP) {
+      const buf_rsrc r = make_rsrc(wg + (long)c * KC * W_TAPS * a.cout_g, wbytes);
+      // (rows beyond the chunk's slab -- the tail lanes of the last piece -- read as zero into the stage's padding)
+      dma_b128(r, opaque(wlane_off) + (unsigned)(q * 8 * a.cout_g * 4), st + G::V_FLOATS + q * 256);
+    }
+  };
+
+  // ---- input transform: lane L < XK * 12 owns task (piece L / 12 of this wave, region / tile / quad from L % 12): the four
+  // columns of its quad, one column per work item (6 ds_read_b32, 22 VALU operations, 6 ds_write_b32: nothing of the
+  // transform stays in registers between work items -- the MFMA loop has ~60 registers beside the accumulators)
+  const int tpi = lane / G::TASKS, tj = lane % G::TASKS;
+  const int tp = wv + 4 * tpi;
+  const int tsub = tj / RQ, tquad = tj % RQ;
+  const int ttile = G::RPP == 1 ? tsub : 0, trsub = G::RPP == 1 ? 0 : tsub;
+  const int tregion = tp * G::RPP + trsub;
+  const bool tvalid = tpi < G::XK && tp < G::XP && tregion < G::NREG;
+  const int tkc = tregion / HH, trow = tregion - tkc * HH;
+  // first / last input band of the tile: band -1 and band NB are the zero padding of the convolution along the bands
+  const bool tlo = ttile > 0, thi = ttile < TT - 1;
+  // raw + trd: the quad's first column in input band MO * ttile (the tile's second input band); band i of the tile at + (i - 1) * RQ * 4
+  const int trd = tvalid ? tp * G::PSTRIDE + trsub * (G::REG_QUADS * 4) + (MO * ttile) * (RQ * 4) + tquad * 4 : RQ * 4;
+  const int twr = tkc * G::V_ELEMS + (ttile * NP * HH + trow) * PW + 4 * tquad - 3;   // + k * HH * PW + column
+  // Work item e handles column (e + trot) % 4 of the lane's quad: the tasks of a wave differ in piece and tile, whose raw
+  // boxes lie a multiple of 32 banks apart -- reading the same column in all of them is a 10-way bank conflict, rotating the
+  // column by (piece, tile) makes it 2-3-way.
+  const int trot = (tpi + 2 * tsub) & 3;
+  float tin[NP];
+  auto tr_load = [&](auto ec) __attribute__((always_inline)) {      // one work item: the column's six input bands ...
+    constexpr int e = decltype(ec)::value;
+    const float* src = raw + opaque(trd) + ((e + trot) & 3);
+#pragma unroll
+    for (int i = 0; i < NP; ++i) tin[i] = src[(i - 1) * (RQ * 4)];
+  };
+  auto tr_col = [&](auto ec, float* st) __attribute__((always_inline)) {   // ... the next: its six planes
+    constexpr int e = decltype(ec)::value;
+    const int col = (e + trot) & 3;
+    const float d0 = tlo ? tin[0] : 0.f, d1 = tin[1], d2 = tin[2], d3 = tin[3], d4 = tin[4], d5 = thi ? tin[5] : 0.f;
+    float o[NP];
+    o[0] = 4.f * d0 - 5.f * d2 + d4;
+    o[1] = -4.f * d1 - 4.f * d2 + d3 + d4;
+    o[2] = 4.f * d1 - 4.f * d2 - d3 + d4;
+    o[3] = -2.f * d1 - d2 + 2.f * d3 + d4;
+    o[4] = 2.f * d1 - d2 - 2.f * d3 + d4;
+    o[5] = 4.f * d1 - 5.f * d3 + d5;
+    // V columns w0-1 .. w0+TW are raw columns 3 .. TW+4: the first quad contributes its last element only, the last its first.
+    // Unconditional stores (a branch in the MFMA stream costs the compiler its count of outstanding LDS operations): lanes
+    // without this column store into a dummy slot
+    const bool we = tvalid && (tquad > 0 || col == 3) && (tquad < RQ - 1 || col == 0);
+    float* dst = we ? st + opaque(twr) + col : dummy + lane;
+    const int kstride = we ? HH * PW : 0;
+#pragma unroll
+    for (int k = 0; k < NP; ++k) dst[k * kstride] = o[k];
+  };
+
+  // ---- per-lane MFMA operand offsets (floats inside a stage) ---------------------------------------------------------
+  // wave wv owns positions wv * 64 .. wv * 64 + 63 of the TT x TH x TW tile (w fastest): sub-tile s = two rows of 16
+  int boff[NS];
+  const int pt = (wv * 64) / (TH * TW);
+#pragma unroll
+  for (int s = 0; s < NS; ++s) {
+    const int p = wv * 64 + s * 32 + l31;
+    const int pw = p % TW, ph = (p / TW) % TH;
+    boff[s] = khalf * G::V_ELEMS + (pt * NP * HH + ph) * PW + pw;
+  }
+  const int aoff = G::V_FLOATS + khalf * W_TAPS * CO + l31;
+
+  float bias_l, sh2_l, sc2_l;
+  {
+    const int col = g * a.cout_g + co0 + l31;
+    bias_l = a.bias ? a.bias[col] * a.bias_scale : 0.f;
+    sh2_l = (a.y2 && a.y2_shift) ? a.y2_shift[(long)b * a.y2_shift_stride + col] : 0.f;
+    sc2_l = (a.y2 && a.y2_scale) ? a.y2_scale[(long)b * a.y2_scale_stride + col] : 1.f;
+  }
+
+  f32x16 acc[NP * NS];    // [k * NS + s]
+#pragma unroll
+  for (int i = 0; i < NP * NS; ++i)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[i][r] = 0.f;
+
+  // ---- first chunk: fetch, transform, and request the second chunk's raw box ------------------------------------------
+  static_for<0, G::XK>([&](auto k) __attribute__((always_inline)) { issue_raw(k, 0); });
+  static_for<0, G::WK>([&](auto k) __attribute__((always_inline)) { issue_w(k, 0, st0); });
+  __builtin_amdgcn_s_waitcnt(0x0F70);       // vmcnt(0): this wave's own pieces have landed (it reads its own regions only)
+  static_for<0, 4>([&](auto ec) __attribute__((always_inline)) { tr_load(ec); tr_col(ec, st0); });
+  static_for<0, G::XK>([&](auto k) __attribute__((always_inline)) { issue_raw(k, nchunks > 1 ? 1 : 0); });
+  __syncthreads();
+  WF_STAMP(2);
+
+  constexpr int KSTEPS = W_TAPS;            // KC = 2: one K pair per tap; tap = (dh * 3 + dw) * NP + k
+  // work items between the MFMAs of a chunk (slot = K-step after whose MFMAs the item is placed)
+  // (no LDS-DMA is outstanding when the raw box is read: the compiler puts vmcnt(0) in front of LDS reads that a pending
+  // DMA might alias)
+  constexpr int SLOT_COL0 = 0, COL_STEP = 6, SLOT_W0 = 26, SLOT_RAW0 = 32, STEP = 2;
+  static_assert(SLOT_COL0 + 4 * COL_STEP <= SLOT_W0 + 1 && SLOT_W0 + G::WK <= SLOT_RAW0 && SLOT_RAW0 + G::XK * STEP <= KSTEPS - 8,
+                "work items in order, raw pieces early enough to land");
+  auto mfma_chunk = [&](const float* st, int c1, int c2, float* st_next) __attribute__((always_inline)) {
+    // st: the stage of this chunk; c1 / c2: the chunks whose weights / raw box are requested now (next, next but one)
+    float av[3], bv[3][NS];                 // operands are fetched two K-steps (four MFMAs) ahead
+    auto fetch = [&](auto ksc) __attribute__((always_inline)) {
+      constexpr int ks = decltype(ksc)::value;
+      constexpr int k = ks % NP, dh = (ks / NP) / 3, dw = (ks / NP) % 3;
+      constexpr int toff = (k * HH + dh) * PW + dw;
+      av[ks % 3] = st[aoff + ks * CO];
+#pragma unroll
+      for (int s = 0; s < NS; ++s) bv[ks % 3][s] = st[boff[s] + toff];
+    };
+    fetch(std::integral_constant<int, 0>{});
+    fetch(std::integral_constant<int, 1>{});
+    static_for<0, KSTEPS>([&](auto ksc) __attribute__((always_inline)) {
+      constexpr int ks = decltype(ksc)::value;
+      constexpr int k = ks % NP;
+      acc[k * NS + 0] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[ks % 3], bv[ks % 3][0], acc[k * NS + 0], 0, 0, 0);
+      __builtin_amdgcn_sched_barrier(0);
+      if constexpr (ks + 2 < KSTEPS) fetch(std::integral_constant<int, ks + 2>{});
+      __builtin_amdgcn_sched_barrier(0);
+      acc[k * NS + 1] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[ks % 3], bv[ks % 3][1], acc[k * NS + 1], 0, 0, 0);
+      __builtin_amdgcn_sched_barrier(0);
+      if constexpr (ks >= SLOT_COL0 && (ks - SLOT_COL0) % COL_STEP == 0 && (ks - SLOT_COL0) / COL_STEP < 4)
+        tr_load(std::integral_constant<int, (ks - SLOT_COL0) / COL_STEP>{});
+      if constexpr (ks > SLOT_COL0 && (ks - 1 - SLOT_COL0) % COL_STEP == 0 && (ks - 1 - SLOT_COL0) / COL_STEP < 4)
+        tr_col(std::integral_constant<int, (ks - 1 - SLOT_COL0) / COL_STEP>{}, st_next);
+      if constexpr (ks >= SLOT_W0 && ks < SLOT_W0 + G::WK) issue_w(std::integral_constant<int, ks - SLOT_W0>{}, c1, st_next);
+      if constexpr (ks >= SLOT_RAW0 && (ks - SLOT_RAW0) % STEP == 0 && (ks - SLOT_RAW0) / STEP < G::XK)
+        issue_raw(std::integral_constant<int, (ks - SLOT_RAW0) / STEP>{}, c2);
+      __builtin_amdgcn_sched_barrier(0);
+    });
+  };
+
+  for (int c = 0; c < nchunks; c += 2) {
+    mfma_chunk(st0, c + 1 < nchunks ? c + 1 : 0, c + 2 < nchunks ? c + 2 : 0, st1);
+    __syncthreads();
+    if (c + 1 < nchunks) {
+      mfma_chunk(st1, c + 2 < nchunks ? c + 2 : 0, c + 3 < nchunks ? c + 3 : 0, st0);
+      __syncthreads();
+    }
+  }
+  WF_STAMP(3);
+
+  // ---- output transform in registers, y_j = sum_k A^T[j][k] m_k, A^T = [1 1 1 1 1 0; 0 1 -1 2 -2 0; 0 1 1 4 4 0; 0 1 -1 8 -8 1],
+  // IN PLACE (band j of a sub-tile takes the place of plane j: no second set of registers), sub-tile by sub-tile, then the
+  // shared dwordx4 epilogue with the four bands as its "sub-tiles".  No barrier: the waves finish independently. -------------
+  float* T = lds + wv * 1024;     // (every wave is past the last barrier: the stages are free)
+  const float bias_v[1] = {bias_l}, sh2_v[1] = {sh2_l}, sc2_v[1] = {sc2_l};
+  static_for<0, NS>([&](auto sc) __attribute__((always_inline)) {
+    constexpr int s = decltype(sc)::value;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const float m0 = acc[0 * NS + s][r], m1 = acc[1 * NS + s][r], m2 = acc[2 * NS + s][r], m3 = acc[3 * NS + s][r],
+                  m4 = acc[4 * NS + s][r], m5 = acc[5 * NS + s][r];
+      const float p12 = m1 + m2, d12 = m1 - m2, p34 = m3 + m4, d34 = m3 - m4;
+      acc[0 * NS + s][r] = (m0 + p12) + p34;
+      acc[1 * NS + s][r] = d12 + 2.f * d34;
+      acc[2 * NS + s][r] = p12 + 4.f * p34;
+      acc[3 * NS + s][r] = (d12 + 8.f * d34) + m5;
+    }
+    f32x16 out[MO][1];
+#pragma unroll
+    for (int j = 0; j < MO; ++j) out[j][0] = acc[j * NS + s];
+    int sub_base[MO];
+    const int rem = (wv * 64 + s * 32) % (TH * TW);
+#pragma unroll
+    for (int j = 0; j < MO; ++j) sub_base[j] = (MO * pt + j) * (TH * TW) + rem;
+    tmdiff::epilogue_vec<MO, 1, NB, TH, TW>(a, out, bias_v, sh2_v, sc2_v, b, g, co0, 0, h0, w0, wv, lane, plane, T, sub_base);
+  });
+#if TMDIFF_WF_STAMPS
+  WF_STAMP(4);
+  __builtin_amdgcn_s_waitcnt(0);
+  WF_STAMP(5);
+  if (a.stamps && lane == 0) {
+    unsigned long long* o = a.stamps + ((unsigned long long)blockIdx.x * 4 + wv) * 8;
+    for (int i = 0; i < 6; ++i) o[i] = stamp_t[i];
+    o[6] = ((unsigned long long)__builtin_amdgcn_s_getreg(4 | (31 << 11)) << 32) | __builtin_amdgcn_s_getreg(6 | (31 << 11)) |
+           ((unsigned long long)(__builtin_amdgcn_s_getreg(20 | (31 << 11)) & 0xf) << 28);
+    o[7] = __builtin_amdgcn_s_memtime() - stamp_c0;
+  }
+#endif
+}
+
+template <int TT, int TH, int TW>
+int launch(WfArgs& a, hipStream_t st) {
+  a.tiles_h = (a.H + TH - 1) / TH;
+  a.tiles_w = (a.W + TW - 1) / TW;
+  a.tiles_co = a.cout_g / 32;
+  const long blocks = (long)a.B * a.groups * a.tiles_h * a.tiles_w * a.tiles_co;
+  if (blocks <= 0 || blocks > 0x7fffffffL) return tmdiff::fail(TMDIFF_E_INVALID, "conv3d_wf_fwd: grid of %ld blocks", blocks);
+  a.total_blocks = (unsigned)blocks;
+  static const double stagger_chunks = [] {
+    const char* e = getenv("TMDIFF_WF_STAGGER");     // experiments: delay of every CU's second resident workgroup, in chunk times
+    return e ? atof(e) : 0.0;
+  }();
+  a.first_round = 512;
+  a.stagger = blocks > 512 ? (int)(stagger_chunks * 2.0 * 54 * 2 * 64) : 0;
+  conv3d_wf_kernel<TT, TH, TW><<<(unsigned)blocks, 256, 0, st>>>(a);
+  return tmdiff::check_launch("conv3d_wf_fwd");
+}
+
+bool wf_shape_ok(const tmdiff_conv3d_desc* d) {
+  if (!d || d->ksize != 3 || (d->groups != 1 && d->groups != 3) || d->in_mask || d->x_bf16 || d->y2_bf16) return false;
+  if (!(d->drop_p >= 0.f && d->drop_p < 1.f)) return false;
+  if (d->nseg < 1 || d->nseg > 3 || d->Cin <= 0 || d->Cout <= 0 || d->Cin % d->groups || d->Cout % d->groups) return false;
+  return (d->Cin / d->groups) % 2 == 0 && (d->Cout / d->groups) % 32 == 0 && (d->N == 8 || d->N == 4) && d->H > 0 && d->W > 0 &&
+         d->W % 4 == 0;
+}
+
+bool wf_plain(const tmdiff_conv3d_desc* d) {
+  return d->nseg == 1 && !d->in_shift && !d->in_scale && !d->in_act && !(d->drop_p > 0.f);
+}
+
+}  // namespace
+
+extern "C" int tmdiff_conv3d_wf_supported(const tmdiff_conv3d_desc* d) { return wf_shape_ok(d) ? 1 : 0; }
+
+extern "C" int64_t tmdiff_conv3d_wf_blocks(const tmdiff_conv3d_desc* d) {
+  if (!wf_shape_ok(d) || d->B <= 0) return 0;
+  const int th = d->N == 8 ? 8 : 16;
+  return (int64_t)d->B * d->groups * ((d->H + th - 1) / th) * ((d->W + 15) / 16) * (d->Cout / d->groups / 32);
+}
+
+/* bytes of the prologue output x' the entry point forms first when the input is not one plain tensor (0: plain input) */
+extern "C" size_t tmdiff_conv3d_wf_workspace_bytes(const tmdiff_conv3d_desc* d) {
+  if (!wf_shape_ok(d) || d->B <= 0 || wf_plain(d)) return 0;
+  return (size_t)d->B * d->Cin * d->N * d->H * d->W * sizeof(float);
+}
+
+extern "C" int tmdiff_conv3d_wf_fwd(const tmdiff_conv3d_desc* d, void* workspace, tmdiff_stream_t stream) {
+  using namespace tmdiff;
+  TMDIFF_REQUIRE(d != nullptr, "conv3d_wf_fwd: NULL descriptor");
+  if (!wf_shape_ok(d))
+    return fail(TMDIFF_E_UNSUPPORTED, "conv3d_wf_fwd: fp32 3x3x3, groups 1 or 3, N = 8 or 4, W %% 4 == 0, Cin/g %% 2 == 0, Cout/g %% 32 == 0, no mask");
+  TMDIFF_REQUIRE(d->B >= 0, "conv3d_wf_fwd: bad extents");
+  if (d->B == 0) return TMDIFF_OK;
+  TMDIFF_REQUIRE(d->w_packed && (d->y || d->y2) && aligned16(d->w_packed), "conv3d_wf_fwd: NULL / unaligned weights or output");
+  TMDIFF_REQUIRE((long)2 * d->N * d->H * d->W < (1L << 31), "conv3d_wf_fwd: plane too large for 32-bit offsets");
+  int csum = 0;
+  for (int i = 0; i < d->nseg; ++i) {
+    TMDIFF_REQUIRE(d->seg_x[i] != nullptr && d->seg_c[i] > 0 && aligned16(d->seg_x[i]), "conv3d_wf_fwd: segment %d is empty / unaligned", i);
+    csum += d->seg_c[i];
+  }
+  TMDIFF_REQUIRE(csum == d->Cin, "conv3d_wf_fwd: segments hold %d channels, Cin=%d", csum, d->Cin);
+  if (!(aligned16(d->y) && aligned16(d->y2) && aligned16(d->residual)))
+    return fail(TMDIFF_E_UNSUPPORTED, "conv3d_wf_fwd: 16-byte aligned outputs / residual");
+  hipStream_t st = as_stream(stream);
+  const float* x = d->seg_x[0];
+  if (!wf_plain(d)) {      // prologue / concatenation / dropout: one elementwise pass (8 B per input element) forms x'
+    TMDIFF_REQUIRE(workspace && aligned16(workspace), "conv3d_wf_fwd: this input needs its workspace (tmdiff_conv3d_wf_workspace_bytes)");
+    const int rc = launch_prologue_apply(d, static_cast<float*>(workspace), st);
+    if (rc) return rc;
+    x = static_cast<const float*>(workspace);
+  }
+  WfArgs a;
+  a.B = d->B; a.N = d->N; a.H = d->H; a.W = d->W;
+  a.Cin = d->Cin; a.Cout = d->Cout; a.groups = d->groups; a.cin_g = d->Cin / d->groups; a.cout_g = d->Cout / d->groups;
+  a.x = x; a.wp = d->w_packed;
+  a.bias = d->bias; a.bias_scale = d->bias_scale;
+  a.residual = d->residual; a.out_scale = d->out_scale; a.y = d->y;
+  a.y2 = d->y2; a.y2_shift = d->y2_shift; a.y2_scale = d->y2_scale; a.y2_act = d->y2_act;
+  a.y2_shift_stride = d->y2_shift_stride > 0 ? d->y2_shift_stride : (d->y2_shift_stride < 0 ? 0 : d->Cout);
+  a.y2_scale_stride = d->y2_scale_stride > 0 ? d->y2_scale_stride : (d->y2_scale_stride < 0 ? 0 : d->Cout);
+  a.vec4 = 1;
+  a.stamps = TMDIFF_WF_STAMPS ? static_cast<unsigned long long*>(d->splitk_ws) : nullptr;
+  if (d->N == 8) return launch<2, 8, 16>(a, st);
+  return launch<1, 16, 16>(a, st);
+}

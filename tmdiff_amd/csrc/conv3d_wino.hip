@@ -24,6 +24,13 @@
 #include "common.h"
 #include "epilogue.h"
 
+// Diagnostic build (-DTMDIFF_WINO_STAMPS=1, tools/wino_stamps.py): every wave records s_memrealtime (100 MHz, one clock for
+// the whole chip) at its phase boundaries plus HW_REG_HW_ID / HW_REG_LDS_ALLOC, into the buffer lent through desc.splitk_ws
+// (8 x u64 per wave; never read by the kernel, no output depends on it).
+#ifndef TMDIFF_WINO_STAMPS
+#define TMDIFF_WINO_STAMPS 0
+#endif
+
 namespace {
 
 using f32x16 = __attribute__((ext_vector_type(16))) float;
@@ -70,6 +77,9 @@ struct WinoArgs {
   int tiles_t, tiles_h, tiles_w, tiles_co;
   unsigned total_blocks;
   int vec4;
+  unsigned long long* stamps;   // diagnostic builds only
+  int stagger;          // cycles the SECOND resident workgroup of a CU waits before its first tile (0 = none): see stagger_start
+  unsigned first_round; // workgroups resident at launch (2 per CU): only they can be in lockstep with their CU partner
 };
 
 struct WinoInArgs {
@@ -191,6 +201,20 @@ __device__ __forceinline__ unsigned xcd_remap(unsigned bid, unsigned nwg) {
   return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + k;
 }
 
+// Two workgroups share a CU (LDS-limited) and one matrix pipe per SIMD.  Launched together and with equal tile times they
+// stay in lockstep for the whole launch: both run their MFMA phases together (each at half the pipe) and both reach their
+// epilogues together -- the pipe idles while every CU of the chip stores its outputs at once (HBM-bound burst: 64 -> 64 at
+// 64x64, B = 32 writes / reads 0.8 GB per launch in four bursts).  Delaying the second resident workgroup of every CU ONCE,
+// by about an epilogue, puts the pairs in anti-phase for good: one computes at the full pipe rate while its partner stores.
+// The second resident is the one whose LDS allocation does not start at 0 (HW_REG_LDS_ALLOC, base field).
+__device__ __forceinline__ void stagger_start(int cycles, unsigned first_round) {
+  if (cycles <= 0 || blockIdx.x >= first_round) return;
+  const unsigned lds_alloc = __builtin_amdgcn_s_getreg(6 | (0 << 6) | (11 << 11));   // hwreg(HW_REG_LDS_ALLOC, 0, 12): LDS_BASE
+  if (lds_alloc == 0) return;
+  const unsigned long long t0 = __builtin_amdgcn_s_memtime();
+  while ((long long)(__builtin_amdgcn_s_memtime() - t0) < (long long)cycles) __builtin_amdgcn_s_sleep(32);
+}
+
 template <int NS, int MSUB, int KC, int TT, int TH, int TW, int NP>
 struct GeoW {
   static constexpr int CO = 32 * MSUB;
@@ -227,6 +251,16 @@ __global__ void __launch_bounds__(256, 2) conv3d_wino_kernel(const WinoArgs a) {
   const int tid = threadIdx.x;
   const int lane = tid & 63, wv = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int l31 = lane & 31, khalf = lane >> 5;
+#if TMDIFF_WINO_STAMPS
+  unsigned long long stamp_t[6];
+  const unsigned long long stamp_c0 = __builtin_amdgcn_s_memtime();
+  stamp_t[0] = __builtin_amdgcn_s_memrealtime();
+#define WINO_STAMP(i) stamp_t[i] = __builtin_amdgcn_s_memrealtime()
+#else
+#define WINO_STAMP(i)
+#endif
+  stagger_start(a.stagger, a.first_round);
+  WINO_STAMP(1);
 
   unsigned id = xcd_remap(blockIdx.x, a.total_blocks);
   const int co_tile = __builtin_amdgcn_readfirstlane(id % a.tiles_co); id /= a.tiles_co;
@@ -358,6 +392,7 @@ __global__ void __launch_bounds__(256, 2) conv3d_wino_kernel(const WinoArgs a) {
   };
 
   __syncthreads();
+  WINO_STAMP(2);
   for (int c = 0; c < nchunks; c += 2) {
     mfma_chunk(st0, c + 1 < nchunks ? c + 1 : 0, st1);
     __syncthreads();
@@ -367,6 +402,7 @@ __global__ void __launch_bounds__(256, 2) conv3d_wino_kernel(const WinoArgs a) {
     }
   }
 
+  WINO_STAMP(3);
   // ---- output transform: y_j = sum_k A^T[j][k] m_k.  This wave holds m_k for its NX planes: it forms its part of every y_j,
   // keeps those of the OH bands it finishes (j = OH * grp .. + OH - 1) and sends the other OH to its partner (wave ^ 2), one
   // accumulator (1024 floats) per round through alternating stages, one barrier per round. -------------------------------
@@ -424,6 +460,18 @@ __global__ void __launch_bounds__(256, 2) conv3d_wino_kernel(const WinoArgs a) {
     tmdiff::epilogue_vec<OH, MSUB, MO * TT, TH, TW>(a, out, bias_v, sh2_v, sc2_v, b, g, co0, MO * t0, h0, w0, wv, lane, plane, T,
                                                     sub_base);
   });
+#if TMDIFF_WINO_STAMPS
+  WINO_STAMP(4);
+  __builtin_amdgcn_s_waitcnt(0);          // every store of this wave has been acknowledged
+  WINO_STAMP(5);
+  if (a.stamps && lane == 0) {
+    unsigned long long* o = a.stamps + ((unsigned long long)blockIdx.x * 4 + wv) * 8;
+    for (int i = 0; i < 6; ++i) o[i] = stamp_t[i];
+    o[6] = ((unsigned long long)__builtin_amdgcn_s_getreg(4 | (31 << 11)) << 32) | __builtin_amdgcn_s_getreg(6 | (31 << 11)) |
+           ((unsigned long long)(__builtin_amdgcn_s_getreg(20 | (31 << 11)) & 0xf) << 28);
+    o[7] = __builtin_amdgcn_s_memtime() - stamp_c0;
+  }
+#endif
 }
 
 template <int NS, int MSUB, int KC, int TT, int TH, int TW, int NP>
@@ -436,6 +484,16 @@ int launch(WinoArgs& a, hipStream_t st) {
   const long blocks = (long)a.B * a.groups * a.tiles_t * a.tiles_h * a.tiles_w * a.tiles_co;
   if (blocks <= 0 || blocks > 0x7fffffffL) return tmdiff::fail(TMDIFF_E_INVALID, "conv3d_wino_fwd: grid of %ld blocks", blocks);
   a.total_blocks = (unsigned)blocks;
+  // stagger (see stagger_start): TMDIFF_WINO_STAGGER = delay in units of one chunk's MFMA time of a workgroup pair
+  // (2 x KSTEPS x MF x 64 cycles); only worth it when there are several rounds of workgroups
+  static const double stagger_chunks = [] {
+    const char* e = getenv("TMDIFF_WINO_STAGGER");
+    return e ? atof(e) : 0.0;
+  }();
+  constexpr int NPIECE_UNUSED = 0; (void)NPIECE_UNUSED;
+  const double chunk_cycles = 2.0 * (KC / 2) * 9 * (NP / 2) * NS * MSUB * 64;
+  a.first_round = 512;
+  a.stagger = blocks > 512 ? (int)(stagger_chunks * chunk_cycles) : 0;
   conv3d_wino_kernel<NS, MSUB, KC, TT, TH, TW, NP><<<(unsigned)blocks, 256, 0, st>>>(a);
   return tmdiff::check_launch("conv3d_wino_fwd");
 }
@@ -454,12 +512,12 @@ __global__ void __launch_bounds__(256) wino_pack_weights_kernel(const float* __r
     const int ci = (int)(r % cin_g);
     const int g = (int)(r / cin_g);
     int co = col;
-    if (cout_g % 64 == 0) {
+    if (cout_g % 64 == 0 && !(mode & 2)) {   // (mode | 2: natural column order, for the 32-channel tiles of conv3d_wf.hip)
       const int tile = col / 64, j = col % 64;
       co = tile * 64 + (j % 2) * 32 + j / 2;
     }
     float g3[3];
-    if (mode == 0) {
+    if ((mode & 1) == 0) {
       const float* wk = w + (((long)g * cout_g + co) * cin_g + ci) * 27 + tap9;   // [dn][dh][dw]: dn stride 9
       g3[0] = wk[0], g3[1] = wk[9], g3[2] = wk[18];
     } else {   // data-gradient form: this convolution's (co, ci) are the forward one's (ci, co), every tap mirrored
@@ -528,7 +586,7 @@ extern "C" int tmdiff_conv3d_wino_pack_weights(const float* w, float* packed, in
   TMDIFF_REQUIRE(w && packed && aligned16(packed), "conv3d_wino_pack_weights: NULL / unaligned pointer");
   TMDIFF_REQUIRE(groups >= 1 && Cout > 0 && Cin > 0 && Cout % groups == 0 && Cin % groups == 0 && (Cout / groups) % 32 == 0,
                  "conv3d_wino_pack_weights: Cout=%d Cin=%d groups=%d (Cout/groups a multiple of 32)", Cout, Cin, groups);
-  TMDIFF_REQUIRE(mode == 0 || mode == 1, "conv3d_wino_pack_weights: mode=%d", mode);
+  TMDIFF_REQUIRE(mode >= 0 && mode <= 3, "conv3d_wino_pack_weights: mode=%d (bit 0: data-gradient form, bit 1: natural column order)", mode);
   TMDIFF_REQUIRE(planes == 4 || planes == 6, "conv3d_wino_pack_weights: planes=%d (tmdiff_conv3d_wino_planes)", planes);
   const long total = (long)(Cin / groups) * 9 * planes * Cout;
   long blocks = (total + 255) / 256;
@@ -597,6 +655,7 @@ extern "C" int tmdiff_conv3d_wino_fwd_planes(const tmdiff_conv3d_desc* d, void* 
   a.y2_shift_stride = d->y2_shift_stride > 0 ? d->y2_shift_stride : (d->y2_shift_stride < 0 ? 0 : d->Cout);
   a.y2_scale_stride = d->y2_scale_stride > 0 ? d->y2_scale_stride : (d->y2_scale_stride < 0 ? 0 : d->Cout);
   a.vec4 = 1;
+  a.stamps = TMDIFF_WINO_STAMPS ? static_cast<unsigned long long*>(d->splitk_ws) : nullptr;
   if (!(d->W % 4 == 0 && aligned16(d->y) && aligned16(d->y2) && aligned16(d->residual)))
     return fail(TMDIFF_E_UNSUPPORTED, "conv3d_wino_fwd: W %% 4 == 0 and 16-byte aligned outputs / residual");
   if (np == 6) {

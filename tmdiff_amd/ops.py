@@ -210,6 +210,14 @@ class ConvTimer:
 
 
 TIMER = None      # set to a ConvTimer() to time every conv launch
+COUNTS = None     # set to a collections.Counter() to count convolution launches per C entry point ("conv3d_fwd",
+                  # "conv3d_fwd_staged", "conv3d_fwd_bf16", "conv3d_wino4_fwd", "conv3d_wino2_fwd", "conv3d_ll_fwd"): the
+                  # tests and bench.py's parity leg assert from it WHICH kernel family produced a result
+
+
+def _count(what):
+    if COUNTS is not None:
+        COUNTS[what] += 1
 
 
 _WS = {}     # (device index, stream) -> grow-only scratch tensor (prologue outputs / bf16-packed conv inputs); launches
@@ -297,6 +305,7 @@ def conv3d(segs, w_packed, cout, ksize, out=None, math="fp32", pack_input=None, 
             fwd, what = lib.tmdiff_conv3d_fwd, "conv3d_fwd"
     else:
         raise ValueError(f"conv3d: unknown math {math!r}")
+    _count(what if ksize == 3 else what + "_k1")
     if TIMER is None:
         check(fwd(C.byref(d), stream_ptr()), what)
         return ret
@@ -322,10 +331,11 @@ def wino_planes(n_bands):
 
 def pack_conv_weight_wino(w, groups=1, mode=0, planes=6):
     """[Cout, Cin/groups, 3, 3, 3] -> the transformed, packed weights of the Winograd-along-n convolution (conv3d_wino);
-    planes = wino_planes(N) of the tensors it will run on.  mode=1: the weights of the DATA-GRADIENT convolution
-    (Cout -> Cin channels, transposed, taps mirrored) of the forward convolution whose weight w is."""
+    planes = wino_planes(N) of the tensors it will run on.  mode bit 0: the weights of the DATA-GRADIENT convolution
+    (Cout -> Cin channels, transposed, taps mirrored) of the forward convolution whose weight w is; mode bit 1 (value 2):
+    natural column order, the form conv3d_wf takes (conv3d_wino: interleaved 64-channel tiles)."""
     cout, cin = w.shape[0], w.shape[1] * groups
-    if mode:
+    if mode & 1:
         cout, cin = cin, cout
     nb = lib.tmdiff_conv3d_wino_packed_bytes(cout, cin, groups, planes)
     if tuple(w.shape[2:]) != (3, 3, 3) or nb == 0:
@@ -378,6 +388,7 @@ def conv3d_wino(segs, w_packed, cout, emit=None, keep_y=True, fallback=None, gro
     ret = y if y2 is None else ((y, y2) if y is not None else y2)
     if xp_out is not None and not (xp_out.is_cuda and xp_out.is_contiguous() and xp_out.numel() == b * d.Cin * n * h * w):
         raise ValueError("conv3d_wino: xp_out must be a contiguous fp32 [B, Cin, N, H, W] tensor")
+    _count(f"conv3d_wino{planes - 2}_fwd")
     if TIMER is None or xp_out is not None:
         check(lib.tmdiff_conv3d_wino_fwd_planes(C.byref(d), ws, 0, xp_out.data_ptr() if xp_out is not None else None, planes,
                                                 stream_ptr()), "conv3d_wino_fwd")
@@ -393,6 +404,67 @@ def conv3d_wino(segs, w_packed, cout, emit=None, keep_y=True, fallback=None, gro
     TIMER.records.append((ev[0], ev[1], (4.0 + 4.0 * planes / mo) * b * d.Cin * n * h * w, 0, "wino_input"))
     # EXECUTED flops: 9 * planes multiply-adds per (ci, co) and tile of mo output bands (the direct kernel: 27 per band)
     TIMER.records.append((ev[1], ev[2], 2.0 * b * cout * (d.Cin // groups) * (9.0 * planes / mo) * n * h * w, 3, f"conv3d_wino{mo}_fwd"))
+    return ret
+
+
+_WF = os.environ.get("TMDIFF_WF", "1") != "0"    # experiments: "0" = never the in-kernel-transform Winograd kernel (conv3d_wf)
+_WF_MIN_FILL = float(os.environ.get("TMDIFF_WF_MIN_FILL", "0.7"))
+
+
+def conv3d_wf(segs, w_packed, cout, emit=None, keep_y=True, fallback=None, groups=1, w_packed_fn=None, xp_out=None, **kw):
+    """conv3d(segs, ...) (fp32, 3x3x3) through the Winograd F(4,3)-along-the-bands kernel that transforms its input INSIDE the
+    kernel (csrc/conv3d_wf.hip; 8- or 4-band tensors, the whole band axis in one workgroup): no transformed copy of the input,
+    no transform pass -- an input that is one plain tensor is read as it stands, any other (prologue, segments, dropout) goes
+    through one elementwise prologue pass first (its output lands in xp_out when given: the finetune path keeps it for the
+    weight gradient).  Same keyword arguments and return convention as conv3d_wino; w_packed / w_packed_fn() = the weights
+    from pack_conv_weight_wino(w, groups, mode | 2, planes=6).  fallback() runs instead when the shape is not taken or the
+    grid is too small for a kernel without split-K."""
+    b, _, n, h, w = segs[0].shape
+    dev = segs[0].device
+    cg = cout // groups
+    blocks = b * groups * ((h + 7) // 8 if n == 8 else (h + 15) // 16) * ((w + 15) // 16) * (cg // 32) if cg % 32 == 0 else 0
+    cin = sum(s_.shape[1] for s_ in segs)
+    ok = _WF and n in (4, 8) and w % 4 == 0 and cg % 32 == 0 and (cin // groups) % 2 == 0 and kw.get("in_mask") is None
+    th = 8 if n == 8 else 16
+    # (tiles of th x 16 positions: an 8 x 8 plane would leave half of every tile empty -- those go to the fallback)
+    fill = (h * w) / float(((h + th - 1) // th) * th * ((w + 15) // 16) * 16)
+    if fallback is not None and (not ok or blocks < _WINO_MIN_BLOCKS or fill < _WF_MIN_FILL):
+        return fallback()
+    if w_packed is None:
+        w_packed = w_packed_fn()
+    y = torch.empty(b, cout, n, h, w, device=dev, dtype=torch.float32) if keep_y else None
+    y2 = None
+    if emit is not None:
+        y2 = torch.empty(b, cout, n, h, w, device=dev, dtype=torch.float32)
+        kw = dict(kw, y2_act=emit.get("act", False), y2_shift=emit.get("shift"), y2_scale=emit.get("scale"),
+                  y2_shift_stride=emit.get("shift_stride", 0), y2_scale_stride=emit.get("scale_stride", 0))
+    elif y is None:
+        raise ValueError("conv3d_wf: keep_y=False needs emit=")
+    d = make_conv_desc(segs, w_packed, cout, 3, y, y2=y2, groups=groups, **kw)
+    if not lib.tmdiff_conv3d_wf_supported(C.byref(d)):
+        raise ValueError("conv3d_wf: shape not supported")
+    nws = lib.tmdiff_conv3d_wf_workspace_bytes(C.byref(d))
+    ws = None
+    if nws:
+        if xp_out is not None:
+            if not (xp_out.is_cuda and xp_out.is_contiguous() and xp_out.numel() * 4 == nws):
+                raise ValueError("conv3d_wf: xp_out must be a contiguous fp32 [B, Cin, N, H, W] tensor")
+            ws = xp_out.data_ptr()
+        else:
+            ws = _workspace(dev, nws).data_ptr()
+    elif xp_out is not None:          # plain input: x' IS the input
+        xp_out.copy_(segs[0])
+    ret = y if y2 is None else ((y, y2) if y is not None else y2)
+    _count("conv3d_wf_fwd")
+    if TIMER is None:
+        check(lib.tmdiff_conv3d_wf_fwd(C.byref(d), ws, stream_ptr()), "conv3d_wf_fwd")
+        return ret
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    check(lib.tmdiff_conv3d_wf_fwd(C.byref(d), ws, stream_ptr()), "conv3d_wf_fwd")
+    e1.record()
+    # EXECUTED flops: 54 multiply-adds per (ci, co) and tile of four output bands (the direct kernel: 27 per band)
+    TIMER.records.append((e0, e1, 2.0 * b * cout * (d.Cin // groups) * 13.5 * n * h * w, 3, "conv3d_wf_fwd"))
     return ret
 
 
@@ -435,6 +507,7 @@ def conv3d_ll(x, w_packed, cout, ll_scale=0.5, emit=None, keep_y=True, **kw):
     if nsk:
         d.splitk_ws, d.splitk_ws_bytes = _workspace(dev, nsk, "splitk").data_ptr(), nsk
     ret = y if y2 is None else ((y, y2) if y is not None else y2)
+    _count("conv3d_ll_fwd")
     if TIMER is None:
         check(lib.tmdiff_conv3d_ll_fwd(C.byref(d), float(ll_scale), stream_ptr()), "conv3d_ll_fwd")
         return ret
