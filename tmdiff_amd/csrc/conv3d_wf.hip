@@ -29,6 +29,9 @@
 #include "common.h"
 #include "epilogue.h"
 
+#ifndef TMDIFF_WF_ABLATE
+#define TMDIFF_WF_ABLATE 0       // timing experiments (WRONG results): 1 = no input transform in the loop, 2 = ... and no raw DMA,
+#endif                           // 3 = ... and no weight DMA
 #ifndef TMDIFF_WF_STAMPS
 #define TMDIFF_WF_STAMPS 0       // diagnostic build: per-wave s_memrealtime stamps (tools/wino_stamps.py)
 #endif
@@ -136,6 +139,80 @@ struct GeoF {
   static_assert(V_FLOATS % 4 == 0, "stage alignment");
 };
 
+// Epilogue of a wave: its 8 output blocks (2 sub-tiles x 4 bands, each 32 channels x 32 positions in the MFMA D layout: a lane
+// = one position, 16 channels) leave as in epilogue.h -- through a wave-private 4 KB LDS tile T[channel][position]
+// (ds_write_b32 in the D layout, ds_read_b128 along the positions), lane (tc, tq) = (lane >> 3, lane & 7) then owns channels
+// tc + 8 j and four consecutive positions: bias, residual, scale, the consumer's prologue, dwordx4 stores -- with one
+// difference: the residual quads are requested THREE blocks ahead (the output transform has already freed a third of the
+// accumulators, so there are registers for it).  With one block of look-ahead a wave waited out most of an HBM round trip
+// per block, eight times per tile: 22 of the 33 us of a tile's epilogue at 32 input channels (tools/wino_stamps.py).
+template <bool Y, bool RES, bool Y2, bool FULL, int TT, int TH, int TW>
+__device__ __forceinline__ void epilogue_wf(const WfArgs& a, f32x16 (&out)[8], float bias_l, float sh2_l, float sc2_l, int b, int g,
+                                            int co0, int h0, int w0, int wv, int lane, long plane, float* T) {
+  constexpr int MO = 4, DEPTH = 3;
+  const int l31 = lane & 31, khalf = lane >> 5, tq = lane & 7, tc = lane >> 3;
+  const int pt = (wv * 64) / (TH * TW);
+  const int hw = a.H * a.W;
+  const long cbase = ((long)b * a.Cout + g * a.cout_g + co0 + tc) * plane + (long)(MO * pt) * hw;
+  int toff[2];
+  bool tok[2];
+#pragma unroll
+  for (int s = 0; s < 2; ++s) {
+    const int p = (wv * 64 + s * 32 + 4 * tq) % (TH * TW);
+    const int h = h0 + p / TW, w = w0 + p % TW;
+    tok[s] = FULL || (h < a.H && w < a.W);                      // (W % 4 == 0: the four positions stand or fall together)
+    toff[s] = tok[s] ? h * a.W + w : 0;
+  }
+  float bias_t[4], sh2_t[4], sc2_t[4];
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    bias_t[j] = tmdiff::lane_value(bias_l, tc + 8 * j);
+    if constexpr (Y2) sh2_t[j] = tmdiff::lane_value(sh2_l, tc + 8 * j), sc2_t[j] = tmdiff::lane_value(sc2_l, tc + 8 * j);
+  }
+  float4 rs[DEPTH + 1][4];          // block i in slot i % (DEPTH + 1)
+  auto load_res = [&](auto ic) __attribute__((always_inline)) {
+    constexpr int i = decltype(ic)::value, s = i / MO, n = i % MO;
+#pragma unroll
+    for (int j = 0; j < 4; ++j)     // (outside the image: a valid address, the value is never stored)
+      rs[i % (DEPTH + 1)][j] = *reinterpret_cast<const float4*>(a.residual + cbase + (long)(8 * j) * plane + (long)n * hw + toff[s]);
+  };
+  if constexpr (RES) static_for<0, DEPTH>([&](auto ic) __attribute__((always_inline)) { load_res(ic); });
+  static_for<0, 8>([&](auto ic) __attribute__((always_inline)) {
+    constexpr int i = decltype(ic)::value, s = i / MO, n = i % MO;
+    if constexpr (RES && i + DEPTH < 8) load_res(std::integral_constant<int, i + DEPTH>{});
+#pragma unroll
+    for (int r = 0; r < 16; ++r) T[((r & 3) + 8 * (r >> 2) + 4 * khalf) * 32 + l31] = out[i][r];
+    __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const float4 t = *reinterpret_cast<const float4*>(T + (tc + 8 * j) * 32 + tq * 4);
+      float v[4] = {t.x, t.y, t.z, t.w};
+      float q[4] = {0.f, 0.f, 0.f, 0.f};
+      if constexpr (RES) {
+        const float4 rq = rs[i % (DEPTH + 1)][j];
+        q[0] = rq.x, q[1] = rq.y, q[2] = rq.z, q[3] = rq.w;
+      }
+#pragma unroll
+      for (int e = 0; e < 4; ++e) v[e] = (v[e] + bias_t[j] + q[e]) * a.out_scale;   // as the scalar epilogue
+      const long o = cbase + (long)(8 * j) * plane + (long)n * hw + toff[s];
+      if constexpr (Y) {
+        if (FULL || tok[s]) *reinterpret_cast<float4*>(a.y + o) = make_float4(v[0], v[1], v[2], v[3]);
+      }
+      if constexpr (Y2) {
+        float u[4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          const float x = v[e] + sh2_t[j];
+          const float xa = tmdiff::silu_f(x);
+          u[e] = (a.y2_act ? xa : x) * sc2_t[j];
+        }
+        if (FULL || tok[s]) *reinterpret_cast<float4*>(a.y2 + o) = make_float4(u[0], u[1], u[2], u[3]);
+      }
+    }
+    __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+  });
+}
+
 template <int TT, int TH, int TW>
 __global__ void __launch_bounds__(256, 2) conv3d_wf_kernel(const WfArgs a) {
   using G = GeoF<TT, TH, TW>;
@@ -237,13 +314,16 @@ __global__ void __launch_bounds__(256, 2) conv3d_wf_kernel(const WfArgs a) {
     constexpr int e = decltype(ec)::value;
     const int col = (e + trot) & 3;
     const float d0 = tlo ? tin[0] : 0.f, d1 = tin[1], d2 = tin[2], d3 = tin[3], d4 = tin[4], d5 = thi ? tin[5] : 0.f;
+    // B^T = [4 0 -5 0 1 0; 0 -4 -4 1 1 0; 0 4 -4 -1 1 0; 0 -2 -1 2 1 0; 0 2 -1 -2 1 0; 0 4 0 -5 0 1] with the rows' shared
+    // sums taken once (14 instead of 22 operations)
+    const float a42 = d4 - 4.f * d2, b31 = d3 - 4.f * d1, c42 = d4 - d2, e31 = d3 - d1;
     float o[NP];
-    o[0] = 4.f * d0 - 5.f * d2 + d4;
-    o[1] = -4.f * d1 - 4.f * d2 + d3 + d4;
-    o[2] = 4.f * d1 - 4.f * d2 - d3 + d4;
-    o[3] = -2.f * d1 - d2 + 2.f * d3 + d4;
-    o[4] = 2.f * d1 - d2 - 2.f * d3 + d4;
-    o[5] = 4.f * d1 - 5.f * d3 + d5;
+    o[0] = (4.f * d0 + d4) - 5.f * d2;
+    o[1] = a42 + b31;
+    o[2] = a42 - b31;
+    o[3] = c42 + 2.f * e31;
+    o[4] = c42 - 2.f * e31;
+    o[5] = (4.f * d1 + d5) - 5.f * d3;
     // V columns w0-1 .. w0+TW are raw columns 3 .. TW+4: the first quad contributes its last element only, the last its first.
     // Unconditional stores (a branch in the MFMA stream costs the compiler its count of outstanding LDS operations): lanes
     // without this column store into a dummy slot
@@ -256,13 +336,13 @@ __global__ void __launch_bounds__(256, 2) conv3d_wf_kernel(const WfArgs a) {
 
   // ---- per-lane MFMA operand offsets (floats inside a stage) ---------------------------------------------------------
   // wave wv owns positions wv * 64 .. wv * 64 + 63 of the TT x TH x TW tile (w fastest): sub-tile s = two rows of 16
-  int boff[NS];
+  // (sub-tile 1 = the two rows below sub-tile 0: one base address, a constant apart -- one ds_read2_b32 fetches both)
   const int pt = (wv * 64) / (TH * TW);
-#pragma unroll
-  for (int s = 0; s < NS; ++s) {
-    const int p = wv * 64 + s * 32 + l31;
+  int boff;
+  {
+    const int p = wv * 64 + l31;
     const int pw = p % TW, ph = (p / TW) % TH;
-    boff[s] = khalf * G::V_ELEMS + (pt * NP * HH + ph) * PW + pw;
+    boff = khalf * G::V_ELEMS + (pt * NP * HH + ph) * PW + pw;
   }
   const int aoff = G::V_FLOATS + khalf * W_TAPS * CO + l31;
 
@@ -305,7 +385,7 @@ __global__ void __launch_bounds__(256, 2) conv3d_wf_kernel(const WfArgs a) {
       constexpr int toff = (k * HH + dh) * PW + dw;
       av[ks % 3] = st[aoff + ks * CO];
 #pragma unroll
-      for (int s = 0; s < NS; ++s) bv[ks % 3][s] = st[boff[s] + toff];
+      for (int s = 0; s < NS; ++s) bv[ks % 3][s] = st[boff + toff + s * 2 * PW];
     };
     fetch(std::integral_constant<int, 0>{});
     fetch(std::integral_constant<int, 1>{});
@@ -318,12 +398,12 @@ __global__ void __launch_bounds__(256, 2) conv3d_wf_kernel(const WfArgs a) {
       __builtin_amdgcn_sched_barrier(0);
       acc[k * NS + 1] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[ks % 3], bv[ks % 3][1], acc[k * NS + 1], 0, 0, 0);
       __builtin_amdgcn_sched_barrier(0);
-      if constexpr (ks >= SLOT_COL0 && (ks - SLOT_COL0) % COL_STEP == 0 && (ks - SLOT_COL0) / COL_STEP < 4)
+      if constexpr (TMDIFF_WF_ABLATE < 1 && ks >= SLOT_COL0 && (ks - SLOT_COL0) % COL_STEP == 0 && (ks - SLOT_COL0) / COL_STEP < 4)
         tr_load(std::integral_constant<int, (ks - SLOT_COL0) / COL_STEP>{});
-      if constexpr (ks > SLOT_COL0 && (ks - 1 - SLOT_COL0) % COL_STEP == 0 && (ks - 1 - SLOT_COL0) / COL_STEP < 4)
+      if constexpr (TMDIFF_WF_ABLATE < 1 && ks > SLOT_COL0 && (ks - 1 - SLOT_COL0) % COL_STEP == 0 && (ks - 1 - SLOT_COL0) / COL_STEP < 4)
         tr_col(std::integral_constant<int, (ks - 1 - SLOT_COL0) / COL_STEP>{}, st_next);
-      if constexpr (ks >= SLOT_W0 && ks < SLOT_W0 + G::WK) issue_w(std::integral_constant<int, ks - SLOT_W0>{}, c1, st_next);
-      if constexpr (ks >= SLOT_RAW0 && (ks - SLOT_RAW0) % STEP == 0 && (ks - SLOT_RAW0) / STEP < G::XK)
+      if constexpr (TMDIFF_WF_ABLATE < 3 && ks >= SLOT_W0 && ks < SLOT_W0 + G::WK) issue_w(std::integral_constant<int, ks - SLOT_W0>{}, c1, st_next);
+      if constexpr (TMDIFF_WF_ABLATE < 2 && ks >= SLOT_RAW0 && (ks - SLOT_RAW0) % STEP == 0 && (ks - SLOT_RAW0) / STEP < G::XK)
         issue_raw(std::integral_constant<int, (ks - SLOT_RAW0) / STEP>{}, c2);
       __builtin_amdgcn_sched_barrier(0);
     });
@@ -340,12 +420,11 @@ __global__ void __launch_bounds__(256, 2) conv3d_wf_kernel(const WfArgs a) {
   WF_STAMP(3);
 
   // ---- output transform in registers, y_j = sum_k A^T[j][k] m_k, A^T = [1 1 1 1 1 0; 0 1 -1 2 -2 0; 0 1 1 4 4 0; 0 1 -1 8 -8 1],
-  // IN PLACE (band j of a sub-tile takes the place of plane j: no second set of registers), sub-tile by sub-tile, then the
-  // shared dwordx4 epilogue with the four bands as its "sub-tiles".  No barrier: the waves finish independently. -------------
-  float* T = lds + wv * 1024;     // (every wave is past the last barrier: the stages are free)
-  const float bias_v[1] = {bias_l}, sh2_v[1] = {sh2_l}, sc2_v[1] = {sc2_l};
-  static_for<0, NS>([&](auto sc) __attribute__((always_inline)) {
-    constexpr int s = decltype(sc)::value;
+  // IN PLACE for both sub-tiles first (band j takes the place of plane j; planes 4 and 5 die: a third of the accumulator
+  // registers is free for the epilogue's residual look-ahead), then the wave's eight output blocks.  No barrier: the waves
+  // of a workgroup finish independently. --------------------------------------------------------------------------------
+#pragma unroll
+  for (int s = 0; s < NS; ++s)
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
       const float m0 = acc[0 * NS + s][r], m1 = acc[1 * NS + s][r], m2 = acc[2 * NS + s][r], m3 = acc[3 * NS + s][r],
@@ -356,15 +435,23 @@ __global__ void __launch_bounds__(256, 2) conv3d_wf_kernel(const WfArgs a) {
       acc[2 * NS + s][r] = p12 + 4.f * p34;
       acc[3 * NS + s][r] = (d12 + 8.f * d34) + m5;
     }
-    f32x16 out[MO][1];
+  f32x16 out[8];                  // block (s, n) = sub-tile s, band n of the wave's band tile
 #pragma unroll
-    for (int j = 0; j < MO; ++j) out[j][0] = acc[j * NS + s];
-    int sub_base[MO];
-    const int rem = (wv * 64 + s * 32) % (TH * TW);
-#pragma unroll
-    for (int j = 0; j < MO; ++j) sub_base[j] = (MO * pt + j) * (TH * TW) + rem;
-    tmdiff::epilogue_vec<MO, 1, NB, TH, TW>(a, out, bias_v, sh2_v, sc2_v, b, g, co0, 0, h0, w0, wv, lane, plane, T, sub_base);
-  });
+  for (int i = 0; i < 8; ++i) out[i] = acc[(i % MO) * NS + i / MO];
+  float* T = lds + wv * 1024;     // (every wave is past the last barrier: the stages are free)
+  const bool full = h0 + TH <= a.H && w0 + TW <= a.W;
+#define WF_EPI2(Y, R, Y2)                                                                                                   \
+  do {                                                                                                                      \
+    if (full) epilogue_wf<Y, R, Y2, true, TT, TH, TW>(a, out, bias_l, sh2_l, sc2_l, b, g, co0, h0, w0, wv, lane, plane, T);  \
+    else epilogue_wf<Y, R, Y2, false, TT, TH, TW>(a, out, bias_l, sh2_l, sc2_l, b, g, co0, h0, w0, wv, lane, plane, T);      \
+  } while (0)
+  if (a.y) {
+    if (a.residual) { if (a.y2) WF_EPI2(true, true, true); else WF_EPI2(true, true, false); }
+    else            { if (a.y2) WF_EPI2(true, false, true); else WF_EPI2(true, false, false); }
+  } else {
+    if (a.residual) WF_EPI2(false, true, true); else WF_EPI2(false, false, true);
+  }
+#undef WF_EPI2
 #if TMDIFF_WF_STAMPS
   WF_STAMP(4);
   __builtin_amdgcn_s_waitcnt(0);

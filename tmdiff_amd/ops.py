@@ -202,11 +202,18 @@ class ConvTimer:
         """{ksize: (launches, ms, flops)}; with by_entry the key is (ksize, C entry point that served the launch)."""
         torch.cuda.synchronize()
         out = {}
-        for e0, e1, fl, k, what in self.records:
-            key = (k, what) if by_entry else k
+        for e0, e1, fl, k, what, tag in self.records:
+            key = (k, what, tag) if by_entry == "layer" else ((k, what) if by_entry else k)
             n, ms, f = out.get(key, (0, 0.0, 0.0))
             out[key] = (n + 1, ms + e0.elapsed_time(e1), f + fl)
         return out
+
+
+def _tag(d):
+    """Shape label of a launch for ConvTimer.summary(by_entry="layer"): channels, plane, what the epilogue reads / writes."""
+    return (f"{d.Cin}->{d.Cout} g{d.groups} {d.N}x{d.H}x{d.W} b{d.B}" + (" seg%d" % d.nseg if d.nseg > 1 else "") +
+            (" pro" if (d.in_act or d.in_shift or d.in_scale) else "") + (" +res" if d.residual else "") +
+            (" y" if d.y else "") + (" y2" if d.y2 else ""))
 
 
 TIMER = None      # set to a ConvTimer() to time every conv launch
@@ -313,7 +320,7 @@ def conv3d(segs, w_packed, cout, ksize, out=None, math="fp32", pack_input=None, 
     e0.record()
     check(fwd(C.byref(d), stream_ptr()), what)
     e1.record()
-    TIMER.records.append((e0, e1, 2.0 * b * cout * (d.Cin // d.groups) * ksize ** 3 * n * h * w, ksize, what))
+    TIMER.records.append((e0, e1, 2.0 * b * cout * (d.Cin // d.groups) * ksize ** 3 * n * h * w, ksize, what, _tag(d)))
     return ret
 
 
@@ -401,9 +408,9 @@ def conv3d_wino(segs, w_packed, cout, emit=None, keep_y=True, fallback=None, gro
     check(lib.tmdiff_conv3d_wino_fwd_planes(C.byref(d), ws, 2, None, planes, stream_ptr()), "conv3d_wino_fwd")
     ev[2].record()
     mo = planes - 2                  # bands per tile; bytes: 4 B read + 4 * planes / mo B written per input element
-    TIMER.records.append((ev[0], ev[1], (4.0 + 4.0 * planes / mo) * b * d.Cin * n * h * w, 0, "wino_input"))
+    TIMER.records.append((ev[0], ev[1], (4.0 + 4.0 * planes / mo) * b * d.Cin * n * h * w, 0, "wino_input", _tag(d)))
     # EXECUTED flops: 9 * planes multiply-adds per (ci, co) and tile of mo output bands (the direct kernel: 27 per band)
-    TIMER.records.append((ev[1], ev[2], 2.0 * b * cout * (d.Cin // groups) * (9.0 * planes / mo) * n * h * w, 3, f"conv3d_wino{mo}_fwd"))
+    TIMER.records.append((ev[1], ev[2], 2.0 * b * cout * (d.Cin // groups) * (9.0 * planes / mo) * n * h * w, 3, f"conv3d_wino{mo}_fwd", _tag(d)))
     return ret
 
 
@@ -464,7 +471,7 @@ def conv3d_wf(segs, w_packed, cout, emit=None, keep_y=True, fallback=None, group
     check(lib.tmdiff_conv3d_wf_fwd(C.byref(d), ws, stream_ptr()), "conv3d_wf_fwd")
     e1.record()
     # EXECUTED flops: 54 multiply-adds per (ci, co) and tile of four output bands (the direct kernel: 27 per band)
-    TIMER.records.append((e0, e1, 2.0 * b * cout * (d.Cin // groups) * 13.5 * n * h * w, 3, "conv3d_wf_fwd"))
+    TIMER.records.append((e0, e1, 2.0 * b * cout * (d.Cin // groups) * 13.5 * n * h * w, 3, "conv3d_wf_fwd", _tag(d)))
     return ret
 
 
@@ -516,7 +523,7 @@ def conv3d_ll(x, w_packed, cout, ll_scale=0.5, emit=None, keep_y=True, **kw):
     check(lib.tmdiff_conv3d_ll_fwd(C.byref(d), float(ll_scale), stream_ptr()), "conv3d_ll_fwd")
     e1.record()
     # EXECUTED flops: 48 multiply-adds per (ci, co, output position) -- the pair it replaces would execute 4 x 27
-    TIMER.records.append((e0, e1, 2.0 * b * cout * d.Cin * 48 * n * (h // 2) * (w // 2), 3, "conv3d_ll_fwd"))
+    TIMER.records.append((e0, e1, 2.0 * b * cout * d.Cin * 48 * n * (h // 2) * (w // 2), 3, "conv3d_ll_fwd", _tag(d)))
     return ret
 
 
