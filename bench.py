@@ -175,11 +175,17 @@ def cpu_baseline():
 
 
 def parity_check(dev):
-    """PSNR(build, oracle) of a short DDPM chain with shared noise (the "PSNR vs ref" half of the metric): full-width
-    network, one 8x16x16 tile, T = 10; the oracle is the checker here, as in tests/ and smoke()."""
+    """PSNR(build, oracle) of a short DDPM chain with shared noise (the "PSNR vs ref" half of the metric) ON THE KERNEL FAMILY
+    THAT PRODUCED `value`: full-width network, two 8x64x64 tiles, T = 10, with the grid-size threshold that keeps small
+    launches on the direct kernels switched off (ops._WINO_MIN_BLOCKS = 1), so that the chain runs on the Winograd kernels
+    (in-kernel transform where the plane has >= 16 columns, transform pass + kernel below) and the composed Conv_0 + LL
+    kernel, as the batch-32 workload does.  The launch counts per C entry point are reported.  The oracle is the checker
+    here, as in tests/ and smoke()."""
+    import collections
     import torch
     from oracle import unet_ref as U
     from oracle.diffusion_ref import GeneralDiffusionRef
+    from tmdiff_amd import ops
     from tmdiff_amd.Hyper_unet_general import WavBEST
     from tmdiff_amd.diffusion_general import GeneralDiffusion
     from tmdiff_amd.util import psnr, synthetic_tile_batch
@@ -187,21 +193,31 @@ def parity_check(dev):
     net = WavBEST(channels=FULL)
     net.load_state_dict(ref_net.state_dict())
     net = net.to(dev).eval()
-    d = synthetic_tile_batch(77, 1, BANDS, 16)
+    d = synthetic_tile_batch(77, 2, BANDS, SIZE)
     noise = lambda like: torch.randn(like.shape, dtype=torch.float32)       # CPU generator on both sides
     want = GeneralDiffusionRef(ref_net, "l1")
     want.set_new_noise_schedule({"schedule": "cosine", "n_timestep": 10}, "cpu")
     got = GeneralDiffusion(net, "l1", noise_fn=noise).to(dev)
     got.set_new_noise_schedule({"schedule": "cosine", "n_timestep": 10}, dev)
+    torch.set_num_threads(usable_cores())
     torch.manual_seed(5)
     with torch.no_grad():
         y_ref = want.p_sample_loop(d, continous=False, prompt="WV3")
-    torch.manual_seed(5)
-    y = got.p_sample_loop({k: v.to(dev) for k, v in d.items()}, continous=False, prompt="WV3").cpu()
+    keep, ops._WINO_MIN_BLOCKS, ops.COUNTS = ops._WINO_MIN_BLOCKS, 1, collections.Counter()
+    try:
+        torch.manual_seed(5)
+        y = got.p_sample_loop({k: v.to(dev) for k, v in d.items()}, continous=False, prompt="WV3").cpu()
+    finally:
+        counts, ops.COUNTS, ops._WINO_MIN_BLOCKS = dict(ops.COUNTS), None, keep
+    k3 = {k: v for k, v in counts.items() if not k.endswith("_k1")}
     return {"psnr_db": round(float(psnr(y, y_ref)), 1), "max_abs_diff": float((y - y_ref).abs().max()),
-            "what": "10-step DDPM chain (T=10 cosine) on one 8x16x16 tile, ch 32-256, shared CPU noise: fused image of the "
-                    "HIP path vs the CPU oracle; budget PSNR >= 60 dB (tests/test_gpu_sampling.py hold 50-step and "
-                    "1000-step chains to the same)"}
+            "launches_by_entry": k3,
+            "what": "10-step DDPM chain (T=10 cosine) on two 8x64x64 tiles, ch 32-256, shared CPU noise: fused image of the "
+                    "HIP path vs the CPU oracle, with the production kernel family forced onto this small batch "
+                    "(conv3d_wf_fwd = Winograd F(4,3) with in-kernel input transform, conv3d_wino*_fwd = transform pass + "
+                    "Winograd kernel, conv3d_ll_fwd = composed Conv_0 + LL; conv3d_fwd* = direct kernels, the 8x8 level "
+                    "here); budget PSNR >= 60 dB (tests/test_gpu_sampling.py hold full-width 50- and 1000-step chains of "
+                    "the reference to the same on these kernels)"}
 
 
 def rehearse(world, rank, args):
@@ -235,18 +251,41 @@ def rehearse(world, rank, args):
         dist.destroy_process_group()
 
 
+def source_sha16():
+    """Digest of the sources that decide which kernels the benchmark launches and what they do (csrc, ops.py, the UNet): the
+    PMC traffic file records it at collection time, so a figure collected from other code is reported as stale."""
+    import glob
+    import hashlib
+    h = hashlib.sha256()
+    files = sorted(glob.glob(os.path.join(ROOT, "tmdiff_amd", "csrc", "*"))) + [
+        os.path.join(ROOT, "tmdiff_amd", "ops.py"), os.path.join(ROOT, "tmdiff_amd", "Hyper_unet_general.py")]
+    for f in files:
+        with open(f, "rb") as fh:
+            h.update(os.path.basename(f).encode() + b"\0" + fh.read())
+    return h.hexdigest()[:16]
+
+
+TRAFFIC_FILE = "profiles/r03_bench_traffic.json"
+
+
 def load_traffic():
     """HBM bytes per 3x3x3 conv launch from the committed PMC passes over this same command (tools/bench_traffic.py:
     separate `rocprofv3 --pmc FETCH_SIZE` / `--pmc WRITE_SIZE` runs of bench.py, FETCH_SIZE doubled as
     MI355X_MICROARCH.md prescribes for gfx950).  Counters cannot be read from inside the process, so the line carries
-    the figure of the last committed collection and says where it came from."""
-    path = os.path.join(ROOT, "profiles", "r02_bench_traffic.json")
+    the figure of the last committed collection, says where it came from, and says whether the kernel sources have
+    changed since (`stale`)."""
+    path = os.path.join(ROOT, TRAFFIC_FILE)
     try:
         with open(path) as fh:
             t = json.load(fh)
-        return t["bytes_per_k3_launch"], {"file": "profiles/r02_bench_traffic.json", **{k: t[k] for k in t if k != "bytes_per_k3_launch"}}
+        src = {"file": TRAFFIC_FILE, **{k: t[k] for k in t if k != "bytes_per_k3_launch"}}
+        now = source_sha16()
+        src["stale"] = t.get("source_sha16") != now
+        if src["stale"]:
+            src["stale_note"] = f"collected from sources {t.get('source_sha16')}, this run is {now}: re-run tools/bench_traffic.sh"
+        return t["bytes_per_k3_launch"], src
     except (OSError, KeyError, ValueError):
-        return None, "profiles/r02_bench_traffic.json missing: run tools/bench_traffic.sh on the GPU box"
+        return None, TRAFFIC_FILE + " missing: run tools/bench_traffic.sh on the GPU box"
 
 
 def train_leg(dev, world, rank, dist, steps, warmup):
@@ -261,7 +300,10 @@ def train_leg(dev, world, rank, dist, steps, warmup):
            "model": {"unet": {"channel_multiplier": FULL}, "diffusion": {"loss_type": "l1"}, "init_type": "orthogonal"},
            "train": {"optimizer": {"lr": 1e-4}, "max_iter": 150000}}
     m = DDPM(opt)
-    fill_weights_(m.netG.denoise_fn)                     # same weights on every rank (replicas start identical)
+    fill_weights_(m.netG.denoise_fn)                     # same weights on every rank (replicas start identical) ...
+    if dist is not None:                                 # ... and, as tmdiff_amd.train.build_replica does, made so by a
+        from tmdiff_amd import dist as tdist             # broadcast from rank 0 (the first RCCL traffic of the leg)
+        tdist.broadcast_module(m.netG, src=0)
     m.netG.denoise_fn.invalidate_prepared()
     m.set_new_noise_schedule({"schedule": "cosine", "n_timestep": T}, "train")
     ema = EmaUpdater(m, copy.deepcopy(m))
@@ -287,7 +329,13 @@ def train_leg(dev, world, rank, dist, steps, warmup):
     t_host = time.perf_counter() - t0          # launches enqueued (the host runs ahead of the GPU when it can)
     barrier()
     dt = time.perf_counter() - t0
-    out = {"seconds": dt, "host_seconds": t_host, "loss": float(m.get_current_log()["l_pix"]), "allreduce": None}
+    from tmdiff_amd import ops as _ops
+    _ops.FLOPS = [0.0]                          # one more step with the executed-FLOP counter on (outside the timed region)
+    run(1, 50)
+    barrier()
+    executed, _ops.FLOPS = _ops.FLOPS[0], None
+    out = {"seconds": dt, "host_seconds": t_host, "loss": float(m.get_current_log()["l_pix"]), "allreduce": None,
+           "executed_gflop_per_step": executed / 1e9}
     if dist is not None:
         red = m.reducer
         hook_launches = red.launched_last      # of the last timed step (the exchange-free steps below reset it)
@@ -331,8 +379,14 @@ def train_object(leg, world, steps):
     dt = leg["seconds"]
     return {"value": round(world * 8 * steps / dt, 2), "unit": "samples/s", "ms_per_step": round(dt / steps * 1e3, 3),
             "host_enqueue_ms_per_step": round(leg["host_seconds"] / steps * 1e3, 3),
-            "steps": steps, "global_batch": 8 * world, "tflops_per_gpu": round(8 * TRAIN_GFLOP_PER_SAMPLE * 1e-3 * steps / dt, 2),
-            "frac_of_fp32_mfma_peak": round(8 * TRAIN_GFLOP_PER_SAMPLE * 1e-3 * steps / dt / PEAK_FP32_MFMA, 4),
+            "steps": steps, "global_batch": 8 * world,
+            # what the matrix pipe EXECUTES (Winograd forward / data-gradient convolutions and the composed Conv_0 + LL
+            # convolution run fewer multiply-adds than the reference's operator order; the weight gradient runs them all)
+            "executed_tflops_per_gpu": round(leg["executed_gflop_per_step"] * 1e-3 * steps / dt, 2),
+            "frac_of_fp32_mfma_peak_executed": round(leg["executed_gflop_per_step"] * 1e-3 * steps / dt / PEAK_FP32_MFMA, 4),
+            # ... and the same step priced at 3 x the forward's FLOPs in the reference's operator order: a rate
+            # for comparisons with the reference, NOT a fraction of the peak
+            "reference_order_tflops_per_gpu": round(8 * TRAIN_GFLOP_PER_SAMPLE * 1e-3 * steps / dt, 2),
             "loss": round(leg["loss"], 5), "allreduce": leg["allreduce"],
             "what": "BASELINE configs[3] per-GPU share: local batch 8 of 8x64x64 tiles, ch 32-256, dropout 0.2 on, fwd + bwd + "
                     "SUM all-reduce of 216 gradient tensors (RCCL, flat buckets, started from backward hooks) + AdamW + EMA"}
@@ -502,13 +556,21 @@ def main():
                        "batch_per_gpu": BATCH, "tile": [BANDS, SIZE, SIZE], "parallelism": f"batch-parallel x{world}",
                        "weights": "key-hashed random init", "text_embedding": "fixed synthetic 768-d"},
             "sample_steps_per_s": round(world * BATCH * args.steps / dt, 2),
-            "unet_tflops": round(BATCH * GFLOP_PER_SAMPLE * 1e-3 * args.steps / dt, 2),   # reference-order FLOPs / time
+            # 172.39 GFLOP per sample per forward in the REFERENCE's operator order / step time: a rate for comparisons with the
+            # reference (the Winograd / composed kernels execute about half of these multiply-adds, so it may exceed the
+            # 157.3 TFLOP/s matrix peak); the roofline object counts executed FLOPs
+            "unet_reference_order_tflops": round(BATCH * GFLOP_PER_SAMPLE * 1e-3 * args.steps / dt, 2),
             "roofline": {"bound": "mfma", "achieved": round(achieved, 2), "peak": PEAK_FP32_MFMA, "unit": "TFLOP/s",
                          "frac": round(achieved / PEAK_FP32_MFMA, 4), "traffic": traffic, "traffic_source": traffic_src,
-                         "kernel": "3x3x3 conv launches, fp32 v_mfma_f32_32x32x2_f32: conv3d_mfma_kernel<3,..> (fused prologue), "
-                                   "prologue_apply_kernel + conv3d_dma_kernel<3,..> (staged), wino_input_kernel + conv3d_wino_kernel "
-                                   "(Winograd F(4,3) / F(2,3) along the band axis: 2x / 1.5x fewer multiply-adds) or conv3d_ll_kernel (Conv_0 + LL "
-                                   "band of the main branch's down blocks as one strided convolution), chosen per layer",
+                         # every pass in front of a convolution kernel (Winograd input transform of the 8x8 level, prologue
+                         # pass of the three-segment inputs) counted INTO the time: the figure DESIGN.md quotes
+                         "frac_with_transforms": round(fl3 / ((ms3 + ms0) * 1e-3) / 1e12 / PEAK_FP32_MFMA, 4) if ms3 > 0 else 0.0,
+                         "kernel": "3x3x3 conv launches, fp32 v_mfma_f32_32x32x2_f32.  Dominant: conv3d_wf_kernel (Winograd F(4,3) "
+                                   "along the band axis, input transform inside the kernel: 2x fewer multiply-adds, no transform "
+                                   "pass; its prologue pass for three-segment inputs is inside its time).  Others: wino_input_kernel "
+                                   "+ conv3d_wino_kernel (F(2,3) / F(4,3) with a transform pass: the 8x8 level), conv3d_ll_kernel "
+                                   "(Conv_0 + LL band of the main branch's down blocks as one strided convolution), "
+                                   "conv3d_dma_kernel<3,..> / conv3d_mfma_kernel<3,..> (direct), chosen per layer",
                          "flops_counted": "EXECUTED on the matrix pipe (what the roofline bounds); in the reference's operator "
                                           "order the same launches are worth `reference_order_tflops`",
                          "reference_order_tflops": round(fl3_ref / (ms3 * 1e-3) / 1e12, 2) if ms3 > 0 else 0.0,
@@ -525,11 +587,13 @@ def main():
                                       for (k, what), (n, ms, fl) in sorted(conv_by_entry.items()) if k == 3},
                          "input_transform_passes": {"launches": n0, "avg_launch_us": round(ms0 / max(n0, 1) * 1e3, 2),
                                                     "tb_per_s": round(by0 / (ms0 * 1e-3) / 1e12, 2) if ms0 > 0 else 0.0,
-                                                    "note": "wino_input_kernel in front of every conv3d_wino_kernel launch: "
-                                                            "HBM-bound (4 B read + 8 B written per input element), timed apart "
-                                                            "and NOT inside `achieved`; with them the 3x3x3 launches run at "
+                                                    "note": "wino_input_kernel in front of the conv3d_wino_kernel launches that remain "
+                                                            "(the 8x8 level: planes too narrow for conv3d_wf's 8x16 tiles): "
+                                                            "HBM-bound (4 B read + 6.6 B (F(4,3)) / 8.8 B (F(2,3)) written per "
+                                                            "input element), timed apart and NOT inside `achieved`; with them "
+                                                            "the 3x3x3 launches run at "
                                                             f"{round(fl3 / ((ms3 + ms0) * 1e-3) / 1e12, 2) if ms3 > 0 else 0.0} "
-                                                            "TFLOP/s executed"},
+                                                            "TFLOP/s executed = `frac_with_transforms`"},
                          "k1_conv": {"launches": n1, "avg_launch_us": round(ms1 / max(n1, 1) * 1e3, 2),
                                      "tflops": round(fl1 / (ms1 * 1e-3) / 1e12, 2) if ms1 > 0 else 0.0}},
         }
@@ -539,7 +603,7 @@ def main():
                                            "evaluated once inside the timed run instead of every step; outputs are "
                                            "bit-identical (tests/test_gpu_sampling.py)"}
             line["bf16_compute"] = {"value": round(world * args.steps / dt_bf16, 4), "unit": "batch32-steps/s",
-                                    "unet_tflops": round(BATCH * GFLOP_PER_SAMPLE * 1e-3 * args.steps / dt_bf16, 2),
+                                    "unet_reference_order_tflops": round(BATCH * GFLOP_PER_SAMPLE * 1e-3 * args.steps / dt_bf16, 2),
                                     "note": "same full-forward steps with bf16 conv operands / fp32 accumulation "
                                             "(set_compute_dtype('bf16'), the config-3 mode; forward rel-L2 7e-3 vs fp32, "
                                             "tests/test_gpu_bf16.py) -- reduced precision, never `value`"}

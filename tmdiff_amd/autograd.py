@@ -177,7 +177,11 @@ class _ConvLL(torch.autograd.Function):
         if need[3]:
             pre = ops.PACKED.lookup(w) if ops.PACKED is not None else None
             wp_t = pre[1] if pre is not None else ops.pack_conv_weight(w, mode=1)
-            gp = ops.conv3d([g], wp_t, cin, 3)                                     # dL/dx'
+            # dL/dx': a 3x3x3 convolution of the up-sampled gradient -- Winograd along the bands (13.5 multiply-adds per
+            # element; the transposed form of the composed strided convolution would take 12)
+            gp = ops.conv3d_wf([g], None, cin, fallback=lambda: ops.conv3d([g], wp_t, cin, 3),
+                               w_packed_fn=lambda: ops.pack_conv_weight_wino(w, 1, mode=3, planes=6)) if _WINOGRAD else \
+                ops.conv3d([g], wp_t, cin, 3)
             d_x = torch.empty_like(x)
             ops.conv3d_prologue_bwd(ops.make_conv_desc([x], 0, cout, 3, g, in_act=True), gp, [d_x], [False], False, False)
         return None, d_w, d_b, d_x

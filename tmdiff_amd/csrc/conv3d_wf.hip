@@ -124,16 +124,21 @@ struct GeoF {
   static constexpr int XK = (XP + 3) / 4;                 // ... per wave
   static constexpr int PSTRIDE = 196;                     // floats between pieces (192 + 4: consecutive pieces of a wave 16 banks apart)
   static constexpr int RAW_FLOATS = XP * PSTRIDE;
-  static constexpr int V_ELEMS = TT * NP * HH * PW;       // one channel
+  // one band tile's planes; with two tiles the stride is padded to 16 mod 32 banks: a sub-tile of MFMA columns is then 16
+  // positions of one row in BOTH band tiles, and its operand read touches every bank once (two rows of one tile, 18 floats
+  // apart, would share two banks: one more LDS cycle on every operand read)
+  static constexpr bool SPLIT = TT == 2;
+  static constexpr int TSTRIDE = SPLIT ? ((NP * HH * PW + 15) / 32) * 32 + 16 : NP * HH * PW;
+  static constexpr int V_ELEMS = (TT - 1) * TSTRIDE + NP * HH * PW;       // one channel
+  static_assert(!SPLIT || (TSTRIDE % 32 == 16 && TSTRIDE >= NP * HH * PW), "tile stride");
   static constexpr int V_FLOATS = KC * V_ELEMS;
   static constexpr int W_TAPS = 9 * NP;
   static constexpr int W_FLOATS = KC * W_TAPS * CO;
   static constexpr int W_UNITS = W_FLOATS / 4;
   static constexpr int WP = (W_UNITS + 63) / 64, WK = (WP + 3) / 4;
   static constexpr int STAGE = V_FLOATS + WP * 256;
-  static constexpr int TASKS = 12;                        // transform tasks per piece: RPP regions x TT tiles x RQ quads
   static_assert(REG_QUADS * RPP == 48, "a piece is 48 lanes of whole regions");
-  static_assert(RPP * TT * RQ == TASKS && XK * TASKS <= 64, "one transform task per lane");
+  static_assert(RPP * TT == 2, "a piece holds two (region, band tile) pairs: 36 transform tasks");
   static_assert(TT * TH * TW == 4 * NS * 32, "4 waves x NS sub-tiles x 32 positions");
   static_assert(TW == 16, "a sub-tile is two rows of 16 positions");
   static_assert(V_FLOATS % 4 == 0, "stage alignment");
@@ -151,17 +156,17 @@ __device__ __forceinline__ void epilogue_wf(const WfArgs& a, f32x16 (&out)[8], f
                                             int co0, int h0, int w0, int wv, int lane, long plane, float* T) {
   constexpr int MO = 4, DEPTH = 3;
   const int l31 = lane & 31, khalf = lane >> 5, tq = lane & 7, tc = lane >> 3;
-  const int pt = (wv * 64) / (TH * TW);
   const int hw = a.H * a.W;
-  const long cbase = ((long)b * a.Cout + g * a.cout_g + co0 + tc) * plane + (long)(MO * pt) * hw;
+  const long cbase = ((long)b * a.Cout + g * a.cout_g + co0 + tc) * plane;
   int toff[2];
   bool tok[2];
 #pragma unroll
   for (int s = 0; s < 2; ++s) {
-    const int p = (wv * 64 + s * 32 + 4 * tq) % (TH * TW);
-    const int h = h0 + p / TW, w = w0 + p % TW;
+    // the lane's four positions 4 tq .. 4 tq + 3 of sub-tile s (see the operand offsets of the kernel): band tile, row, column
+    const int bt = TT == 2 ? tq >> 2 : 0;
+    const int h = h0 + (TT == 2 ? 2 * wv + s : 4 * wv + 2 * s + (tq >> 2)), w = w0 + 4 * (tq & 3);
     tok[s] = FULL || (h < a.H && w < a.W);                      // (W % 4 == 0: the four positions stand or fall together)
-    toff[s] = tok[s] ? h * a.W + w : 0;
+    toff[s] = tok[s] ? (MO * bt) * hw + h * a.W + w : 0;
   }
   float bias_t[4], sh2_t[4], sc2_t[4];
 #pragma unroll
@@ -218,11 +223,10 @@ __global__ void __launch_bounds__(256, 2) conv3d_wf_kernel(const WfArgs a) {
   using G = GeoF<TT, TH, TW>;
   constexpr int NP = G::NP, MO = G::MO, NB = G::NB, KC = G::KC, CO = G::CO, NS = G::NS, HH = G::HH, RQ = G::RQ, PW = G::PW;
   constexpr int W_TAPS = G::W_TAPS;
-  __shared__ __attribute__((aligned(16))) float lds[2 * G::STAGE + G::RAW_FLOATS + 64];
+  __shared__ __attribute__((aligned(16))) float lds[2 * G::STAGE + G::RAW_FLOATS];
   float* const st0 = lds;
   float* const st1 = lds + G::STAGE;
   float* const raw = lds + 2 * G::STAGE;
-  float* const dummy = raw + G::RAW_FLOATS;      // 64 floats nobody reads: where a lane's out-of-range transform results go
   static_assert(2 * G::STAGE + G::RAW_FLOATS >= 4 * 4096, "the epilogue borrows 16 KB of LDS per wave");
 
   const int tid = threadIdx.x;
@@ -284,66 +288,60 @@ __global__ void __launch_bounds__(256, 2) conv3d_wf_kernel(const WfArgs a) {
     }
   };
 
-  // ---- input transform: lane L < XK * 12 owns task (piece L / 12 of this wave, region / tile / quad from L % 12): the four
-  // columns of its quad, one column per work item (6 ds_read_b32, 22 VALU operations, 6 ds_write_b32: nothing of the
-  // transform stays in registers between work items -- the MFMA loop has ~60 registers beside the accumulators)
-  const int tpi = lane / G::TASKS, tj = lane % G::TASKS;
-  const int tp = wv + 4 * tpi;
-  const int tsub = tj / RQ, tquad = tj % RQ;
-  const int ttile = G::RPP == 1 ? tsub : 0, trsub = G::RPP == 1 ? 0 : tsub;
-  const int tregion = tp * G::RPP + trsub;
-  const bool tvalid = tpi < G::XK && tp < G::XP && tregion < G::NREG;
-  const int tkc = tregion / HH, trow = tregion - tkc * HH;
-  // first / last input band of the tile: band -1 and band NB are the zero padding of the convolution along the bands
-  const bool tlo = ttile > 0, thi = ttile < TT - 1;
-  // raw + trd: the quad's first column in input band MO * ttile (the tile's second input band); band i of the tile at + (i - 1) * RQ * 4
-  const int trd = tvalid ? tp * G::PSTRIDE + trsub * (G::REG_QUADS * 4) + (MO * ttile) * (RQ * 4) + tquad * 4 : RQ * 4;
-  const int twr = tkc * G::V_ELEMS + (ttile * NP * HH + trow) * PW + 4 * tquad - 3;   // + k * HH * PW + column
-  // Work item e handles column (e + trot) % 4 of the lane's quad: the tasks of a wave differ in piece and tile, whose raw
-  // boxes lie a multiple of 32 banks apart -- reading the same column in all of them is a 10-way bank conflict, rotating the
-  // column by (piece, tile) makes it 2-3-way.
-  const int trot = (tpi + 2 * tsub) & 3;
+  // ---- input transform.  A task = one column of one (region, band tile): six input bands in, six planes out.  A wave has
+  // XK pieces x RPP regions x TT tiles x PW columns = 180 tasks, all inside the regions it fetched itself; lane L takes tasks
+  // L, L + 64, L + 128, one per work item (6 ds_read_b32, 16 VALU operations, 6 ds_write_b32 with immediate offsets: nothing
+  // conditional, nothing kept in registers between work items but two addresses per task -- every VALU instruction between
+  // two MFMAs costs the matrix pipe its issue cycles).  Tasks beyond the last repeat an earlier one (same values, same place).
+  constexpr int TPP = G::RPP * TT * PW;                 // tasks per piece (36)
+  constexpr int NTASK = G::XK * TPP, NTR = (NTASK + 63) / 64;
+  int trd[NTR], twr[NTR];
+  bool tlo[NTR], thi[NTR];   // the tile has a band below / above inside the image (else that input band is zero padding)
+#pragma unroll
+  for (int j = 0; j < NTR; ++j) {
+    int id = j * 64 + lane;
+    if (id >= NTASK) id -= TPP;
+    if (wv + 4 * (id / TPP) >= G::XP) id -= TPP;        // (a wave without a last piece)
+    const int tpi = id / TPP, rem = id % TPP, sub = rem / PW, col = rem % PW;
+    const int tp = wv + 4 * tpi;
+    const int ttile = G::RPP == 1 ? sub : 0, trsub = G::RPP == 1 ? 0 : sub;
+    const int tregion = tp * G::RPP + trsub;
+    const int tkc = tregion / HH, trow = tregion - tkc * HH;
+    // raw column of V column c is c + 3 (V columns w0-1 .. w0+TW are raw columns 3 .. TW+4); band i of the tile at + (i - 1) * RQ * 4
+    trd[j] = tp * G::PSTRIDE + trsub * (G::REG_QUADS * 4) + (MO * ttile) * (RQ * 4) + col + 3;
+    twr[j] = tkc * G::V_ELEMS + ttile * G::TSTRIDE + trow * PW + col;      // + k * HH * PW
+    tlo[j] = ttile > 0, thi[j] = ttile < TT - 1;
+  }
   float tin[NP];
-  auto tr_load = [&](auto ec) __attribute__((always_inline)) {      // one work item: the column's six input bands ...
-    constexpr int e = decltype(ec)::value;
-    const float* src = raw + opaque(trd) + ((e + trot) & 3);
+  auto tr_load = [&](auto jc) __attribute__((always_inline)) {      // one work item: the task's six input bands ...
+    constexpr int j = decltype(jc)::value;
+    const float* src = raw + opaque(trd[j]);
 #pragma unroll
     for (int i = 0; i < NP; ++i) tin[i] = src[(i - 1) * (RQ * 4)];
   };
-  auto tr_col = [&](auto ec, float* st) __attribute__((always_inline)) {   // ... the next: its six planes
-    constexpr int e = decltype(ec)::value;
-    const int col = (e + trot) & 3;
-    const float d0 = tlo ? tin[0] : 0.f, d1 = tin[1], d2 = tin[2], d3 = tin[3], d4 = tin[4], d5 = thi ? tin[5] : 0.f;
+  auto tr_col = [&](auto jc, float* st) __attribute__((always_inline)) {   // ... the next: its six planes
+    constexpr int j = decltype(jc)::value;
+    const float d0 = tlo[j] ? tin[0] : 0.f, d1 = tin[1], d2 = tin[2], d3 = tin[3], d4 = tin[4], d5 = thi[j] ? tin[5] : 0.f;
     // B^T = [4 0 -5 0 1 0; 0 -4 -4 1 1 0; 0 4 -4 -1 1 0; 0 -2 -1 2 1 0; 0 2 -1 -2 1 0; 0 4 0 -5 0 1] with the rows' shared
     // sums taken once (14 instead of 22 operations)
     const float a42 = d4 - 4.f * d2, b31 = d3 - 4.f * d1, c42 = d4 - d2, e31 = d3 - d1;
-    float o[NP];
-    o[0] = (4.f * d0 + d4) - 5.f * d2;
-    o[1] = a42 + b31;
-    o[2] = a42 - b31;
-    o[3] = c42 + 2.f * e31;
-    o[4] = c42 - 2.f * e31;
-    o[5] = (4.f * d1 + d5) - 5.f * d3;
-    // V columns w0-1 .. w0+TW are raw columns 3 .. TW+4: the first quad contributes its last element only, the last its first.
-    // Unconditional stores (a branch in the MFMA stream costs the compiler its count of outstanding LDS operations): lanes
-    // without this column store into a dummy slot
-    const bool we = tvalid && (tquad > 0 || col == 3) && (tquad < RQ - 1 || col == 0);
-    float* dst = we ? st + opaque(twr) + col : dummy + lane;
-    const int kstride = we ? HH * PW : 0;
-#pragma unroll
-    for (int k = 0; k < NP; ++k) dst[k * kstride] = o[k];
+    float* dst = st + opaque(twr[j]);
+    dst[0 * HH * PW] = (4.f * d0 + d4) - 5.f * d2;
+    dst[1 * HH * PW] = a42 + b31;
+    dst[2 * HH * PW] = a42 - b31;
+    dst[3 * HH * PW] = c42 + 2.f * e31;
+    dst[4 * HH * PW] = c42 - 2.f * e31;
+    dst[5 * HH * PW] = (4.f * d1 + d5) - 5.f * d3;
   };
 
   // ---- per-lane MFMA operand offsets (floats inside a stage) ---------------------------------------------------------
   // wave wv owns positions wv * 64 .. wv * 64 + 63 of the TT x TH x TW tile (w fastest): sub-tile s = two rows of 16
-  // (sub-tile 1 = the two rows below sub-tile 0: one base address, a constant apart -- one ds_read2_b32 fetches both)
-  const int pt = (wv * 64) / (TH * TW);
-  int boff;
-  {
-    const int p = wv * 64 + l31;
-    const int pw = p % TW, ph = (p / TW) % TH;
-    boff = khalf * G::V_ELEMS + (pt * NP * HH + ph) * PW + pw;
-  }
+  // N = 8 (two band tiles): wave wv owns rows 2 wv, 2 wv + 1 of the tile in both band tiles; sub-tile s = row 2 wv + s, MFMA
+  // column l31 = (band tile l31 >> 4, column l31 & 15).  N = 4: wave wv owns rows 4 wv .. 4 wv + 3, sub-tile s = two rows of 16.
+  // Either way sub-tile 1 lies a constant behind sub-tile 0: one base address, one ds_read2_b32 for both.
+  constexpr int SUB_STEP = G::SPLIT ? PW : 2 * PW;
+  const int boff = khalf * G::V_ELEMS + (G::SPLIT ? (l31 >> 4) * G::TSTRIDE + (2 * wv) * PW + (l31 & 15)
+                                                  : (4 * wv + (l31 >> 4)) * PW + (l31 & 15));
   const int aoff = G::V_FLOATS + khalf * W_TAPS * CO + l31;
 
   float bias_l, sh2_l, sc2_l;
@@ -364,7 +362,7 @@ __global__ void __launch_bounds__(256, 2) conv3d_wf_kernel(const WfArgs a) {
   static_for<0, G::XK>([&](auto k) __attribute__((always_inline)) { issue_raw(k, 0); });
   static_for<0, G::WK>([&](auto k) __attribute__((always_inline)) { issue_w(k, 0, st0); });
   __builtin_amdgcn_s_waitcnt(0x0F70);       // vmcnt(0): this wave's own pieces have landed (it reads its own regions only)
-  static_for<0, 4>([&](auto ec) __attribute__((always_inline)) { tr_load(ec); tr_col(ec, st0); });
+  static_for<0, NTR>([&](auto jc) __attribute__((always_inline)) { tr_load(jc); tr_col(jc, st0); });
   static_for<0, G::XK>([&](auto k) __attribute__((always_inline)) { issue_raw(k, nchunks > 1 ? 1 : 0); });
   __syncthreads();
   WF_STAMP(2);
@@ -373,8 +371,8 @@ __global__ void __launch_bounds__(256, 2) conv3d_wf_kernel(const WfArgs a) {
   // work items between the MFMAs of a chunk (slot = K-step after whose MFMAs the item is placed)
   // (no LDS-DMA is outstanding when the raw box is read: the compiler puts vmcnt(0) in front of LDS reads that a pending
   // DMA might alias)
-  constexpr int SLOT_COL0 = 0, COL_STEP = 6, SLOT_W0 = 26, SLOT_RAW0 = 32, STEP = 2;
-  static_assert(SLOT_COL0 + 4 * COL_STEP <= SLOT_W0 + 1 && SLOT_W0 + G::WK <= SLOT_RAW0 && SLOT_RAW0 + G::XK * STEP <= KSTEPS - 8,
+  constexpr int SLOT_COL0 = 0, COL_STEP = 6, SLOT_W0 = 20, SLOT_RAW0 = 26, STEP = 2;
+  static_assert(SLOT_COL0 + NTR * COL_STEP <= SLOT_W0 + 1 && SLOT_W0 + G::WK <= SLOT_RAW0 && SLOT_RAW0 + G::XK * STEP <= KSTEPS - 8,
                 "work items in order, raw pieces early enough to land");
   auto mfma_chunk = [&](const float* st, int c1, int c2, float* st_next) __attribute__((always_inline)) {
     // st: the stage of this chunk; c1 / c2: the chunks whose weights / raw box are requested now (next, next but one)
@@ -385,7 +383,7 @@ __global__ void __launch_bounds__(256, 2) conv3d_wf_kernel(const WfArgs a) {
       constexpr int toff = (k * HH + dh) * PW + dw;
       av[ks % 3] = st[aoff + ks * CO];
 #pragma unroll
-      for (int s = 0; s < NS; ++s) bv[ks % 3][s] = st[boff + toff + s * 2 * PW];
+      for (int s = 0; s < NS; ++s) bv[ks % 3][s] = st[boff + toff + s * SUB_STEP];
     };
     fetch(std::integral_constant<int, 0>{});
     fetch(std::integral_constant<int, 1>{});
@@ -398,9 +396,9 @@ __global__ void __launch_bounds__(256, 2) conv3d_wf_kernel(const WfArgs a) {
       __builtin_amdgcn_sched_barrier(0);
       acc[k * NS + 1] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[ks % 3], bv[ks % 3][1], acc[k * NS + 1], 0, 0, 0);
       __builtin_amdgcn_sched_barrier(0);
-      if constexpr (TMDIFF_WF_ABLATE < 1 && ks >= SLOT_COL0 && (ks - SLOT_COL0) % COL_STEP == 0 && (ks - SLOT_COL0) / COL_STEP < 4)
+      if constexpr (TMDIFF_WF_ABLATE < 1 && ks >= SLOT_COL0 && (ks - SLOT_COL0) % COL_STEP == 0 && (ks - SLOT_COL0) / COL_STEP < NTR)
         tr_load(std::integral_constant<int, (ks - SLOT_COL0) / COL_STEP>{});
-      if constexpr (TMDIFF_WF_ABLATE < 1 && ks > SLOT_COL0 && (ks - 1 - SLOT_COL0) % COL_STEP == 0 && (ks - 1 - SLOT_COL0) / COL_STEP < 4)
+      if constexpr (TMDIFF_WF_ABLATE < 1 && ks > SLOT_COL0 && (ks - 1 - SLOT_COL0) % COL_STEP == 0 && (ks - 1 - SLOT_COL0) / COL_STEP < NTR)
         tr_col(std::integral_constant<int, (ks - 1 - SLOT_COL0) / COL_STEP>{}, st_next);
       if constexpr (TMDIFF_WF_ABLATE < 3 && ks >= SLOT_W0 && ks < SLOT_W0 + G::WK) issue_w(std::integral_constant<int, ks - SLOT_W0>{}, c1, st_next);
       if constexpr (TMDIFF_WF_ABLATE < 2 && ks >= SLOT_RAW0 && (ks - SLOT_RAW0) % STEP == 0 && (ks - SLOT_RAW0) / STEP < G::XK)

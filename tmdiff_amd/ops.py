@@ -222,9 +222,15 @@ COUNTS = None     # set to a collections.Counter() to count convolution launches
                   # tests and bench.py's parity leg assert from it WHICH kernel family produced a result
 
 
-def _count(what):
+FLOPS = None      # set to [0.0] to add up the multiply-add FLOPs the convolution launches EXECUTE on the matrix pipe (Winograd
+                  # and composed kernels execute fewer than the reference's operator order): bench.py's train_step object
+
+
+def _count(what, flops=0.0):
     if COUNTS is not None:
         COUNTS[what] += 1
+    if FLOPS is not None:
+        FLOPS[0] += flops
 
 
 _WS = {}     # (device index, stream) -> grow-only scratch tensor (prologue outputs / bf16-packed conv inputs); launches
@@ -312,7 +318,7 @@ def conv3d(segs, w_packed, cout, ksize, out=None, math="fp32", pack_input=None, 
             fwd, what = lib.tmdiff_conv3d_fwd, "conv3d_fwd"
     else:
         raise ValueError(f"conv3d: unknown math {math!r}")
-    _count(what if ksize == 3 else what + "_k1")
+    _count(what if ksize == 3 else what + "_k1", 2.0 * b * cout * (d.Cin // d.groups) * ksize ** 3 * n * h * w)
     if TIMER is None:
         check(fwd(C.byref(d), stream_ptr()), what)
         return ret
@@ -395,7 +401,7 @@ def conv3d_wino(segs, w_packed, cout, emit=None, keep_y=True, fallback=None, gro
     ret = y if y2 is None else ((y, y2) if y is not None else y2)
     if xp_out is not None and not (xp_out.is_cuda and xp_out.is_contiguous() and xp_out.numel() == b * d.Cin * n * h * w):
         raise ValueError("conv3d_wino: xp_out must be a contiguous fp32 [B, Cin, N, H, W] tensor")
-    _count(f"conv3d_wino{planes - 2}_fwd")
+    _count(f"conv3d_wino{planes - 2}_fwd", 2.0 * b * cout * (d.Cin // groups) * (9.0 * planes / (planes - 2)) * n * h * w)
     if TIMER is None or xp_out is not None:
         check(lib.tmdiff_conv3d_wino_fwd_planes(C.byref(d), ws, 0, xp_out.data_ptr() if xp_out is not None else None, planes,
                                                 stream_ptr()), "conv3d_wino_fwd")
@@ -462,7 +468,7 @@ def conv3d_wf(segs, w_packed, cout, emit=None, keep_y=True, fallback=None, group
     elif xp_out is not None:          # plain input: x' IS the input
         xp_out.copy_(segs[0])
     ret = y if y2 is None else ((y, y2) if y is not None else y2)
-    _count("conv3d_wf_fwd")
+    _count("conv3d_wf_fwd", 2.0 * b * cout * (d.Cin // groups) * 13.5 * n * h * w)
     if TIMER is None:
         check(lib.tmdiff_conv3d_wf_fwd(C.byref(d), ws, stream_ptr()), "conv3d_wf_fwd")
         return ret
@@ -514,7 +520,7 @@ def conv3d_ll(x, w_packed, cout, ll_scale=0.5, emit=None, keep_y=True, **kw):
     if nsk:
         d.splitk_ws, d.splitk_ws_bytes = _workspace(dev, nsk, "splitk").data_ptr(), nsk
     ret = y if y2 is None else ((y, y2) if y is not None else y2)
-    _count("conv3d_ll_fwd")
+    _count("conv3d_ll_fwd", 2.0 * b * cout * d.Cin * 48 * n * (h // 2) * (w // 2))
     if TIMER is None:
         check(lib.tmdiff_conv3d_ll_fwd(C.byref(d), float(ll_scale), stream_ptr()), "conv3d_ll_fwd")
         return ret
@@ -735,6 +741,7 @@ def conv3d_wgrad(desc, g, weight_shape, want_bias=False):
     """dL/dw [Cout, Cin/g, k,k,k] for the convolution described by `desc` (a filled Conv3dDesc) given g = dL/dy; with
     want_bias also dL/dbias = desc.bias_scale * sum_{b,pos} g, accumulated inside the same kernel: returns (dw, dbias)."""
     dw = torch.empty(weight_shape, device=g.device, dtype=torch.float32)
+    _count("conv3d_wgrad", 2.0 * desc.B * desc.Cout * (desc.Cin // desc.groups) * desc.ksize ** 3 * desc.N * desc.H * desc.W)
     nbytes = lib.tmdiff_conv3d_wgrad_workspace_bytes(C.byref(desc))
     ws = _workspace(g.device, max(4, nbytes), "wgrad")
     if not want_bias:
