@@ -1,7 +1,7 @@
 #!/bin/bash
 # collect_profiles.sh [TAG]: everything profiles/ holds for a round, in one GPU call (~4 min).  Outputs land in
 # gpurun_out/${TAG}_final/ (scratch); copy the summaries into profiles/ afterwards (tools/README.md).
-R=$PWD; TAG=${1:-r02}; O=$R/gpurun_out/${TAG}_final; mkdir -p $O
+R=$PWD; TAG=${1:-r03}; O=$R/gpurun_out/${TAG}_final; mkdir -p $O
 python3 bench.py --steps 20 --warmup 3 > $O/bench_line.json 2> $O/bench.err; echo "bench rc=$?"
 python3 bench.py --mode train --steps 10 --warmup 3 > $O/bench_train_line.json 2>> $O/bench.err; echo "train rc=$?"
 bash tools/bench_traffic.sh $TAG > $O/traffic.log 2>&1; echo "traffic rc=$?"
@@ -13,6 +13,15 @@ python3 tools/bench_conv.py 32 3 fp32 2>&1 | grep -v amdgpu > $O/conv_layers_fp3
 python3 tools/bench_conv.py 32 3 bf16 2>&1 | grep -v amdgpu > $O/conv_layers_bf16.txt
 python3 tools/bench_conv_ll.py 32 5 2>&1 | grep -v amdgpu > $O/conv_ll.txt
 python3 tools/bench_conv_wino.py 32 5 2>&1 | grep -v amdgpu > $O/conv_wino.txt
+python3 tools/bench_conv_wino.py 32 5 epi 2>&1 | grep -v amdgpu > $O/conv_wino_epilogue.txt
+python3 tools/bench_layers.py 5 2>&1 | grep -v amdgpu > $O/bench_layers.txt
+./tools/micro/cu_probe > $O/cu_probe.txt 2>&1
+# (diagnostic builds with s_memrealtime stamps / ablation switches, before the call:
+#  tools/build_variant.sh wstamps "-DTMDIFF_WINO_STAMPS=1" conv3d_wino; tools/build_variant.sh wfstamps "-DTMDIFF_WF_STAMPS=1" conv3d_wf;
+#  for v in 1 2 3: tools/build_variant.sh wfab$v "-DTMDIFF_WF_ABLATE=$v" conv3d_wf)
+[ -f tools/lib_wstamps.so ] && TMDIFF_HIP_LIB=tools/lib_wstamps.so python3 tools/wino_stamps.py 32 2>&1 | grep -v amdgpu > $O/wino_stamps_round2_kernel.txt
+[ -f tools/lib_wfstamps.so ] && TMDIFF_HIP_LIB=tools/lib_wfstamps.so python3 tools/wino_stamps.py 32 wf 2>&1 | grep -v amdgpu > $O/wino_stamps.txt
+for v in 1 2 3; do [ -f tools/lib_wfab$v.so ] && { echo "== TMDIFF_WF_ABLATE=$v (1: no input transform, 2: + no raw DMA, 3: + no weight DMA; results wrong)"; TMDIFF_HIP_LIB=tools/lib_wfab$v.so python3 tools/bench_conv_wino.py 32 5 2>&1 | grep -v amdgpu | cut -c1-48; } >> $O/conv_wf_ablation.txt; done
 python3 tools/bench_bf16_dma.py 32 10 2>&1 | grep -v amdgpu > $O/conv_bf16_packed.txt
 # (diagnostic build with s_memtime stamps: tools/build_variant.sh stamps "-DTMDIFF_BF16_STAMPS=1" conv3d_bf16, before the call)
 [ -f tools/lib_stamps.so ] && TMDIFF_HIP_LIB=tools/lib_stamps.so python3 tools/bf16_stamps.py 32 2>&1 | grep -v amdgpu > $O/conv_bf16_stamps.txt

@@ -1,6 +1,6 @@
 #!/bin/bash
 # copy_profiles.sh [TAG]: copy the summaries tools/collect_profiles.sh left under gpurun_out/ into profiles/ (tracked)
-TAG=${1:-r02}; R=gpurun_out/${TAG}_final
+TAG=${1:-r03}; R=gpurun_out/${TAG}_final
 cp gpurun_out/${TAG}_traffic.json profiles/${TAG}_bench_traffic.json
 cp gpurun_out/${TAG}_traffic/stats/p_kernel_stats.csv profiles/${TAG}_bench_kernel_stats.csv
 cp $R/prof_train/p_kernel_stats.csv profiles/${TAG}_train_step_kernel_stats.csv
@@ -15,3 +15,6 @@ cp $R/conv_bf16_packed.txt profiles/${TAG}_conv_bf16_packed.txt; cp $R/conv_bf16
 cp $R/prof_bf16/p_kernel_stats.csv profiles/${TAG}_bf16_step_kernel_stats.csv
 cp $R/conv_ll.txt profiles/${TAG}_conv_ll.txt; cp $R/pmc_conv_ll.txt profiles/${TAG}_conv_ll_pmc.txt
 cp $R/conv_wino.txt profiles/${TAG}_conv_wino.txt; cp $R/pmc_conv_wino.txt profiles/${TAG}_conv_wino_pmc.txt
+cp $R/conv_wino_epilogue.txt profiles/${TAG}_conv_wino_epilogue.txt; cp $R/bench_layers.txt profiles/${TAG}_bench_layers.txt
+cp $R/cu_probe.txt profiles/${TAG}_cu_probe.txt; cp $R/conv_wf_ablation.txt profiles/${TAG}_conv_wf_ablation.txt
+cp $R/wino_stamps.txt profiles/${TAG}_wino_stamps.txt; cp $R/wino_stamps_round2_kernel.txt profiles/${TAG}_wino_stamps_round2_kernel.txt
