@@ -1,6 +1,9 @@
 #!/usr/bin/env python3
 """The packed-input bf16 convolution kernel alone (input already in bf16 units, as its producer leaves it), per layer
-shape of the bench workload: y only / y + residual + packed second output / packed output only.
+shape of the bench workload: y only / y + residual + packed second output / packed output only.  Per case: time, TFLOP/s
+(dense bf16 MFMA peak 2 500) and the ALGORITHMIC HBM bytes (packed bf16 input 2 B per element, fp32 output / residual 4 B,
+packed second output 2 B; weights and halo re-reads not counted) over the time, as a fraction of the 6.29 TB/s copy rate --
+so that which roof a layer sits under is a number.
 Usage: python tools/bench_bf16_dma.py [B] [reps]"""
 import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -35,7 +38,10 @@ for name, ci, co, h, cnt in LAYERS:
     b = t(lambda: ops.conv3d([xp], w, co, 3, math="bf16", out=y, x_bf16_shape=shp, residual=res, emit=dict(act=True, scale=sc)))
     c = t(lambda: ops.conv3d([xp], w, co, 3, math="bf16", keep_y=False, x_bf16_shape=shp, emit=dict(act=True, scale=sc)))
     fl = 2.0 * B * co * ci * 27 * plane
-    print(f"{name:12s} y {a:7.1f} us {fl / a / 1e6:7.1f} TF | y+res+y2 {b:7.1f} us {fl / b / 1e6:7.1f} TF | y2 only {c:7.1f} us {fl / c / 1e6:7.1f} TF  x{cnt}", flush=True)
+    by = [B * plane * (2 * ci + k * co) for k in (4, 4 + 4 + 2, 2)]        # algorithmic bytes of the three cases
+    hb = lambda nb, us: f"{nb / us / 1e6:4.2f} TB/s = {nb / us / 1e6 / 6.29:4.2f} of copy rate, {fl / us / 1e6 / 2500:4.2f} of MFMA peak"
+    print(f"{name:12s} y {a:7.1f} us {fl / a / 1e6:7.1f} TF ({hb(by[0], a)}) | y+res+y2 {b:7.1f} us {fl / b / 1e6:7.1f} TF ({hb(by[1], b)}) | "
+          f"y2 only {c:7.1f} us {fl / c / 1e6:7.1f} TF ({hb(by[2], c)})  x{cnt}", flush=True)
     for i, v in enumerate((a, b, c)): tot[i] += v * cnt
     totf += fl * cnt
 print("weighted: " + " | ".join(f"{v / 1e3:.2f} ms {totf / v / 1e6:.0f} TF" for v in tot))
