@@ -198,7 +198,8 @@ int tmdiff_conv3d_wino_fwd_planes(const tmdiff_conv3d_desc* d, void* workspace, 
  * convolution input and forms v = B^T d in LDS between its MFMAs: no transformed copy of the input in HBM, no transform
  * pass.  Same descriptor and epilogue as tmdiff_conv3d_fwd (fp32, groups 1 or 3, N = 8 or 4, W % 4 == 0, Cin/groups % 2 == 0,
  * Cout/groups % 32 == 0, no mask tensor).  An input that is ONE plain tensor (no prologue / dropout: every convolution whose
- * producer applied the consumer's prologue, every data-gradient convolution) needs no workspace; otherwise `workspace`
+ * producer applied the consumer's prologue, every data-gradient convolution) -- or, for groups = 3, three plain segments of
+ * Cin/3 channels, one per group -- needs no workspace; otherwise `workspace`
  * (tmdiff_conv3d_wf_workspace_bytes(d) = the input's bytes) receives the prologue output x' first (one elementwise pass,
  * as tmdiff_conv3d_fwd_staged).  d->w_packed = tmdiff_conv3d_wino_pack_weights(..., mode | 2, planes 6): the same
  * transformed weights in natural column order.  Replaces, for the Python reference, the F.conv3d / nn.Conv3d calls of

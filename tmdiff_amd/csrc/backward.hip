@@ -151,6 +151,18 @@ __device__ __forceinline__ void dma_word(const float* src, float* dst) {
 #endif
 }
 
+// The same through a buffer descriptor (round 3, as conv3d_wf.hip): base + size in scalar registers, the per-lane address
+// one 32-bit byte offset; an offset at or beyond the size -- kOutsideW, or anything at all when the size is 0 (a channel row
+// beyond the tensor) -- reads as zero.  A piece then costs its wave no VALU instruction (the pointer form: a compare, a
+// 64-bit add and a 64-bit select per piece, ~180 per box against 224 MFMAs).
+constexpr unsigned kOutsideW = 0xFFFFFFFCu;
+__device__ __forceinline__ void dma_word_buf(const float* base, unsigned bytes, unsigned voff, float* dst) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  __builtin_amdgcn_raw_ptr_buffer_load_lds(__builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(base), 0, bytes, 0x00020000), dst, 4,
+                                           voff, 0, 0, 0);
+#endif
+}
+
 constexpr int WG_WAVES = 8;
 
 template <int KS>
@@ -178,6 +190,7 @@ __global__ void __launch_bounds__(64 * WG_WAVES, 1) conv3d_wgrad_kernel(const Wg
   const int g = id / a.tiles_co;
   const int co0 = co_t * 32, ci0 = ci_t * 32;
   const long plane = (long)a.N * a.H * a.W;
+  const unsigned pbytes = (unsigned)(plane * 4);
 
   f32x16 acc[NT];
 #pragma unroll
@@ -193,7 +206,7 @@ __global__ void __launch_bounds__(64 * WG_WAVES, 1) conv3d_wgrad_kernel(const Wg
   // ---- staging by LDS-DMA: wave w brings in channel rows ROWS*w .. ROWS*w+ROWS-1 of both boxes, one 64-element piece per
   //      instruction (the channel base is wave-uniform; the per-lane position offset is shared by the 8 rows).
   //      Out-of-image positions, layout filler and out-of-range channels read a zero word.
-  int goff[GJ], xoff[XJ];  // position offset inside a channel plane, or -1
+  unsigned goff[GJ], xoff[XJ];  // byte offset of the position inside a channel plane, or kOutsideW
   const float* gbase;      // g  [b][g*cout_g + co0]
   const float* xbase;      // x' [b][g*cin_g + ci0]
   auto locate = [&](long bx) __attribute__((always_inline)) {
@@ -208,14 +221,14 @@ __global__ void __launch_bounds__(64 * WG_WAVES, 1) conv3d_wgrad_kernel(const Wg
       const int p = j * 64 + lane;
       const int n = n0 + p / (BH * BW), h = h0 + (p / BW) % BH, w = w0 + p % BW;
       const bool ok = (n < a.N) & (h < a.H) & (w < a.W);
-      goff[j] = ok ? (n * a.H + h) * a.W + w : -1;
+      goff[j] = ok ? (unsigned)(((n * a.H + h) * a.W + w) * 4) : kOutsideW;
     }
 #pragma unroll
     for (int j = 0; j < XJ; ++j) {
       const int e = j * 64 + lane;
       const int n = n0 + e / (HH * HW) - HALO, h = h0 + (e / HW) % HH - HALO, w = w0 + e % HW - HALO;
       const bool ok = (e < XE) & ((unsigned)n < (unsigned)a.N) & ((unsigned)h < (unsigned)a.H) & ((unsigned)w < (unsigned)a.W);
-      xoff[j] = ok ? (n * a.H + h) * a.W + w : -1;
+      xoff[j] = ok ? (unsigned)(((n * a.H + h) * a.W + w) * 4) : kOutsideW;
     }
     gbase = a.g + ((long)b * a.Cout + g * a.cout_g + co0) * plane;
     xbase = a.xp + ((long)b * a.Cin + g * a.cin_g + ci0) * plane;
@@ -226,12 +239,11 @@ __global__ void __launch_bounds__(64 * WG_WAVES, 1) conv3d_wgrad_kernel(const Wg
       constexpr int c = i / (GJ + XJ), j = i % (GJ + XJ);
       const int ch = wv * ROWS + c;  // wave-uniform
       if constexpr (j < GJ) {
-        const bool ok = (goff[j] >= 0) & (co0 + ch < a.cout_g);
-        dma_word(ok ? gbase + (long)ch * plane + goff[j] : &kZeroWord, st + ch * GS + j * 64);
+        // (wave-uniform: the channel row's plane as the descriptor, an empty one for a row beyond the tensor)
+        dma_word_buf(gbase + (long)ch * plane, co0 + ch < a.cout_g ? pbytes : 0u, goff[j], st + ch * GS + j * 64);
       } else if constexpr (!((TMDIFF_WGRAD_DEBUG & 8) && ((j - GJ) % 3 != 0))) {   // (8: only every third x piece: results wrong)
         constexpr int jj = j - GJ;
-        const bool ok = (xoff[jj] >= 0) & (ci0 + ch < a.cin_g);
-        dma_word(ok ? xbase + (long)ch * plane + xoff[jj] : &kZeroWord, st + 32 * GS + ch * XS + jj * 64);
+        dma_word_buf(xbase + (long)ch * plane, ci0 + ch < a.cin_g ? pbytes : 0u, xoff[jj], st + 32 * GS + ch * XS + jj * 64);
       }
     }
   };

@@ -51,7 +51,9 @@ __device__ __forceinline__ void static_for(F&& f) {
 struct WfArgs {
   int B, N, H, W;
   int Cin, Cout, cin_g, cout_g, groups;
-  const float* x;       // x' [B, Cin, N, H, W]
+  const float* x;       // x' [B, Cin, N, H, W] ...
+  const float* xgrp[3]; // ... or (grouped convolution whose three segments ARE its three groups' inputs) one tensor
+  int grouped_segs;     //     [B, cin_g, N, H, W] per group: the concatenation never has to exist
   const float* wp;      // U packed [g][ci][9][6][co], natural column order (tmdiff_conv3d_wino_pack_weights, mode | 2)
   const float* bias;
   float bias_scale;
@@ -254,7 +256,8 @@ __global__ void __launch_bounds__(256, 2) conv3d_wf_kernel(const WfArgs a) {
   const int hw = a.H * a.W;
   const long plane = (long)a.N * hw;                           // one channel of x' / y
   const int nchunks = a.cin_g / KC;
-  const float* xg = a.x + ((long)b * a.Cin + (long)g * a.cin_g) * plane;
+  const float* xg = a.grouped_segs ? (g == 0 ? a.xgrp[0] : (g == 1 ? a.xgrp[1] : a.xgrp[2])) + (long)b * a.cin_g * plane
+                                   : a.x + ((long)b * a.Cin + (long)g * a.cin_g) * plane;
   const float* wg = a.wp + (long)g * a.cin_g * W_TAPS * a.cout_g + co0;
 
   // ---- DMA: raw pieces (48 lanes: RPP regions of NB bands x RQ quads) and weight pieces ------------------------------
@@ -490,8 +493,14 @@ bool wf_shape_ok(const tmdiff_conv3d_desc* d) {
          d->W % 4 == 0;
 }
 
+// three plain segments that are exactly the three groups' inputs (convH_0 on the three high bands of the skip connection)
+bool wf_grouped_segs(const tmdiff_conv3d_desc* d) {
+  return d->nseg == 3 && d->groups == 3 && d->seg_c[0] == d->seg_c[1] && d->seg_c[1] == d->seg_c[2] &&
+         d->seg_c[0] * 3 == d->Cin;
+}
+
 bool wf_plain(const tmdiff_conv3d_desc* d) {
-  return d->nseg == 1 && !d->in_shift && !d->in_scale && !d->in_act && !(d->drop_p > 0.f);
+  return (d->nseg == 1 || wf_grouped_segs(d)) && !d->in_shift && !d->in_scale && !d->in_act && !(d->drop_p > 0.f);
 }
 
 }  // namespace
@@ -536,6 +545,8 @@ extern "C" int tmdiff_conv3d_wf_fwd(const tmdiff_conv3d_desc* d, void* workspace
     x = static_cast<const float*>(workspace);
   }
   WfArgs a;
+  a.grouped_segs = wf_plain(d) && d->nseg == 3;
+  for (int i = 0; i < 3; ++i) a.xgrp[i] = a.grouped_segs ? d->seg_x[i] : nullptr;
   a.B = d->B; a.N = d->N; a.H = d->H; a.W = d->W;
   a.Cin = d->Cin; a.Cout = d->Cout; a.groups = d->groups; a.cin_g = d->Cin / d->groups; a.cout_g = d->Cout / d->groups;
   a.x = x; a.wp = d->w_packed;

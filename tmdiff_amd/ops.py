@@ -466,7 +466,7 @@ def conv3d_wf(segs, w_packed, cout, emit=None, keep_y=True, fallback=None, group
         else:
             ws = _workspace(dev, nws).data_ptr()
     elif xp_out is not None:          # plain input: x' IS the input
-        xp_out.copy_(segs[0])
+        xp_out.copy_(segs[0] if len(segs) == 1 else torch.cat(segs, 1))
     ret = y if y2 is None else ((y, y2) if y is not None else y2)
     _count("conv3d_wf_fwd", 2.0 * b * cout * (d.Cin // groups) * 13.5 * n * h * w)
     if TIMER is None:
