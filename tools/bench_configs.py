@@ -1,6 +1,7 @@
 #!/usr/bin/env python3
-"""Secondary measurements for DESIGN.md (not the headline bench): BASELINE configs 1, 3 (fp32 and bf16 compute) and the
-finetune step of config 4 on ONE GPU.  Prints one line per config."""
+"""Secondary measurements for DESIGN.md (not the headline bench): BASELINE configs 1, 3 (fp32 and bf16 compute), the
+finetune step of config 4 and the per-GPU share of config 5 (mixed 4-band GF-2 / 8-band WV-3 tiles) on ONE GPU.
+Prints one line per config.  Usage: python tools/bench_configs.py [c1] [c3] [c4] [c5]"""
 import os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np, torch
@@ -12,7 +13,7 @@ def sync_time(fn):
     torch.cuda.synchronize(); t0 = time.perf_counter(); out = fn(); torch.cuda.synchronize()
     return time.perf_counter() - t0, out
 
-which = sys.argv[1:] or ["c1", "c3", "c4"]
+which = sys.argv[1:] or ["c1", "c3", "c4", "c5"]
 if "c1" in which:   # single 8-ch 64x64 tile, 50-step DDPM
     net = fill_weights_(WavBEST(channels=[32, 64, 128, 256])).cuda().eval()
     diff = GeneralDiffusion(net, "l1").cuda(); diff.set_new_noise_schedule({"schedule": "cosine", "n_timestep": 50}, "cuda")
@@ -60,3 +61,23 @@ if "c4" in which:   # finetune step, local batch 8, ch 32-256, AdamW, dropout on
     dt, loss = sync_time(lambda: [step() for _ in range(5)])
     print(f"config4 (1 GPU share): train step local batch 8, 8x64x64, dropout on: {dt / 5 * 1e3:.1f} ms/step "
           f"({3 * 8 * 172.39 / (dt / 5) / 1e3:.1f} TFLOP/s at 3x forward FLOPs), loss {loss[-1]:.4f}", flush=True)
+if "c5" in which:   # multi-satellite config: a 512x512 scene = 64 tiles of 64x64; one GPU's share of a mixed GF-2 (4 bands,
+    # prompt "GF2") / WV-3 (8 bands, "WV3") job is a batch of each.  The reference never mixes band counts within a batch
+    # (general_sharpening...py:45-53): two sub-batches of 32 tiles, 10 DDPM steps each, condition branch cached.
+    net = fill_weights_(WavBEST(channels=[32, 64, 128, 256])).cuda().eval()
+    diff = GeneralDiffusion(net, "l1").cuda(); diff.set_new_noise_schedule({"schedule": "cosine", "n_timestep": 1000}, "cuda")
+    for bands, prompt in ((4, "GF2"), (8, "WV3")):
+        d = synthetic_tile_batch(3407 + bands, 32, bands, 64, device="cuda")
+        x = torch.randn_like(d["Res"])
+        net.begin_condition_cache(d["PAN"], d["MS"], prompt)
+        for i in range(3):
+            x = diff.p_sample(x, 999 - i, condition_x=d, prompt=prompt)
+        def run(x=x):
+            for i in range(10):
+                x = diff.p_sample(x, 990 - i, condition_x=d, prompt=prompt)
+            return x
+        dt, _ = sync_time(run)
+        net.end_condition_cache()
+        gf = 109.57 * bands / 8          # per sample per step, condition branch cached
+        print(f"config5 ({prompt}, {bands} bands): 32 tiles of {bands}x64x64, condition branch cached: {dt / 10 * 1e3:.2f} ms per step "
+              f"-> {32 * 10 / dt:.0f} tile-steps/s ({32 * gf / (dt / 10) / 1e3:.1f} TFLOP/s in the reference's operator order)", flush=True)

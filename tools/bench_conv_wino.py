@@ -8,7 +8,8 @@ from tmdiff_amd import ops
 
 B = int(sys.argv[1]) if len(sys.argv) > 1 else 32
 REPS = int(sys.argv[2]) if len(sys.argv) > 2 else 5
-EPI = len(sys.argv) > 3 and sys.argv[3] == "epi"     # with residual + second output (the in-network conv21 epilogue)
+EPI = "epi" in sys.argv[3:]      # with residual + second output (the in-network conv21 epilogue)
+NB = 4 if "n4" in sys.argv[3:] else 8     # band count of the tensors (n4: GF-2 / QuickBird)
 LAYERS = [("L0 32->32", 32, 32, 64), ("L0 32->64", 32, 64, 64), ("L0 64->64", 64, 64, 64), ("L1 64->128", 64, 128, 32),
           ("L1 128->128", 128, 128, 32), ("L2 256->256", 256, 256, 16), ("L3 256->256", 256, 256, 8)]
 
@@ -23,20 +24,20 @@ def t(fn):
 
 
 for name, ci, co, h in LAYERS:
-    x = torch.randn(B, ci, 8, h, h, device="cuda")
+    x = torch.randn(B, ci, NB, h, h, device="cuda")
     w = torch.randn(co, ci, 3, 3, 3, device="cuda") / (ci * 27) ** 0.5
-    y = torch.empty(B, co, 8, h, h, device="cuda")
-    ww, wd = ops.pack_conv_weight_wino(w, planes=ops.wino_planes(8)), ops.pack_conv_weight(w)
+    y = torch.empty(B, co, NB, h, h, device="cuda")
+    ww, wd = ops.pack_conv_weight_wino(w, planes=ops.wino_planes(NB)), ops.pack_conv_weight(w)
     wf = ops.pack_conv_weight_wino(w, planes=6, mode=2)
     kw = {}
     if EPI:
-        res = torch.randn(B, co, 8, h, h, device="cuda")
+        res = torch.randn(B, co, NB, h, h, device="cuda")
         sc = torch.rand(B, co, device="cuda") + 0.5
         kw = dict(residual=res, emit=dict(act=True, scale=sc))
     f = t(lambda: ops.conv3d_wf([x], wf, co, **kw))
     a = t(lambda: ops.conv3d_wino([x], ww, co, **kw))
     b = t(lambda: ops.conv3d([x], wd, co, 3, out=y))
-    fl = 2.0 * B * co * ci * 27 * 8 * h * h
-    red = 27.0 / (9.0 * ops.wino_planes(8) / (ops.wino_planes(8) - 2))       # 2 for F(4,3), 1.5 for F(2,3)
+    fl = 2.0 * B * co * ci * 27 * NB * h * h
+    red = 27.0 / (9.0 * ops.wino_planes(NB) / (ops.wino_planes(NB) - 2))       # 2 for F(4,3), 1.5 for F(2,3)
     print(f"{name:12s} wf {f:6.3f} ms ({fl / 2 / f / 1e9:6.1f} executed) | winograd+pass {a:6.3f} ms ({fl / a / 1e9:6.1f} TFLOP/s in the direct count, {fl / red / a / 1e9:6.1f} executed) | "
           f"direct {b:6.3f} ms ({fl / b / 1e9:6.1f} TFLOP/s)", flush=True)
