@@ -379,25 +379,33 @@ __global__ void __launch_bounds__(256, 2) conv3d_wf_kernel(const WfArgs a) {
                 "work items in order, raw pieces early enough to land");
   auto mfma_chunk = [&](const float* st, int c1, int c2, float* st_next) __attribute__((always_inline)) {
     // st: the stage of this chunk; c1 / c2: the chunks whose weights / raw box are requested now (next, next but one)
-    float av[3], bv[3][NS];                 // operands are fetched two K-steps (four MFMAs) ahead
-    auto fetch = [&](auto ksc) __attribute__((always_inline)) {
+    // operands are fetched two K-steps (four MFMAs) ahead: the weights of two consecutive K-steps by ONE ds_read2_b32 (their
+    // rows lie 32 floats apart), the two sub-tiles' positions by another
+    float av[4], bv[3][NS];
+    auto fetch_a2 = [&](auto ksc) __attribute__((always_inline)) {      // weights of K-steps ks, ks + 1 (ks even)
+      constexpr int ks = decltype(ksc)::value;
+      av[ks % 4] = st[aoff + ks * CO];
+      if constexpr (ks + 1 < KSTEPS) av[(ks + 1) % 4] = st[aoff + (ks + 1) * CO];
+    };
+    auto fetch_b = [&](auto ksc) __attribute__((always_inline)) {
       constexpr int ks = decltype(ksc)::value;
       constexpr int k = ks % NP, dh = (ks / NP) / 3, dw = (ks / NP) % 3;
       constexpr int toff = (k * HH + dh) * PW + dw;
-      av[ks % 3] = st[aoff + ks * CO];
 #pragma unroll
       for (int s = 0; s < NS; ++s) bv[ks % 3][s] = st[boff + toff + s * SUB_STEP];
     };
-    fetch(std::integral_constant<int, 0>{});
-    fetch(std::integral_constant<int, 1>{});
+    fetch_a2(std::integral_constant<int, 0>{});
+    fetch_b(std::integral_constant<int, 0>{});
+    fetch_b(std::integral_constant<int, 1>{});
     static_for<0, KSTEPS>([&](auto ksc) __attribute__((always_inline)) {
       constexpr int ks = decltype(ksc)::value;
       constexpr int k = ks % NP;
-      acc[k * NS + 0] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[ks % 3], bv[ks % 3][0], acc[k * NS + 0], 0, 0, 0);
+      acc[k * NS + 0] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[ks % 4], bv[ks % 3][0], acc[k * NS + 0], 0, 0, 0);
       __builtin_amdgcn_sched_barrier(0);
-      if constexpr (ks + 2 < KSTEPS) fetch(std::integral_constant<int, ks + 2>{});
+      if constexpr (ks % 2 == 0 && ks + 2 < KSTEPS) fetch_a2(std::integral_constant<int, ks + 2>{});
+      if constexpr (ks + 2 < KSTEPS) fetch_b(std::integral_constant<int, ks + 2>{});
       __builtin_amdgcn_sched_barrier(0);
-      acc[k * NS + 1] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[ks % 3], bv[ks % 3][1], acc[k * NS + 1], 0, 0, 0);
+      acc[k * NS + 1] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[ks % 4], bv[ks % 3][1], acc[k * NS + 1], 0, 0, 0);
       __builtin_amdgcn_sched_barrier(0);
       if constexpr (TMDIFF_WF_ABLATE < 1 && ks >= SLOT_COL0 && (ks - SLOT_COL0) % COL_STEP == 0 && (ks - SLOT_COL0) / COL_STEP < NTR)
         tr_load(std::integral_constant<int, (ks - SLOT_COL0) / COL_STEP>{});
