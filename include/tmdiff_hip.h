@@ -205,7 +205,11 @@ int tmdiff_conv3d_wino_fwd_planes(const tmdiff_conv3d_desc* d, void* workspace, 
  * transformed weights in natural column order.  Replaces, for the Python reference, the F.conv3d / nn.Conv3d calls of
  * GeneralModel/Hyper_unet_general.py:51-77, :161-164, :224-227, :344-361 on 8- and 4-band tensors. */
 int tmdiff_conv3d_wf_supported(const tmdiff_conv3d_desc* d);
-int64_t tmdiff_conv3d_wf_blocks(const tmdiff_conv3d_desc* d);     /* workgroups of its grid (no split-K: keep small grids on tmdiff_conv3d_fwd) */
+int64_t tmdiff_conv3d_wf_blocks(const tmdiff_conv3d_desc* d);     /* workgroups of its grid, split-K included */
+/* small grids (single images, the deep levels of a small batch) split the input channels over workgroups when d->splitk_ws
+ * lends tmdiff_conv3d_wf_splitk_workspace_bytes(d) bytes (0: the grid needs no split); splitk_reduce_kernel sums the ranges
+ * in a fixed order and applies the epilogue, as for tmdiff_conv3d_fwd */
+size_t tmdiff_conv3d_wf_splitk_workspace_bytes(const tmdiff_conv3d_desc* d);
 size_t tmdiff_conv3d_wf_workspace_bytes(const tmdiff_conv3d_desc* d);
 int tmdiff_conv3d_wf_fwd(const tmdiff_conv3d_desc* d, void* workspace, tmdiff_stream_t stream);
 

@@ -666,6 +666,9 @@ def test_conv3d_winograd_along_bands(ops, case):
     (1, (6,), 32, 4, 20, 24, 1),          # N = 4, ragged
     (1, (4, 4, 4), 96, 4, 16, 16, 3),     # N = 4, groups = 3
     (3, (64,), 64, 8, 32, 32, 1),         # 32 chunks, several workgroups per image
+    (1, (64,), 64, 8, 16, 16, 1),         # 4 tiles: split over the input channels (16 ranges of 2 chunks) + reduction kernel
+    (2, (48,), 32, 4, 16, 32, 1),         # N = 4, split-K (12 ranges)
+    (1, (8, 8, 8), 96, 8, 8, 16, 3),      # groups = 3 with split-K (2 ranges of 2 chunks)
 ])
 def test_conv3d_winograd_in_kernel_transform(ops, case):
     """tmdiff_conv3d_wf_fwd: Winograd F(4,3) along the bands with the input transform inside the kernel (no transformed

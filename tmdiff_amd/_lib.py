@@ -54,6 +54,7 @@ SIGNATURES = {
     "tmdiff_conv3d_wf_supported": (C.c_int, [C.POINTER(Conv3dDesc)]),
     "tmdiff_conv3d_wf_blocks": (C.c_int64, [C.POINTER(Conv3dDesc)]),
     "tmdiff_conv3d_wf_workspace_bytes": (C.c_size_t, [C.POINTER(Conv3dDesc)]),
+    "tmdiff_conv3d_wf_splitk_workspace_bytes": (C.c_size_t, [C.POINTER(Conv3dDesc)]),
     "tmdiff_conv3d_wf_fwd": (C.c_int, [C.POINTER(Conv3dDesc), vp, vp]),
     "tmdiff_conv3d_wino_fwd": (C.c_int, [C.POINTER(Conv3dDesc), vp, vp]),
     "tmdiff_conv3d_wino_fwd_planes": (C.c_int, [C.POINTER(Conv3dDesc), vp, C.c_int32, vp, C.c_int32, vp]),

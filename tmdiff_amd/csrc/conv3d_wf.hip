@@ -67,6 +67,8 @@ struct WfArgs {
   int tiles_h, tiles_w, tiles_co;
   unsigned total_blocks;
   int vec4;
+  int ksplit, split_chunks;   // split-K (small grids): ksplit ranges of split_chunks chunks each; 1 = no split
+  float* part;                // ... whose partial outputs go to part[split][B][Cout][plane] (splitk_reduce_kernel finishes)
   unsigned long long* stamps;
   int stagger;
   unsigned first_round;
@@ -155,7 +157,8 @@ struct GeoF {
 // per block, eight times per tile: 22 of the 33 us of a tile's epilogue at 32 input channels (tools/wino_stamps.py).
 template <bool Y, bool RES, bool Y2, bool FULL, int TT, int TH, int TW>
 __device__ __forceinline__ void epilogue_wf(const WfArgs& a, f32x16 (&out)[8], float bias_l, float sh2_l, float sc2_l, int b, int g,
-                                            int co0, int h0, int w0, int wv, int lane, long plane, float* T) {
+                                            int co0, int h0, int w0, int wv, int lane, long plane, float* T, float* ydst,
+                                            float oscale) {
   constexpr int MO = 4, DEPTH = 3;
   const int l31 = lane & 31, khalf = lane >> 5, tq = lane & 7, tc = lane >> 3;
   const int hw = a.H * a.W;
@@ -200,10 +203,10 @@ __device__ __forceinline__ void epilogue_wf(const WfArgs& a, f32x16 (&out)[8], f
         q[0] = rq.x, q[1] = rq.y, q[2] = rq.z, q[3] = rq.w;
       }
 #pragma unroll
-      for (int e = 0; e < 4; ++e) v[e] = (v[e] + bias_t[j] + q[e]) * a.out_scale;   // as the scalar epilogue
+      for (int e = 0; e < 4; ++e) v[e] = (v[e] + bias_t[j] + q[e]) * oscale;   // as the scalar epilogue
       const long o = cbase + (long)(8 * j) * plane + (long)n * hw + toff[s];
       if constexpr (Y) {
-        if (FULL || tok[s]) *reinterpret_cast<float4*>(a.y + o) = make_float4(v[0], v[1], v[2], v[3]);
+        if (FULL || tok[s]) *reinterpret_cast<float4*>(ydst + o) = make_float4(v[0], v[1], v[2], v[3]);
       }
       if constexpr (Y2) {
         float u[4];
@@ -246,6 +249,7 @@ __global__ void __launch_bounds__(256, 2) conv3d_wf_kernel(const WfArgs a) {
   WF_STAMP(1);
 
   unsigned id = xcd_remap(blockIdx.x, a.total_blocks);
+  const int split = __builtin_amdgcn_readfirstlane(id % a.ksplit); id /= a.ksplit;      // (1: no split-K)
   const int co_tile = __builtin_amdgcn_readfirstlane(id % a.tiles_co); id /= a.tiles_co;
   const int tw_i = __builtin_amdgcn_readfirstlane(id % a.tiles_w); id /= a.tiles_w;
   const int th_i = __builtin_amdgcn_readfirstlane(id % a.tiles_h); id /= a.tiles_h;
@@ -255,10 +259,10 @@ __global__ void __launch_bounds__(256, 2) conv3d_wf_kernel(const WfArgs a) {
   const int co0 = co_tile * CO;
   const int hw = a.H * a.W;
   const long plane = (long)a.N * hw;                           // one channel of x' / y
-  const int nchunks = a.cin_g / KC;
-  const float* xg = a.grouped_segs ? (g == 0 ? a.xgrp[0] : (g == 1 ? a.xgrp[1] : a.xgrp[2])) + (long)b * a.cin_g * plane
-                                   : a.x + ((long)b * a.Cin + (long)g * a.cin_g) * plane;
-  const float* wg = a.wp + (long)g * a.cin_g * W_TAPS * a.cout_g + co0;
+  const int nchunks = a.split_chunks;                          // this workgroup's range of input-channel chunks
+  const float* xg = (a.grouped_segs ? (g == 0 ? a.xgrp[0] : (g == 1 ? a.xgrp[1] : a.xgrp[2])) + (long)b * a.cin_g * plane
+                                    : a.x + ((long)b * a.Cin + (long)g * a.cin_g) * plane) + (long)split * nchunks * KC * plane;
+  const float* wg = a.wp + ((long)g * a.cin_g + (long)split * nchunks * KC) * W_TAPS * a.cout_g + co0;
 
   // ---- DMA: raw pieces (48 lanes: RPP regions of NB bands x RQ quads) and weight pieces ------------------------------
   // descriptors per chunk: the chunk's KC channels of x' (everything outside reads as zero) / its KC * 54 weight rows
@@ -451,10 +455,14 @@ __global__ void __launch_bounds__(256, 2) conv3d_wf_kernel(const WfArgs a) {
   const bool full = h0 + TH <= a.H && w0 + TW <= a.W;
 #define WF_EPI2(Y, R, Y2)                                                                                                   \
   do {                                                                                                                      \
-    if (full) epilogue_wf<Y, R, Y2, true, TT, TH, TW>(a, out, bias_l, sh2_l, sc2_l, b, g, co0, h0, w0, wv, lane, plane, T);  \
-    else epilogue_wf<Y, R, Y2, false, TT, TH, TW>(a, out, bias_l, sh2_l, sc2_l, b, g, co0, h0, w0, wv, lane, plane, T);      \
+    if (full) epilogue_wf<Y, R, Y2, true, TT, TH, TW>(a, out, bias_l, sh2_l, sc2_l, b, g, co0, h0, w0, wv, lane, plane, T, a.y, a.out_scale);  \
+    else epilogue_wf<Y, R, Y2, false, TT, TH, TW>(a, out, bias_l, sh2_l, sc2_l, b, g, co0, h0, w0, wv, lane, plane, T, a.y, a.out_scale);      \
   } while (0)
-  if (a.y) {
+  if (a.part) {     // split-K: this range's partial sums, bare (bias / residual / scale / second output: splitk_reduce_kernel)
+    float* pd = a.part + (long)split * a.B * a.Cout * plane;
+    if (full) epilogue_wf<true, false, false, true, TT, TH, TW>(a, out, 0.f, 0.f, 1.f, b, g, co0, h0, w0, wv, lane, plane, T, pd, 1.f);
+    else epilogue_wf<true, false, false, false, TT, TH, TW>(a, out, 0.f, 0.f, 1.f, b, g, co0, h0, w0, wv, lane, plane, T, pd, 1.f);
+  } else if (a.y) {
     if (a.residual) { if (a.y2) WF_EPI2(true, true, true); else WF_EPI2(true, true, false); }
     else            { if (a.y2) WF_EPI2(true, false, true); else WF_EPI2(true, false, false); }
   } else {
@@ -480,7 +488,7 @@ int launch(WfArgs& a, hipStream_t st) {
   a.tiles_h = (a.H + TH - 1) / TH;
   a.tiles_w = (a.W + TW - 1) / TW;
   a.tiles_co = a.cout_g / 32;
-  const long blocks = (long)a.B * a.groups * a.tiles_h * a.tiles_w * a.tiles_co;
+  const long blocks = (long)a.ksplit * a.B * a.groups * a.tiles_h * a.tiles_w * a.tiles_co;
   if (blocks <= 0 || blocks > 0x7fffffffL) return tmdiff::fail(TMDIFF_E_INVALID, "conv3d_wf_fwd: grid of %ld blocks", blocks);
   a.total_blocks = (unsigned)blocks;
   static const double stagger_chunks = [] {
@@ -507,6 +515,30 @@ bool wf_grouped_segs(const tmdiff_conv3d_desc* d) {
          d->seg_c[0] * 3 == d->Cin;
 }
 
+long wf_tiles(const tmdiff_conv3d_desc* d) {
+  const int th = d->N == 8 ? 8 : 16;
+  return (long)d->B * d->groups * ((d->H + th - 1) / th) * ((d->W + 15) / 16) * (d->Cout / d->groups / 32);
+}
+
+// split-K factor for grids that cannot fill the chip (two workgroups per CU are resident): the smallest divisor of the chunk
+// count that brings the grid to 384 workgroups (as plan_conv3), at least two chunks per range; TMDIFF_SPLITK=0: never
+int wf_ksplit(const tmdiff_conv3d_desc* d) {
+  static const long target = [] {
+    const char* e = getenv("TMDIFF_SPLITK");
+    return e ? atol(e) : 384L;
+  }();
+  const long tiles = wf_tiles(d);
+  const int nchunks = d->Cin / d->groups / 2;
+  if (target <= 0 || tiles >= target) return 1;
+  int best = 1;
+  for (int s = 2; s <= nchunks / 2; ++s) {
+    if (nchunks % s) continue;
+    best = s;
+    if (tiles * s >= target) break;
+  }
+  return best;
+}
+
 bool wf_plain(const tmdiff_conv3d_desc* d) {
   return (d->nseg == 1 || wf_grouped_segs(d)) && !d->in_shift && !d->in_scale && !d->in_act && !(d->drop_p > 0.f);
 }
@@ -515,10 +547,17 @@ bool wf_plain(const tmdiff_conv3d_desc* d) {
 
 extern "C" int tmdiff_conv3d_wf_supported(const tmdiff_conv3d_desc* d) { return wf_shape_ok(d) ? 1 : 0; }
 
+/* workgroups of the grid when the split-K workspace is lent (tiles x split factor) */
 extern "C" int64_t tmdiff_conv3d_wf_blocks(const tmdiff_conv3d_desc* d) {
   if (!wf_shape_ok(d) || d->B <= 0) return 0;
-  const int th = d->N == 8 ? 8 : 16;
-  return (int64_t)d->B * d->groups * ((d->H + th - 1) / th) * ((d->W + 15) / 16) * (d->Cout / d->groups / 32);
+  return (int64_t)wf_tiles(d) * wf_ksplit(d);
+}
+
+/* bytes of partial outputs a small grid splits its input channels into (lend them through d->splitk_ws; 0: no split) */
+extern "C" size_t tmdiff_conv3d_wf_splitk_workspace_bytes(const tmdiff_conv3d_desc* d) {
+  if (!wf_shape_ok(d) || d->B <= 0) return 0;
+  const int ks = wf_ksplit(d);
+  return ks > 1 ? (size_t)ks * d->B * d->Cout * d->N * d->H * d->W * sizeof(float) : 0;
 }
 
 /* bytes of the prologue output x' the entry point forms first when the input is not one plain tensor (0: plain input) */
@@ -565,6 +604,17 @@ extern "C" int tmdiff_conv3d_wf_fwd(const tmdiff_conv3d_desc* d, void* workspace
   a.y2_scale_stride = d->y2_scale_stride > 0 ? d->y2_scale_stride : (d->y2_scale_stride < 0 ? 0 : d->Cout);
   a.vec4 = 1;
   a.stamps = TMDIFF_WF_STAMPS ? static_cast<unsigned long long*>(d->splitk_ws) : nullptr;
-  if (d->N == 8) return launch<2, 8, 16>(a, st);
-  return launch<1, 16, 16>(a, st);
+  a.ksplit = 1; a.split_chunks = a.cin_g / 2; a.part = nullptr;
+  if (!TMDIFF_WF_STAMPS) {
+    const int ks = wf_ksplit(d);
+    const size_t need = (size_t)ks * d->B * d->Cout * d->N * d->H * d->W * sizeof(float);
+    if (ks > 1 && d->splitk_ws && (size_t)d->splitk_ws_bytes >= need && aligned16(d->splitk_ws)) {
+      a.ksplit = ks; a.split_chunks = a.cin_g / 2 / ks; a.part = static_cast<float*>(d->splitk_ws);
+    }
+  }
+  const int rc = d->N == 8 ? launch<2, 8, 16>(a, st) : launch<1, 16, 16>(a, st);
+  if (rc || !a.part) return rc;
+  SplitKReduceArgs r{a.part, a.ksplit, d->B, d->Cout, (long)d->N * d->H * d->W, d->bias, d->bias_scale, d->residual,
+                     d->out_scale, d->y, d->y2, d->y2_shift, d->y2_scale, a.y2_shift_stride, a.y2_scale_stride, d->y2_act};
+  return launch_splitk_reduce(r, st);
 }

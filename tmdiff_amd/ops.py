@@ -422,6 +422,7 @@ def conv3d_wino(segs, w_packed, cout, emit=None, keep_y=True, fallback=None, gro
 
 _WF = os.environ.get("TMDIFF_WF", "1") != "0"    # experiments: "0" = never the in-kernel-transform Winograd kernel (conv3d_wf)
 _WF_MIN_FILL = float(os.environ.get("TMDIFF_WF_MIN_FILL", "0.7"))
+_WF_SPLITK = os.environ.get("TMDIFF_WF_SPLITK", "1") != "0"      # experiments: "0" = small grids go to the fallback kernels
 
 
 def conv3d_wf(segs, w_packed, cout, emit=None, keep_y=True, fallback=None, groups=1, w_packed_fn=None, xp_out=None, **kw):
@@ -435,14 +436,25 @@ def conv3d_wf(segs, w_packed, cout, emit=None, keep_y=True, fallback=None, group
     b, _, n, h, w = segs[0].shape
     dev = segs[0].device
     cg = cout // groups
-    blocks = b * groups * ((h + 7) // 8 if n == 8 else (h + 15) // 16) * ((w + 15) // 16) * (cg // 32) if cg % 32 == 0 else 0
     cin = sum(s_.shape[1] for s_ in segs)
-    ok = _WF and n in (4, 8) and w % 4 == 0 and cg % 32 == 0 and (cin // groups) % 2 == 0 and kw.get("in_mask") is None
     th = 8 if n == 8 else 16
+    tiles = b * groups * ((h + th - 1) // th) * ((w + 15) // 16) * (cg // 32) if cg % 32 == 0 else 0
+    # small grids split their input channels over workgroups (the smallest divisor of the chunk count that reaches 384
+    # workgroups, at least two chunks per range: tmdiff_conv3d_wf_blocks) -- single images, the deep levels of a local batch
+    nchunks = (cin // groups) // 2
+    split = 1
+    if 0 < tiles < 384:
+        for s_ in range(2, nchunks // 2 + 1):
+            if nchunks % s_ == 0:
+                split = s_
+                if tiles * s_ >= 384:
+                    break
+    blocks = tiles * (split if _WF_SPLITK else 1)
+    ok = _WF and n in (4, 8) and w % 4 == 0 and cg % 32 == 0 and (cin // groups) % 2 == 0 and kw.get("in_mask") is None
     # (tiles of th x 16 positions: an 8 x 8 plane would leave half of every tile empty -- those go to the fallback)
     fill = (h * w) / float(((h + th - 1) // th) * th * ((w + 15) // 16) * 16)
     if fallback is not None and (not ok or blocks < _WINO_MIN_BLOCKS or fill < _WF_MIN_FILL):
-        return fallback()
+        return fallback()            # unsupported extents, or a grid too small even with its input channels split
     if w_packed is None:
         w_packed = w_packed_fn()
     y = torch.empty(b, cout, n, h, w, device=dev, dtype=torch.float32) if keep_y else None
@@ -456,6 +468,9 @@ def conv3d_wf(segs, w_packed, cout, emit=None, keep_y=True, fallback=None, group
     d = make_conv_desc(segs, w_packed, cout, 3, y, y2=y2, groups=groups, **kw)
     if not lib.tmdiff_conv3d_wf_supported(C.byref(d)):
         raise ValueError("conv3d_wf: shape not supported")
+    nsk = lib.tmdiff_conv3d_wf_splitk_workspace_bytes(C.byref(d)) if _WF_SPLITK else 0
+    if nsk:
+        d.splitk_ws, d.splitk_ws_bytes = _workspace(dev, nsk, "splitk").data_ptr(), nsk
     nws = lib.tmdiff_conv3d_wf_workspace_bytes(C.byref(d))
     ws = None
     if nws:
