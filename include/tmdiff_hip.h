@@ -182,6 +182,18 @@ size_t tmdiff_conv3d_wino_packed_bytes(int32_t Cout, int32_t Cin, int32_t groups
  * interleaved 64-channel tiles of tmdiff_conv3d_wino_fwd */
 int tmdiff_conv3d_wino_pack_weights(const float* w, float* packed, int32_t Cout, int32_t Cin, int32_t groups,
                                     int32_t mode, int32_t planes, tmdiff_stream_t stream);
+/* Multi-tensor form, ONE launch for every (weight, mode) of a network (the finetune step re-packs the Winograd weights of its
+ * ~50 convolutions in both forms after every optimizer step).  `entries_dev` is a DEVICE array; workgroup k packs elements
+ * [chunk_index_dev[k] * tmdiff_conv3d_wino_pack_weights_multi_chunk(), ...) of entry chunk_tensor_dev[k].  Cout / Cin / groups are
+ * those of the weight tensor w = [Cout, Cin/groups, 3,3,3]; mode / planes as tmdiff_conv3d_wino_pack_weights. */
+typedef struct tmdiff_wino_pack_entry {
+  const float* w;
+  float* packed;
+  int32_t Cout, Cin, groups, mode, planes, reserved;
+} tmdiff_wino_pack_entry;
+int32_t tmdiff_conv3d_wino_pack_weights_multi_chunk(void);
+int tmdiff_conv3d_wino_pack_weights_multi(const tmdiff_wino_pack_entry* entries_dev, const int32_t* chunk_tensor_dev,
+                                          const int32_t* chunk_index_dev, int32_t n_chunks, tmdiff_stream_t stream);
 int tmdiff_conv3d_wino_fwd(const tmdiff_conv3d_desc* d, void* workspace, tmdiff_stream_t stream);
 /* stage 1: the input-transform pass alone; stage 2: the convolution alone on a workspace that holds it; 0: both */
 int tmdiff_conv3d_wino_fwd_stage(const tmdiff_conv3d_desc* d, void* workspace, int32_t stage, tmdiff_stream_t stream);

@@ -870,3 +870,26 @@ def test_multi_tensor_weight_packing_equals_single(ops):
     assert pk.lookup(ws[2][0]) is None and pk.lookup(ws[1][0]) is not None
     pk.refresh()
     assert torch.equal(pk.lookup(ws[2][0])[0], ops.pack_conv_weight(ws[2][0], groups=1, mode=0))
+
+
+def test_multi_tensor_winograd_weight_packing_equals_single(ops):
+    """tmdiff_conv3d_wino_pack_weights_multi (every weight, forward + data-gradient form, one launch: the finetune step's
+    re-pack) against the single-tensor packing, bit for bit; and its refresh / lookup bookkeeping."""
+    torch.manual_seed(3)
+    ws = [(torch.randn(64, 32, 3, 3, 3, device="cuda"), 1), (torch.randn(32, 32, 3, 3, 3, device="cuda"), 1),
+          (torch.randn(96, 32, 3, 3, 3, device="cuda"), 3), (torch.randn(128, 64, 3, 3, 3, device="cuda"), 1)]
+    pk = ops.WinoPackedWeights()
+    first = {(i, mode): pk.get(w, g, mode).clone() for i, (w, g) in enumerate(ws) for mode in (2, 3)}    # packed singly, registered
+    for i, (w, g) in enumerate(ws):
+        for mode in (2, 3):
+            assert torch.equal(first[(i, mode)], ops.pack_conv_weight_wino(w, groups=g, mode=mode, planes=6))
+    for w, _ in ws:
+        w.mul_(1.5)                                     # (an optimizer step: every version changes)
+    pk.refresh()                                        # ONE launch re-packs all eight
+    for i, (w, g) in enumerate(ws):
+        for mode in (2, 3):
+            got = pk.get(w, g, mode)
+            assert torch.equal(got, ops.pack_conv_weight_wino(w, groups=g, mode=mode, planes=6)), (tuple(w.shape), g, mode)
+            assert not torch.equal(got, first[(i, mode)])
+    ws[1][0].mul_(2.0)                                  # changed after the refresh: re-packed on demand
+    assert torch.equal(pk.get(ws[1][0], 1, 3), ops.pack_conv_weight_wino(ws[1][0], groups=1, mode=3, planes=6))

@@ -34,6 +34,7 @@ _EPILOGUE_FUSE = os.environ.get("TMDIFF_EPILOGUE_FUSE", "1") != "0"   # experime
 _CONV2_AFTER_LL = os.environ.get("TMDIFF_CONV2_AFTER_LL", "1") != "0"   # experiments: "0" = Conv_2 of a down block at full resolution, as the reference orders it
 _WINOGRAD = os.environ.get("TMDIFF_WINOGRAD", "1") != "0"     # experiments: "0" = every 3x3x3 convolution on the direct kernels
 _LL_COMPOSE = os.environ.get("TMDIFF_LL_COMPOSE", "1") != "0"   # experiments: "0" = Conv_0 at full resolution + LL-only DWT where the high bands are dropped
+_WINO_MULTIPACK = os.environ.get("TMDIFF_WINO_MULTIPACK", "1") != "0"   # experiments: "0" = the Winograd weights of a finetune step packed one launch per (weight, form)
 _PRODUCER_FUSE = os.environ.get("TMDIFF_PRODUCER_FUSE", "1") != "0"   # experiments: "0" = only the conv20 -> conv21 exchange
 
 
@@ -614,6 +615,7 @@ class WavBEST(nn.Module):
         self._prep = None
         self._cond = None
         self.__dict__.pop("_train_pack", None)       # the training path's packed weights (ops.PackedWeights)
+        self.__dict__.pop("_train_pack_wino", None)
 
     # ---- forward ------------------------------------------------------------------------------------
     def forward(self, x_t, t_input, PAN=None, MS=None, prompt=None):
@@ -687,6 +689,11 @@ class WavBEST(nn.Module):
                 [(m.weight, m.groups) for m in self.modules()
                  if isinstance(m, nn.Conv3d) and m.in_channels > 1 and m.out_channels > 1])
         ops.PACKED = pk.refresh()
+        # ... and the Winograd (conv3d_wf) forms of the 3x3x3 weights, forward and data gradient, in one more
+        wk = self.__dict__.get("_train_pack_wino")
+        if wk is None:
+            wk = self.__dict__["_train_pack_wino"] = ops.WinoPackedWeights()
+        ops.WINO_PACKED = wk.refresh() if _WINO_MULTIPACK else None
         lin = lambda seq, i, x, act: A.linear(x, seq[i].weight, seq[i].bias, act=act)
         pe = self._prompt_rows(prompt, b, dev)
         pemb = lin(self.embed2, 4, lin(self.embed2, 2, lin(self.embed2, 0, pe, True), True), True)

@@ -51,6 +51,8 @@ SIGNATURES = {
     "tmdiff_conv3d_wino_planes": (C.c_int32, [C.c_int32]),
     "tmdiff_conv3d_wino_packed_bytes": (C.c_size_t, [C.c_int32, C.c_int32, C.c_int32, C.c_int32]),
     "tmdiff_conv3d_wino_pack_weights": (C.c_int, [vp, vp, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32, vp]),
+    "tmdiff_conv3d_wino_pack_weights_multi_chunk": (C.c_int32, []),
+    "tmdiff_conv3d_wino_pack_weights_multi": (C.c_int, [vp, vp, vp, C.c_int32, vp]),
     "tmdiff_conv3d_wf_supported": (C.c_int, [C.POINTER(Conv3dDesc)]),
     "tmdiff_conv3d_wf_blocks": (C.c_int64, [C.POINTER(Conv3dDesc)]),
     "tmdiff_conv3d_wf_workspace_bytes": (C.c_size_t, [C.POINTER(Conv3dDesc)]),

@@ -30,6 +30,14 @@ class DropSpec(tuple):
         return super().__new__(cls, (int(seed), float(p)))
 
 
+def _wf_weights(w, groups, mode):
+    """conv3d_wf's packing of w (mode 2: forward, 3: data gradient): from the network's one-launch multi-tensor packing
+    (WavBEST.forward_train refreshes it once per step; a pair it has not seen yet is packed on the spot and joins it)."""
+    if ops.WINO_PACKED is not None:
+        return ops.WINO_PACKED.get(w, groups, mode)
+    return ops.pack_conv_weight_wino(w, groups, mode=mode, planes=6)
+
+
 class _FusedConv3d(torch.autograd.Function):
     """y = (conv3d(act(cat(segs) + shift) * scale * mask, w) + bias_scale*bias + residual) * out_scale"""
 
@@ -66,8 +74,7 @@ class _FusedConv3d(torch.autograd.Function):
                                            w_packed_fn=lambda planes: ops.pack_conv_weight_wino(w, groups, planes=planes), **kw)
             # 8- / 4-band tensors: the kernel that transforms its input in LDS (its prologue pass writes x' where the weight
             # gradient will read it); other even band counts: transform pass + kernel
-            y = ops.conv3d_wf(segs, None, cout, fallback=wino,
-                              w_packed_fn=lambda: ops.pack_conv_weight_wino(w, groups, mode=2, planes=6), **kw)
+            y = ops.conv3d_wf(segs, None, cout, fallback=wino, w_packed_fn=lambda: _wf_weights(w, groups, 2), **kw)
         else:
             y = direct()
         ctx.meta = meta
@@ -123,7 +130,7 @@ class _FusedConv3d(torch.autograd.Function):
                 wino = lambda: ops.conv3d_wino([g], None, cin, groups=groups, fallback=direct,
                                                w_packed_fn=lambda planes: ops.pack_conv_weight_wino(w, groups, mode=1, planes=planes))
                 gp = ops.conv3d_wf([g], None, cin, groups=groups, fallback=wino,      # (a plain input: no pass at all)
-                                   w_packed_fn=lambda: ops.pack_conv_weight_wino(w, groups, mode=3, planes=6))
+                                   w_packed_fn=lambda: _wf_weights(w, groups, 3))
             else:
                 gp = direct()                                                    # dL/dx'
             outs = [torch.empty_like(s) if need[7 + i] else None for i, s in enumerate(segs)]
@@ -180,7 +187,7 @@ class _ConvLL(torch.autograd.Function):
             # dL/dx': a 3x3x3 convolution of the up-sampled gradient -- Winograd along the bands (13.5 multiply-adds per
             # element; the transposed form of the composed strided convolution would take 12)
             gp = ops.conv3d_wf([g], None, cin, fallback=lambda: ops.conv3d([g], wp_t, cin, 3),
-                               w_packed_fn=lambda: ops.pack_conv_weight_wino(w, 1, mode=3, planes=6)) if _WINOGRAD else \
+                               w_packed_fn=lambda: _wf_weights(w, 1, 3)) if _WINOGRAD else \
                 ops.conv3d([g], wp_t, cin, 3)
             d_x = torch.empty_like(x)
             ops.conv3d_prologue_bwd(ops.make_conv_desc([x], 0, cout, 3, g, in_act=True), gp, [d_x], [False], False, False)

@@ -499,37 +499,58 @@ int launch(WinoArgs& a, hipStream_t st) {
 }
 
 // packed[g][ci][tap9][k][col(co)] = (G g)[k] of w[g * cout_g + co][ci][.][dh][dw]   (ci, co inside the group)
-// (column order inside a 64-channel tile as tmdiff_conv3d_pack_weights: channel c at (c % 32) * 2 + c / 32)
+// (column order inside a 64-channel tile as tmdiff_conv3d_pack_weights: channel c at (c % 32) * 2 + c / 32; mode | 2: natural
+// column order, for the 32-channel tiles of conv3d_wf.hip; mode | 1: the data-gradient form -- this convolution's (co, ci) are
+// the forward one's (ci, co), every tap mirrored)
+template <int NP>
+__device__ __forceinline__ float wino_pack_one(const float* __restrict__ w, long i, int cout_g, int cin_g, int mode) {
+#pragma clang fp contract(off)     // (the single- and the multi-tensor kernel must give the same bits: no per-site FMA fusion)
+  using M = WM<NP>;
+  const int col = (int)(i % cout_g);
+  long r = i / cout_g;
+  const int k = (int)(r % NP); r /= NP;
+  const int tap9 = (int)(r % 9); r /= 9;
+  const int ci = (int)(r % cin_g);
+  const int g = (int)(r / cin_g);
+  int co = col;
+  if (cout_g % 64 == 0 && !(mode & 2)) {
+    const int tile = col / 64, j = col % 64;
+    co = tile * 64 + (j % 2) * 32 + j / 2;
+  }
+  float g3[3];
+  if ((mode & 1) == 0) {
+    const float* wk = w + (((long)g * cout_g + co) * cin_g + ci) * 27 + tap9;
+    g3[0] = wk[0], g3[1] = wk[9], g3[2] = wk[18];
+  } else {
+    const float* wk = w + (((long)g * cin_g + ci) * cout_g + co) * 27 + (8 - tap9);
+    g3[0] = wk[18], g3[1] = wk[9], g3[2] = wk[0];
+  }
+  float u = 0.f;
+#pragma unroll
+  for (int kk = 0; kk < NP; ++kk)
+    if (kk == k) u = M::G[kk][0] * g3[0] + M::G[kk][1] * g3[1] + M::G[kk][2] * g3[2];
+  return u;
+}
+
 template <int NP>
 __global__ void __launch_bounds__(256) wino_pack_weights_kernel(const float* __restrict__ w, float* __restrict__ packed, int cout_g,
                                                                 int cin_g, int mode, long total) {
-  using M = WM<NP>;
-  for (long i = blockIdx.x * 256L + threadIdx.x; i < total; i += 256L * gridDim.x) {
-    const int col = (int)(i % cout_g);
-    long r = i / cout_g;
-    const int k = (int)(r % NP); r /= NP;
-    const int tap9 = (int)(r % 9); r /= 9;
-    const int ci = (int)(r % cin_g);
-    const int g = (int)(r / cin_g);
-    int co = col;
-    if (cout_g % 64 == 0 && !(mode & 2)) {   // (mode | 2: natural column order, for the 32-channel tiles of conv3d_wf.hip)
-      const int tile = col / 64, j = col % 64;
-      co = tile * 64 + (j % 2) * 32 + j / 2;
-    }
-    float g3[3];
-    if ((mode & 1) == 0) {
-      const float* wk = w + (((long)g * cout_g + co) * cin_g + ci) * 27 + tap9;   // [dn][dh][dw]: dn stride 9
-      g3[0] = wk[0], g3[1] = wk[9], g3[2] = wk[18];
-    } else {   // data-gradient form: this convolution's (co, ci) are the forward one's (ci, co), every tap mirrored
-      const float* wk = w + (((long)g * cin_g + ci) * cout_g + co) * 27 + (8 - tap9);
-      g3[0] = wk[18], g3[1] = wk[9], g3[2] = wk[0];
-    }
-    float u = 0.f;
-#pragma unroll
-    for (int kk = 0; kk < NP; ++kk)
-      if (kk == k) u = M::G[kk][0] * g3[0] + M::G[kk][1] * g3[1] + M::G[kk][2] * g3[2];
-    packed[i] = u;
-  }
+  for (long i = blockIdx.x * 256L + threadIdx.x; i < total; i += 256L * gridDim.x) packed[i] = wino_pack_one<NP>(w, i, cout_g, cin_g, mode);
+}
+
+// Multi-tensor form: every (weight, mode) of a network in ONE launch.  Workgroup k packs elements
+// [chunk_index[k] * WINO_MT_CHUNK, + WINO_MT_CHUNK) of entry chunk_tensor[k] (the element order of wino_pack_weights_kernel).
+constexpr int WINO_MT_CHUNK = 4096;
+__global__ void __launch_bounds__(256) wino_pack_weights_multi_kernel(const tmdiff_wino_pack_entry* __restrict__ entries,
+                                                                      const int32_t* __restrict__ chunk_tensor,
+                                                                      const int32_t* __restrict__ chunk_index) {
+  const tmdiff_wino_pack_entry e = entries[chunk_tensor[blockIdx.x]];
+  // Cout / Cin of THIS convolution (for the data-gradient form the forward weight's dimensions swapped)
+  const int cout_g = ((e.mode & 1) ? e.Cin : e.Cout) / e.groups, cin_g = ((e.mode & 1) ? e.Cout : e.Cin) / e.groups;
+  const long total = (long)cin_g * 9 * e.planes * cout_g * e.groups;
+  const long lo = (long)chunk_index[blockIdx.x] * WINO_MT_CHUNK;
+  for (long i = lo + threadIdx.x; i < lo + WINO_MT_CHUNK && i < total; i += 256)
+    e.packed[i] = e.planes == 6 ? wino_pack_one<6>(e.w, i, cout_g, cin_g, e.mode) : wino_pack_one<4>(e.w, i, cout_g, cin_g, e.mode);
 }
 
 bool wino_ok(const tmdiff_conv3d_desc* d) {
@@ -596,6 +617,17 @@ extern "C" int tmdiff_conv3d_wino_pack_weights(const float* w, float* packed, in
   else
     wino_pack_weights_kernel<4><<<(int)blocks, 256, 0, as_stream(stream)>>>(w, packed, Cout / groups, Cin / groups, mode, total);
   return check_launch("conv3d_wino_pack_weights");
+}
+
+extern "C" int32_t tmdiff_conv3d_wino_pack_weights_multi_chunk(void) { return WINO_MT_CHUNK; }
+
+extern "C" int tmdiff_conv3d_wino_pack_weights_multi(const tmdiff_wino_pack_entry* entries_dev, const int32_t* chunk_tensor_dev,
+                                                     const int32_t* chunk_index_dev, int32_t n_chunks, tmdiff_stream_t stream) {
+  using namespace tmdiff;
+  TMDIFF_REQUIRE(entries_dev && chunk_tensor_dev && chunk_index_dev && n_chunks >= 0, "conv3d_wino_pack_weights_multi: bad arguments");
+  if (n_chunks == 0) return TMDIFF_OK;
+  wino_pack_weights_multi_kernel<<<(unsigned)n_chunks, 256, 0, as_stream(stream)>>>(entries_dev, chunk_tensor_dev, chunk_index_dev);
+  return check_launch("conv3d_wino_pack_weights_multi");
 }
 
 // stage: 0 = input transform + convolution, 1 = the transform pass alone (fills the workspace), 2 = the convolution alone

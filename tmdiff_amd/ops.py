@@ -97,7 +97,69 @@ class PackedWeights:
         return self.fwd[k], self.dgrad[k]
 
 
+class WinoPackedWeights:
+    """The Winograd (conv3d_wf) packings -- forward (mode 2) / data-gradient (mode 3) form, F(4,3), natural column order -- of the
+    3x3x3 weights a finetune step ACTUALLY runs through that kernel, refreshed by ONE launch per step
+    (tmdiff_conv3d_wino_pack_weights_multi).  Which (weight, form) pairs those are depends on the tensor sizes (the 8x8 level
+    and small grids take other kernels, and the deep levels hold most of the parameters), so the set is learnt: ``get``
+    packs a pair it does not hold by itself and registers it; ``refresh`` (once per step, before the forward) re-packs the
+    registered pairs whose weight changed."""
+
+    def __init__(self):
+        self.items = {}               # (data_ptr, mode) -> [weight, groups, packed tensor, packed version]
+        self._dirty = False
+        self.n_chunks = 0
+
+    def _build_tables(self):
+        import struct
+        chunk = lib.tmdiff_conv3d_wino_pack_weights_multi_chunk()
+        ent, ct, ci = bytearray(), [], []
+        for n, ((_, mode), (w, g, out, _)) in enumerate(self.items.items()):
+            ent += struct.pack("<QQiiiiii", w.data_ptr(), out.data_ptr(), w.shape[0], w.shape[1] * g, g, mode, 6, 0)
+            nck = (out.numel() + chunk - 1) // chunk
+            ct += [n] * nck
+            ci += list(range(nck))
+        dev = next(iter(self.items.values()))[0].device
+        self.entries = torch.frombuffer(bytearray(ent), dtype=torch.uint8).clone().to(dev)
+        self.chunk_tensor = torch.tensor(ct, dtype=torch.int32).to(dev)
+        self.chunk_index = torch.tensor(ci, dtype=torch.int32).to(dev)
+        self.n_chunks = len(ct)
+        self._dirty = False
+
+    def refresh(self):
+        if not self.items:
+            return self
+        if self._dirty:
+            self._build_tables()
+        if any(it[3] != it[0]._version for it in self.items.values()):
+            check(lib.tmdiff_conv3d_wino_pack_weights_multi(self.entries.data_ptr(), self.chunk_tensor.data_ptr(),
+                                                            self.chunk_index.data_ptr(), self.n_chunks, stream_ptr()),
+                  "conv3d_wino_pack_weights_multi")
+            for it in self.items.values():
+                it[3] = it[0]._version
+        return self
+
+    def get(self, w, groups, mode):
+        it = self.items.get((w.data_ptr(), mode))
+        if it is not None and it[0] is w and it[3] == w._version:
+            return it[2]
+        if it is not None and it[0] is w:       # registered, but the weight changed since the last refresh
+            out = it[2]
+        else:
+            _chk(w.detach(), "weight")
+            out = torch.empty(w.numel() * 2, device=w.device, dtype=torch.float32)   # six planes for three taps
+            self._dirty = True
+        cout, cin = w.shape[0], w.shape[1] * groups
+        if mode & 1:
+            cout, cin = cin, cout
+        check(lib.tmdiff_conv3d_wino_pack_weights(w.detach().data_ptr(), out.data_ptr(), cout, cin, groups, mode, 6, stream_ptr()),
+              "conv3d_wino_pack_weights")
+        self.items[(w.data_ptr(), mode)] = [w, groups, out, w._version]
+        return out
+
+
 PACKED = None      # the PackedWeights of the network being trained (set by WavBEST.forward_train; autograd.py consults it)
+WINO_PACKED = None # ... and its WinoPackedWeights
 
 
 def bf16_conv_supported(cout, cin, ksize, groups=1, seg_channels=None):
