@@ -669,6 +669,11 @@ def test_conv3d_winograd_along_bands(ops, case):
     (1, (64,), 64, 8, 16, 16, 1),         # 4 tiles: split over the input channels (16 ranges of 2 chunks) + reduction kernel
     (2, (48,), 32, 4, 16, 32, 1),         # N = 4, split-K (12 ranges)
     (1, (8, 8, 8), 96, 8, 8, 16, 3),      # groups = 3 with split-K (2 ranges of 2 chunks)
+    (4, (8,), 64, 8, 8, 8, 1),            # 8-column planes: two images side by side in one tile (pair mode)
+    (3, (6,), 32, 8, 12, 8, 1),           # pair mode, odd batch (the last tile holds one image), ragged in h
+    (1, (4,), 32, 8, 8, 8, 1),            # pair mode, a single image
+    (3, (8, 8, 8), 192, 8, 8, 8, 3),      # pair mode, groups = 3 on three segments (read in place), split-K
+    (5, (64,), 64, 8, 16, 8, 1),          # pair mode, split-K, odd batch
 ])
 def test_conv3d_winograd_in_kernel_transform(ops, case):
     """tmdiff_conv3d_wf_fwd: Winograd F(4,3) along the bands with the input transform inside the kernel (no transformed

@@ -115,18 +115,24 @@ __device__ __forceinline__ void stagger_start(int cycles, unsigned first_round) 
   while ((long long)(__builtin_amdgcn_s_memtime() - t0) < (long long)cycles) __builtin_amdgcn_s_sleep(32);
 }
 
-template <int TT, int TH, int TW>
+// PAIR (planes of exactly 8 columns -- the 8x8 level): the tile's 16 columns are TWO IMAGES side by side, 8 columns each.  The
+// raw box then needs no halo columns at all (left and right of an 8-column image is the zero padding of the convolution), a V
+// row holds [0, image 0, 0, 0, image 1, 0] (20 columns: each image its own zero halo, written once and never touched again),
+// and a lane of the second image reads its operands 2 columns further right.  An 8x16 tile over one 8-column plane would be
+// half empty.
+template <int TT, int TH, int TW, bool PAIR = false>
 struct GeoF {
   static constexpr int NP = 6, MO = 4, NB = TT * MO, KC = 2, CO = 32, NS = 2;
   static constexpr int HH = TH + 2;
-  static constexpr int RW = TW + 8, RQ = RW / 4;          // raw row: columns w0-4 .. w0+TW+3 as RQ aligned quads
-  static constexpr int PW = TW + 2;                       // V row: columns w0-1 .. w0+TW
+  static constexpr int RW = PAIR ? TW : TW + 8, RQ = RW / 4;   // raw row: columns w0-4 .. w0+TW+3 as RQ aligned quads (PAIR: 2 x 8 columns)
+  static constexpr int PW = PAIR ? TW + 4 : TW + 2;            // V row: columns w0-1 .. w0+TW (PAIR: two images with their own halo columns)
   static constexpr int REG_QUADS = NB * RQ;               // one region = (kc, row): every band's raw row
-  static constexpr int RPP = 48 / REG_QUADS;              // regions per 48-lane DMA piece
+  static constexpr int PLANES = PAIR ? 32 : 48;           // lanes of a DMA piece
+  static constexpr int RPP = PLANES / REG_QUADS;          // regions per piece
   static constexpr int NREG = KC * HH;
   static constexpr int XP = (NREG + RPP - 1) / RPP;       // raw pieces per chunk
   static constexpr int XK = (XP + 3) / 4;                 // ... per wave
-  static constexpr int PSTRIDE = 196;                     // floats between pieces (192 + 4: consecutive pieces of a wave 16 banks apart)
+  static constexpr int PSTRIDE = PLANES * 4 + 4;          // floats between pieces (+ 4: consecutive pieces of a wave 16 banks apart)
   static constexpr int RAW_FLOATS = XP * PSTRIDE;
   // one band tile's planes; with two tiles the stride is padded to 16 mod 32 banks: a sub-tile of MFMA columns is then 16
   // positions of one row in BOTH band tiles, and its operand read touches every bank once (two rows of one tile, 18 floats
@@ -141,10 +147,12 @@ struct GeoF {
   static constexpr int W_UNITS = W_FLOATS / 4;
   static constexpr int WP = (W_UNITS + 63) / 64, WK = (WP + 3) / 4;
   static constexpr int STAGE = V_FLOATS + WP * 256;
-  static_assert(REG_QUADS * RPP == 48, "a piece is 48 lanes of whole regions");
-  static_assert(RPP * TT == 2, "a piece holds two (region, band tile) pairs: 36 transform tasks");
+  static constexpr int TCOLS = PAIR ? TW : PW;            // V columns the transform writes per (region, band tile)
+  static_assert(REG_QUADS * RPP == PLANES, "a piece holds whole regions");
+  static_assert(RPP * TT == 2, "a piece holds two (region, band tile) pairs");
   static_assert(TT * TH * TW == 4 * NS * 32, "4 waves x NS sub-tiles x 32 positions");
   static_assert(TW == 16, "a sub-tile is two rows of 16 positions");
+  static_assert(!PAIR || (TT == 2 && TH == 8), "pair mode: two band tiles of 8 rows");
   static_assert(V_FLOATS % 4 == 0, "stage alignment");
 };
 
@@ -155,10 +163,12 @@ struct GeoF {
 // difference: the residual quads are requested THREE blocks ahead (the output transform has already freed a third of the
 // accumulators, so there are registers for it).  With one block of look-ahead a wave waited out most of an HBM round trip
 // per block, eight times per tile: 22 of the 33 us of a tile's epilogue at 32 input channels (tools/wino_stamps.py).
-template <bool Y, bool RES, bool Y2, bool FULL, int TT, int TH, int TW>
+// (PAIR: the lane's four positions belong to image b or b + 1 -- pimg_ok says whether the second exists -- and the second
+// output's per-(b, channel) shift / scale come in both versions, sh2_l / sc2_l for b and sh2_m / sc2_m for b + 1)
+template <bool Y, bool RES, bool Y2, bool FULL, int TT, int TH, int TW, bool PAIR>
 __device__ __forceinline__ void epilogue_wf(const WfArgs& a, f32x16 (&out)[8], float bias_l, float sh2_l, float sc2_l, int b, int g,
                                             int co0, int h0, int w0, int wv, int lane, long plane, float* T, float* ydst,
-                                            float oscale) {
+                                            float oscale, float sh2_m = 0.f, float sc2_m = 1.f, bool pimg_ok = true) {
   constexpr int MO = 4, DEPTH = 3;
   const int l31 = lane & 31, khalf = lane >> 5, tq = lane & 7, tc = lane >> 3;
   const int hw = a.H * a.W;
@@ -169,15 +179,29 @@ __device__ __forceinline__ void epilogue_wf(const WfArgs& a, f32x16 (&out)[8], f
   for (int s = 0; s < 2; ++s) {
     // the lane's four positions 4 tq .. 4 tq + 3 of sub-tile s (see the operand offsets of the kernel): band tile, row, column
     const int bt = TT == 2 ? tq >> 2 : 0;
-    const int h = h0 + (TT == 2 ? 2 * wv + s : 4 * wv + 2 * s + (tq >> 2)), w = w0 + 4 * (tq & 3);
-    tok[s] = FULL || (h < a.H && w < a.W);                      // (W % 4 == 0: the four positions stand or fall together)
-    toff[s] = tok[s] ? (MO * bt) * hw + h * a.W + w : 0;
+    const int h = h0 + (TT == 2 ? 2 * wv + s : 4 * wv + 2 * s + (tq >> 2));
+    if constexpr (PAIR) {      // columns 0-7 of the tile: image b, 8-15: image b + 1 (a whole sample further on)
+      const int img = (tq & 3) >> 1, w = 4 * (tq & 1);
+      tok[s] = h < a.H && (img == 0 || pimg_ok);
+      toff[s] = tok[s] ? img * a.Cout * (int)plane + (MO * bt) * hw + h * a.W + w : 0;
+    } else {
+      const int w = w0 + 4 * (tq & 3);
+      tok[s] = FULL || (h < a.H && w < a.W);                    // (W % 4 == 0: the four positions stand or fall together)
+      toff[s] = tok[s] ? (MO * bt) * hw + h * a.W + w : 0;
+    }
   }
   float bias_t[4], sh2_t[4], sc2_t[4];
+  const bool second = PAIR && ((tq & 3) >> 1);
 #pragma unroll
   for (int j = 0; j < 4; ++j) {
     bias_t[j] = tmdiff::lane_value(bias_l, tc + 8 * j);
-    if constexpr (Y2) sh2_t[j] = tmdiff::lane_value(sh2_l, tc + 8 * j), sc2_t[j] = tmdiff::lane_value(sc2_l, tc + 8 * j);
+    if constexpr (Y2) {
+      sh2_t[j] = tmdiff::lane_value(sh2_l, tc + 8 * j), sc2_t[j] = tmdiff::lane_value(sc2_l, tc + 8 * j);
+      if constexpr (PAIR) {
+        const float s1 = tmdiff::lane_value(sh2_m, tc + 8 * j), c1 = tmdiff::lane_value(sc2_m, tc + 8 * j);
+        sh2_t[j] = second ? s1 : sh2_t[j], sc2_t[j] = second ? c1 : sc2_t[j];
+      }
+    }
   }
   float4 rs[DEPTH + 1][4];          // block i in slot i % (DEPTH + 1)
   auto load_res = [&](auto ic) __attribute__((always_inline)) {
@@ -223,9 +247,9 @@ __device__ __forceinline__ void epilogue_wf(const WfArgs& a, f32x16 (&out)[8], f
   });
 }
 
-template <int TT, int TH, int TW>
+template <int TT, int TH, int TW, bool PAIR>
 __global__ void __launch_bounds__(256, 2) conv3d_wf_kernel(const WfArgs a) {
-  using G = GeoF<TT, TH, TW>;
+  using G = GeoF<TT, TH, TW, PAIR>;
   constexpr int NP = G::NP, MO = G::MO, NB = G::NB, KC = G::KC, CO = G::CO, NS = G::NS, HH = G::HH, RQ = G::RQ, PW = G::PW;
   constexpr int W_TAPS = G::W_TAPS;
   __shared__ __attribute__((aligned(16))) float lds[2 * G::STAGE + G::RAW_FLOATS];
@@ -254,7 +278,8 @@ __global__ void __launch_bounds__(256, 2) conv3d_wf_kernel(const WfArgs a) {
   const int tw_i = __builtin_amdgcn_readfirstlane(id % a.tiles_w); id /= a.tiles_w;
   const int th_i = __builtin_amdgcn_readfirstlane(id % a.tiles_h); id /= a.tiles_h;
   const int g = __builtin_amdgcn_readfirstlane(id % a.groups);
-  const int b = __builtin_amdgcn_readfirstlane(id / a.groups);
+  const int b = __builtin_amdgcn_readfirstlane(id / a.groups) * (PAIR ? 2 : 1);     // (PAIR: images b and b + 1)
+  const bool pimg_ok = !PAIR || b + 1 < a.B;
   const int h0 = th_i * TH, w0 = tw_i * TW;
   const int co0 = co_tile * CO;
   const int hw = a.H * a.W;
@@ -266,10 +291,18 @@ __global__ void __launch_bounds__(256, 2) conv3d_wf_kernel(const WfArgs a) {
 
   // ---- DMA: raw pieces (48 lanes: RPP regions of NB bands x RQ quads) and weight pieces ------------------------------
   // descriptors per chunk: the chunk's KC channels of x' (everything outside reads as zero) / its KC * 54 weight rows
-  const unsigned xbytes = (unsigned)(KC * plane * 4), wbytes = (unsigned)(KC * W_TAPS * a.cout_g * 4);
-  const int xq = lane % G::REG_QUADS, xsub = lane / G::REG_QUADS;          // (lanes >= 48 issue nothing)
-  const int xwq = w0 - 4 + 4 * (xq % RQ);
-  const unsigned xlane_off = (lane < 48 && xwq >= 0 && xwq < a.W) ? (unsigned)(((xq / RQ) * hw + xwq) * 4) : kOutside;
+  // (PAIR: the descriptor also spans the same channels of image b + 1, one sample stride further on)
+  const long xbs = PAIR && pimg_ok ? (long)(a.grouped_segs ? a.cin_g : a.Cin) * plane : 0;
+  const unsigned xbytes = (unsigned)((xbs + KC * plane) * 4), wbytes = (unsigned)(KC * W_TAPS * a.cout_g * 4);
+  const int xq = lane % G::REG_QUADS, xsub = lane / G::REG_QUADS;          // (lanes >= PLANES issue nothing)
+  unsigned xlane_off;
+  if constexpr (PAIR) {     // quad (image, half row): no halo columns, they are the padding
+    const int img = (xq % RQ) >> 1;
+    xlane_off = (lane < G::PLANES && (img == 0 || pimg_ok)) ? (unsigned)((img * xbs + (xq / RQ) * hw + 4 * (xq & 1)) * 4) : kOutside;
+  } else {
+    const int xwq = w0 - 4 + 4 * (xq % RQ);
+    xlane_off = (lane < G::PLANES && xwq >= 0 && xwq < a.W) ? (unsigned)(((xq / RQ) * hw + xwq) * 4) : kOutside;
+  }
   auto issue_raw = [&](auto kc_, int c) __attribute__((always_inline)) {
     constexpr int k = decltype(kc_)::value;
     const int p = wv + 4 * k;
@@ -281,7 +314,7 @@ __global__ void __launch_bounds__(256, 2) conv3d_wf_kernel(const WfArgs a) {
       const bool ok = h >= 0 && h < a.H && region < G::NREG;
       const unsigned lo = opaque(xlane_off);
       const unsigned voff = ok ? lo + (unsigned)((kc * (int)plane + h * a.W) * 4) : kOutside;
-      if (lane < 48) dma_b128(r, lo >= kOutside ? kOutside : voff, raw + p * G::PSTRIDE);
+      if (lane < G::PLANES) dma_b128(r, lo >= kOutside ? kOutside : voff, raw + p * G::PSTRIDE);
     }
   };
   const unsigned wlane_off = (unsigned)(((lane >> 3) * a.cout_g + (lane & 7) * 4) * 4);
@@ -300,7 +333,8 @@ __global__ void __launch_bounds__(256, 2) conv3d_wf_kernel(const WfArgs a) {
   // L, L + 64, L + 128, one per work item (6 ds_read_b32, 16 VALU operations, 6 ds_write_b32 with immediate offsets: nothing
   // conditional, nothing kept in registers between work items but two addresses per task -- every VALU instruction between
   // two MFMAs costs the matrix pipe its issue cycles).  Tasks beyond the last repeat an earlier one (same values, same place).
-  constexpr int TPP = G::RPP * TT * PW;                 // tasks per piece (36)
+  constexpr int TC = G::TCOLS;
+  constexpr int TPP = G::RPP * TT * TC;                 // tasks per piece (36; PAIR: 32, the halo columns stay zero)
   constexpr int NTASK = G::XK * TPP, NTR = (NTASK + 63) / 64;
   int trd[NTR], twr[NTR];
   bool tlo[NTR], thi[NTR];   // the tile has a band below / above inside the image (else that input band is zero padding)
@@ -309,14 +343,15 @@ __global__ void __launch_bounds__(256, 2) conv3d_wf_kernel(const WfArgs a) {
     int id = j * 64 + lane;
     if (id >= NTASK) id -= TPP;
     if (wv + 4 * (id / TPP) >= G::XP) id -= TPP;        // (a wave without a last piece)
-    const int tpi = id / TPP, rem = id % TPP, sub = rem / PW, col = rem % PW;
+    const int tpi = id / TPP, rem = id % TPP, sub = rem / TC, col = rem % TC;
     const int tp = wv + 4 * tpi;
     const int ttile = G::RPP == 1 ? sub : 0, trsub = G::RPP == 1 ? 0 : sub;
     const int tregion = tp * G::RPP + trsub;
     const int tkc = tregion / HH, trow = tregion - tkc * HH;
     // raw column of V column c is c + 3 (V columns w0-1 .. w0+TW are raw columns 3 .. TW+4); band i of the tile at + (i - 1) * RQ * 4
-    trd[j] = tp * G::PSTRIDE + trsub * (G::REG_QUADS * 4) + (MO * ttile) * (RQ * 4) + col + 3;
-    twr[j] = tkc * G::V_ELEMS + ttile * G::TSTRIDE + trow * PW + col;      // + k * HH * PW
+    // (PAIR: raw column = tile column, V column = 1 + column of image 0 / 11 + column of image 1)
+    trd[j] = tp * G::PSTRIDE + trsub * (G::REG_QUADS * 4) + (MO * ttile) * (RQ * 4) + col + (PAIR ? 0 : 3);
+    twr[j] = tkc * G::V_ELEMS + ttile * G::TSTRIDE + trow * PW + (PAIR ? col + 1 + 2 * (col >> 3) : col);      // + k * HH * PW
     tlo[j] = ttile > 0, thi[j] = ttile < TT - 1;
   }
   float tin[NP];
@@ -347,16 +382,29 @@ __global__ void __launch_bounds__(256, 2) conv3d_wf_kernel(const WfArgs a) {
   // column l31 = (band tile l31 >> 4, column l31 & 15).  N = 4: wave wv owns rows 4 wv .. 4 wv + 3, sub-tile s = two rows of 16.
   // Either way sub-tile 1 lies a constant behind sub-tile 0: one base address, one ds_read2_b32 for both.
   constexpr int SUB_STEP = G::SPLIT ? PW : 2 * PW;
-  const int boff = khalf * G::V_ELEMS + (G::SPLIT ? (l31 >> 4) * G::TSTRIDE + (2 * wv) * PW + (l31 & 15)
+  const int boff = khalf * G::V_ELEMS + (G::SPLIT ? (l31 >> 4) * G::TSTRIDE + (2 * wv) * PW + (l31 & 15) + (PAIR ? 2 * ((l31 & 15) >> 3) : 0)
                                                   : (4 * wv + (l31 >> 4)) * PW + (l31 & 15));
   const int aoff = G::V_FLOATS + khalf * W_TAPS * CO + l31;
 
-  float bias_l, sh2_l, sc2_l;
+  float bias_l, sh2_l, sc2_l, sh2_m = 0.f, sc2_m = 1.f;
   {
     const int col = g * a.cout_g + co0 + l31;
     bias_l = a.bias ? a.bias[col] * a.bias_scale : 0.f;
     sh2_l = (a.y2 && a.y2_shift) ? a.y2_shift[(long)b * a.y2_shift_stride + col] : 0.f;
     sc2_l = (a.y2 && a.y2_scale) ? a.y2_scale[(long)b * a.y2_scale_stride + col] : 1.f;
+    if constexpr (PAIR) {
+      const int b1 = pimg_ok ? b + 1 : b;
+      sh2_m = (a.y2 && a.y2_shift) ? a.y2_shift[(long)b1 * a.y2_shift_stride + col] : 0.f;
+      sc2_m = (a.y2 && a.y2_scale) ? a.y2_scale[(long)b1 * a.y2_scale_stride + col] : 1.f;
+    }
+  }
+  if constexpr (PAIR) {     // the four halo columns of every V row, both stages: zero, for good
+    constexpr int ROWS = G::V_FLOATS / PW;
+    static_assert(ROWS * PW == G::V_FLOATS, "the planes of a stage are one run of rows");
+    for (int i = tid; i < 2 * ROWS * 4; i += 256) {
+      const int stg = i / (ROWS * 4), r = (i >> 2) % ROWS, q = i & 3;
+      lds[stg * G::STAGE + r * PW + (q == 0 ? 0 : (q == 1 ? 9 : (q == 2 ? 10 : 19)))] = 0.f;
+    }
   }
 
   f32x16 acc[NP * NS];    // [k * NS + s]
@@ -452,16 +500,18 @@ __global__ void __launch_bounds__(256, 2) conv3d_wf_kernel(const WfArgs a) {
 #pragma unroll
   for (int i = 0; i < 8; ++i) out[i] = acc[(i % MO) * NS + i / MO];
   float* T = lds + wv * 1024;     // (every wave is past the last barrier: the stages are free)
-  const bool full = h0 + TH <= a.H && w0 + TW <= a.W;
+  const bool full = !PAIR && h0 + TH <= a.H && w0 + TW <= a.W;     // (PAIR: every store is checked -- the second image may not exist)
 #define WF_EPI2(Y, R, Y2)                                                                                                   \
   do {                                                                                                                      \
-    if (full) epilogue_wf<Y, R, Y2, true, TT, TH, TW>(a, out, bias_l, sh2_l, sc2_l, b, g, co0, h0, w0, wv, lane, plane, T, a.y, a.out_scale);  \
-    else epilogue_wf<Y, R, Y2, false, TT, TH, TW>(a, out, bias_l, sh2_l, sc2_l, b, g, co0, h0, w0, wv, lane, plane, T, a.y, a.out_scale);      \
+    if constexpr (!PAIR) {                                                                                                  \
+      if (full) { epilogue_wf<Y, R, Y2, true, TT, TH, TW, false>(a, out, bias_l, sh2_l, sc2_l, b, g, co0, h0, w0, wv, lane, plane, T, a.y, a.out_scale); break; }  \
+    }                                                                                                                       \
+    epilogue_wf<Y, R, Y2, false, TT, TH, TW, PAIR>(a, out, bias_l, sh2_l, sc2_l, b, g, co0, h0, w0, wv, lane, plane, T, a.y, a.out_scale, sh2_m, sc2_m, pimg_ok);  \
   } while (0)
   if (a.part) {     // split-K: this range's partial sums, bare (bias / residual / scale / second output: splitk_reduce_kernel)
     float* pd = a.part + (long)split * a.B * a.Cout * plane;
-    if (full) epilogue_wf<true, false, false, true, TT, TH, TW>(a, out, 0.f, 0.f, 1.f, b, g, co0, h0, w0, wv, lane, plane, T, pd, 1.f);
-    else epilogue_wf<true, false, false, false, TT, TH, TW>(a, out, 0.f, 0.f, 1.f, b, g, co0, h0, w0, wv, lane, plane, T, pd, 1.f);
+    if (full) epilogue_wf<true, false, false, !PAIR, TT, TH, TW, PAIR>(a, out, 0.f, 0.f, 1.f, b, g, co0, h0, w0, wv, lane, plane, T, pd, 1.f);
+    else epilogue_wf<true, false, false, false, TT, TH, TW, PAIR>(a, out, 0.f, 0.f, 1.f, b, g, co0, h0, w0, wv, lane, plane, T, pd, 1.f, 0.f, 1.f, pimg_ok);
   } else if (a.y) {
     if (a.residual) { if (a.y2) WF_EPI2(true, true, true); else WF_EPI2(true, true, false); }
     else            { if (a.y2) WF_EPI2(true, false, true); else WF_EPI2(true, false, false); }
@@ -483,12 +533,12 @@ __global__ void __launch_bounds__(256, 2) conv3d_wf_kernel(const WfArgs a) {
 #endif
 }
 
-template <int TT, int TH, int TW>
+template <int TT, int TH, int TW, bool PAIR = false>
 int launch(WfArgs& a, hipStream_t st) {
   a.tiles_h = (a.H + TH - 1) / TH;
-  a.tiles_w = (a.W + TW - 1) / TW;
+  a.tiles_w = PAIR ? 1 : (a.W + TW - 1) / TW;
   a.tiles_co = a.cout_g / 32;
-  const long blocks = (long)a.ksplit * a.B * a.groups * a.tiles_h * a.tiles_w * a.tiles_co;
+  const long blocks = (long)a.ksplit * (PAIR ? (a.B + 1) / 2 : a.B) * a.groups * a.tiles_h * a.tiles_w * a.tiles_co;
   if (blocks <= 0 || blocks > 0x7fffffffL) return tmdiff::fail(TMDIFF_E_INVALID, "conv3d_wf_fwd: grid of %ld blocks", blocks);
   a.total_blocks = (unsigned)blocks;
   static const double stagger_chunks = [] {
@@ -497,7 +547,7 @@ int launch(WfArgs& a, hipStream_t st) {
   }();
   a.first_round = 512;
   a.stagger = blocks > 512 ? (int)(stagger_chunks * 2.0 * 54 * 2 * 64) : 0;
-  conv3d_wf_kernel<TT, TH, TW><<<(unsigned)blocks, 256, 0, st>>>(a);
+  conv3d_wf_kernel<TT, TH, TW, PAIR><<<(unsigned)blocks, 256, 0, st>>>(a);
   return tmdiff::check_launch("conv3d_wf_fwd");
 }
 
@@ -515,9 +565,13 @@ bool wf_grouped_segs(const tmdiff_conv3d_desc* d) {
          d->seg_c[0] * 3 == d->Cin;
 }
 
+// 8 bands x 8 columns (the 8x8 level): two images share a tile, see GeoF
+bool wf_pair(const tmdiff_conv3d_desc* d) { return d->N == 8 && d->W == 8; }
+
 long wf_tiles(const tmdiff_conv3d_desc* d) {
   const int th = d->N == 8 ? 8 : 16;
-  return (long)d->B * d->groups * ((d->H + th - 1) / th) * ((d->W + 15) / 16) * (d->Cout / d->groups / 32);
+  const long units = wf_pair(d) ? (d->B + 1) / 2 : (long)d->B * ((d->W + 15) / 16);
+  return units * d->groups * ((d->H + th - 1) / th) * (d->Cout / d->groups / 32);
 }
 
 // split-K factor for grids that cannot fill the chip (two workgroups per CU are resident): the smallest divisor of the chunk
@@ -612,7 +666,9 @@ extern "C" int tmdiff_conv3d_wf_fwd(const tmdiff_conv3d_desc* d, void* workspace
       a.ksplit = ks; a.split_chunks = a.cin_g / 2 / ks; a.part = static_cast<float*>(d->splitk_ws);
     }
   }
-  const int rc = d->N == 8 ? launch<2, 8, 16>(a, st) : launch<1, 16, 16>(a, st);
+  if (wf_pair(d))
+    TMDIFF_REQUIRE(((long)d->Cin + 2) * d->N * d->H * d->W < (1L << 29), "conv3d_wf_fwd: sample too large for 32-bit offsets");
+  const int rc = wf_pair(d) ? launch<2, 8, 16, true>(a, st) : (d->N == 8 ? launch<2, 8, 16>(a, st) : launch<1, 16, 16>(a, st));
   if (rc || !a.part) return rc;
   SplitKReduceArgs r{a.part, a.ksplit, d->B, d->Cout, (long)d->N * d->H * d->W, d->bias, d->bias_scale, d->residual,
                      d->out_scale, d->y, d->y2, d->y2_shift, d->y2_scale, a.y2_shift_stride, a.y2_scale_stride, d->y2_act};

@@ -484,6 +484,7 @@ def conv3d_wino(segs, w_packed, cout, emit=None, keep_y=True, fallback=None, gro
 
 _WF = os.environ.get("TMDIFF_WF", "1") != "0"    # experiments: "0" = never the in-kernel-transform Winograd kernel (conv3d_wf)
 _WF_MIN_FILL = float(os.environ.get("TMDIFF_WF_MIN_FILL", "0.7"))
+_WF_PAIR = os.environ.get("TMDIFF_WF_PAIR", "1") != "0"          # experiments: "0" = 8-column planes go to the fallback kernels
 _WF_SPLITK = os.environ.get("TMDIFF_WF_SPLITK", "1") != "0"      # experiments: "0" = small grids go to the fallback kernels
 
 
@@ -500,7 +501,10 @@ def conv3d_wf(segs, w_packed, cout, emit=None, keep_y=True, fallback=None, group
     cg = cout // groups
     cin = sum(s_.shape[1] for s_ in segs)
     th = 8 if n == 8 else 16
-    tiles = b * groups * ((h + th - 1) // th) * ((w + 15) // 16) * (cg // 32) if cg % 32 == 0 else 0
+    # (8 bands x 8 columns: two images side by side in one 8 x 16 tile -- the kernel's pair mode)
+    pair = _WF_PAIR and n == 8 and w == 8
+    units = (b + 1) // 2 if pair else b * ((w + 15) // 16)
+    tiles = units * groups * ((h + th - 1) // th) * (cg // 32) if cg % 32 == 0 else 0
     # small grids split their input channels over workgroups (the smallest divisor of the chunk count that reaches 384
     # workgroups, at least two chunks per range: tmdiff_conv3d_wf_blocks) -- single images, the deep levels of a local batch
     nchunks = (cin // groups) // 2
@@ -513,8 +517,10 @@ def conv3d_wf(segs, w_packed, cout, emit=None, keep_y=True, fallback=None, group
                     break
     blocks = tiles * (split if _WF_SPLITK else 1)
     ok = _WF and n in (4, 8) and w % 4 == 0 and cg % 32 == 0 and (cin // groups) % 2 == 0 and kw.get("in_mask") is None
-    # (tiles of th x 16 positions: an 8 x 8 plane would leave half of every tile empty -- those go to the fallback)
-    fill = (h * w) / float(((h + th - 1) // th) * th * ((w + 15) // 16) * 16)
+    # (tiles of th x 16 positions: a plane that leaves much of every tile empty goes to the fallback)
+    fill = (h * w) / float(((h + th - 1) // th) * th * (8 if pair else ((w + 15) // 16) * 16))
+    if n == 8 and w == 8 and not pair:
+        fill = 0.0
     if fallback is not None and (not ok or blocks < _WINO_MIN_BLOCKS or fill < _WF_MIN_FILL):
         return fallback()            # unsupported extents, or a grid too small even with its input channels split
     if w_packed is None:
