@@ -23,7 +23,7 @@
 extern "C" {
 #endif
 
-#define TMDIFF_ABI_VERSION 4
+#define TMDIFF_ABI_VERSION 5
 
 #define TMDIFF_OK 0
 #define TMDIFF_E_INVALID (-1)     /* bad argument / shape */
@@ -267,6 +267,17 @@ int tmdiff_conv3d_wgrad(const tmdiff_conv3d_desc* d, const float* g, float* dw, 
 /* The same, and dbias[Cout] = d->bias_scale * sum_{b,pos} g[b,co,pos] on the side (the kernel reads every g element anyway;
  * this replaces a tmdiff_channel_sum pass over g).  dbias NULL = tmdiff_conv3d_wgrad. */
 int tmdiff_conv3d_wgrad_bias(const tmdiff_conv3d_desc* d, const float* g, float* dw, float* dbias, void* workspace,
+                             tmdiff_stream_t stream);
+
+/* The same weight gradient in the Winograd domain along the band axis (csrc/wgrad_wino.hip): F(3,4), the transpose of the
+ * forward's F(4,3) -- dw = A'^T[(G' g) (.) (B^T x')], half the multiply-adds.  Both operands are first transformed into
+ * channels-last zero-padded arrays by one pass each (inside the workspace), the accumulation over positions runs on the matrix
+ * pipe per Winograd plane, a reduction kernel sums the split partials in a fixed order and applies A'^T.  Takes fp32 3x3x3,
+ * groups 1 or 3, N % 4 == 0 (at most 16 bands), W % 4 == 0, any channel counts; _supported() says so (else: tmdiff_conv3d_wgrad;
+ * ATen's conv3d backward: Hyper_unet_general.py:74, :244, :372).  Same arguments and result layout as tmdiff_conv3d_wgrad. */
+int tmdiff_conv3d_wgrad_wino_supported(const tmdiff_conv3d_desc* d);
+size_t tmdiff_conv3d_wgrad_wino_workspace_bytes(const tmdiff_conv3d_desc* d);
+int tmdiff_conv3d_wgrad_wino(const tmdiff_conv3d_desc* d, const float* g, float* dw, void* workspace,
                              tmdiff_stream_t stream);
 
 /* out[c] = scale * sum_{b, p} x[b, c, p]   (x is [B, C, P]); bias gradients. */

@@ -368,6 +368,72 @@ def test_wgrad_with_bias_gradient_on_the_side(shape):
     assert_close(ops.channel_sum(g, 2.0).cpu(), want.float().cpu(), 1e-5, 1e-5, "channel_sum")
 
 
+@pytest.mark.parametrize("case", [
+    # B, segs, Cout, N, H, W, groups, prologue
+    (2, (32,), 64, 8, 16, 16, 1, False),       # two band tiles, whole boxes, 2 x 1 channel tiles
+    (1, (24,), 40, 8, 12, 20, 1, False),       # ragged h / w, channel counts that are no multiples of 32
+    (2, (16, 8, 8), 32, 4, 16, 32, 1, True),   # N = 4 (one band tile), three segments + prologue (the x' pass first)
+    (2, (16, 16, 16), 96, 8, 8, 16, 3, False), # groups = 3 on three plain segments
+    (3, (64,), 64, 8, 8, 8, 1, False),         # 8-column planes: the 8 x 8 box
+    (1, (8,), 8, 4, 8, 136, 1, False),         # three column chunks of the transform pass, ragged last chunk
+    (4, (32,), 32, 8, 32, 32, 1, False),       # one channel tile, many boxes: split over positions
+    (1, (4,), 4, 12, 8, 16, 1, False),         # three band tiles
+    (2, (64,), 64, 8, 64, 64, 1, False),       # 128 boxes per plane class: several boxes per workgroup (double buffering)
+    (1, (32,), 32, 8, 40, 48, 1, False),       # an odd number of boxes per workgroup
+])
+def test_weight_gradient_in_the_winograd_domain(case):
+    """tmdiff_conv3d_wgrad_wino: F(3,4) along the bands (transform passes + per-plane MFMA accumulation + reduction with
+    A'^T) against CPU autograd in fp64 and against the direct weight-gradient kernel; deterministic."""
+    import torch.nn.functional as F
+    from tmdiff_amd import ops
+    B, segc, cout, N, H, W, groups, pro = case
+    cin = sum(segc)
+    torch.manual_seed(11 + cout + W)
+    segs = [torch.randn(B, c, N, H, W) for c in segc]
+    g = torch.randn(B, cout, N, H, W)
+    sh, sc = torch.randn(B, cin) * 0.3, torch.rand(B, cin) + 0.5
+    xs = torch.cat(segs, 1).double()
+    if pro:
+        xs = xs + sh[:, :, None, None, None].double()
+        xs = xs * torch.sigmoid(xs) * sc[:, :, None, None, None].double()
+    with torch.enable_grad():
+        wd = torch.zeros(cout, cin // groups, 3, 3, 3, dtype=torch.float64, requires_grad=True)
+        F.conv3d(xs, wd, padding=1, groups=groups).backward(g.double())
+    kw = dict(in_shift=cu(sh), in_scale=cu(sc), in_act=True) if pro else {}
+    gd, xd = cu(g), [cu(s_) for s_ in segs]          # (the descriptor holds bare pointers: the tensors must outlive it)
+    d = ops.make_conv_desc(xd, 0, cout, 3, gd, groups=groups, **kw)
+    from tmdiff_amd import _lib
+    import ctypes as C
+    assert _lib.lib.tmdiff_conv3d_wgrad_wino_supported(C.byref(d)) == 1
+    counts = ops.COUNTS
+    ops.COUNTS = __import__("collections").Counter()
+    try:
+        dw = ops.conv3d_wgrad(d, gd, tuple(wd.shape))
+        again = ops.conv3d_wgrad(d, gd, tuple(wd.shape))
+        assert ops.COUNTS["conv3d_wgrad_wino"] == 2 and ops.COUNTS["conv3d_wgrad"] == 0
+    finally:
+        ops.COUNTS = counts
+    assert torch.equal(dw, again)
+    scale = float(wd.grad.abs().max())
+    err = float((dw.cpu().double() - wd.grad).abs().max()) / scale
+    l2 = float((dw.cpu().double() - wd.grad).norm() / wd.grad.norm())
+    print(f"winograd wgrad {case}: max err / max |dw| {err:.2e}, rel-L2 {l2:.2e}")
+    assert err <= 1e-5 and l2 <= 3e-6
+    keep, ops._WGRAD_WINO = ops._WGRAD_WINO, False
+    try:
+        direct = ops.conv3d_wgrad(d, gd, tuple(wd.shape))
+    finally:
+        ops._WGRAD_WINO = keep
+    l2d = float((direct.cpu().double() - wd.grad).norm() / wd.grad.norm())
+    print(f"   direct kernel rel-L2 {l2d:.2e}")
+    assert float((dw - direct).abs().max()) / scale <= 1e-5
+    # with the bias gradient on the side (a channel sum beside the Winograd kernel)
+    d.bias_scale = 2.0
+    dw2, db = ops.conv3d_wgrad(d, gd, tuple(wd.shape), want_bias=True)
+    assert torch.equal(dw2, dw)
+    assert_close(db.cpu(), (2.0 * g.double().sum(dim=(0, 2, 3, 4))).float(), 1e-5, 1e-5, "dbias beside the Winograd weight gradient")
+
+
 @pytest.mark.parametrize("shape", [(2, 8, 64, 4, 16, 16), (1, 6, 128, 3, 12, 20)])
 def test_composed_conv_ll_gradients_vs_cpu_autograd(shape):
     """autograd.conv3d_ll = LL(conv3d(SiLU(x), w) + b) / 2 with the forward as ONE strided convolution on composed weights

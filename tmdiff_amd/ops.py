@@ -820,10 +820,21 @@ def q_sample(x0, noise, a, out=None):
 
 
 # ---- backward-side wrappers (finetune path) -----------------------------------------------------------
+_WGRAD_WINO = os.environ.get("TMDIFF_WGRAD_WINO", "1") != "0"   # experiments: "0" = every weight gradient on the direct kernel
+
+
 def conv3d_wgrad(desc, g, weight_shape, want_bias=False):
     """dL/dw [Cout, Cin/g, k,k,k] for the convolution described by `desc` (a filled Conv3dDesc) given g = dL/dy; with
     want_bias also dL/dbias = desc.bias_scale * sum_{b,pos} g, accumulated inside the same kernel: returns (dw, dbias)."""
     dw = torch.empty(weight_shape, device=g.device, dtype=torch.float32)
+    if _WGRAD_WINO and desc.ksize == 3 and lib.tmdiff_conv3d_wgrad_wino_supported(C.byref(desc)):
+        # Winograd F(3,4) along the bands (csrc/wgrad_wino.hip): 13.5 executed multiply-adds per element instead of 27
+        _count("conv3d_wgrad_wino", 2.0 * desc.B * desc.Cout * (desc.Cin // desc.groups) * 13.5 * desc.N * desc.H * desc.W)
+        nbytes = lib.tmdiff_conv3d_wgrad_wino_workspace_bytes(C.byref(desc))
+        ws = _workspace(g.device, max(16, nbytes), "wgrad")
+        check(lib.tmdiff_conv3d_wgrad_wino(C.byref(desc), _chk(g, "g"), dw.data_ptr(), ws.data_ptr(), stream_ptr()),
+              "conv3d_wgrad_wino")
+        return (dw, channel_sum(g, desc.bias_scale)) if want_bias else dw
     _count("conv3d_wgrad", 2.0 * desc.B * desc.Cout * (desc.Cin // desc.groups) * desc.ksize ** 3 * desc.N * desc.H * desc.W)
     nbytes = lib.tmdiff_conv3d_wgrad_workspace_bytes(C.byref(desc))
     ws = _workspace(g.device, max(4, nbytes), "wgrad")

@@ -1,6 +1,7 @@
 #!/usr/bin/env python3
 """Per-layer weight-gradient micro-benchmark (finetune shapes: local batch 8, 8x64x64, ch 32-256).
-Usage: python tools/bench_wgrad.py [B] [reps]"""
+Usage: python tools/bench_wgrad.py [B] [reps] [plain]     (plain: x' is a kept tensor, no prologue pass -- the finetune path;
+TMDIFF_WGRAD_WINO=0: the direct kernel everywhere).  TFLOP/s in the direct kernel's operation count (27 taps)."""
 import sys, os
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
@@ -8,6 +9,7 @@ from tmdiff_amd import ops
 
 B = int(sys.argv[1]) if len(sys.argv) > 1 else 8
 REPS = int(sys.argv[2]) if len(sys.argv) > 2 else 5
+PLAIN = "plain" in sys.argv[3:]
 LAYERS = [("L0 32->32", 32, 32, 64, 3, 1, 10), ("L0 32->64", 32, 64, 64, 3, 1, 2), ("L0 64->64", 64, 64, 64, 3, 1, 4),
           ("L0 96->32", 96, 32, 64, 3, 1, 1), ("L1 64->128", 64, 128, 32, 3, 1, 2), ("L1 128->128", 128, 128, 32, 3, 1, 4),
           ("L1 192->32", 192, 32, 32, 3, 1, 1), ("L2 128->256", 128, 256, 16, 3, 1, 2), ("L2 256->256", 256, 256, 16, 3, 1, 4),
@@ -20,7 +22,7 @@ for name, ci, co, h, k, g, cnt in LAYERS:
     sc = torch.rand(B, ci, device="cuda") + 0.5
     y = torch.empty(B, co, 8, h, h, device="cuda")
     wp = torch.empty(co * (ci // g) * k ** 3, device="cuda")
-    d = ops.make_conv_desc([x], wp, co, k, y, groups=g, in_scale=sc, in_act=True)
+    d = ops.make_conv_desc([x], wp, co, k, y, groups=g) if PLAIN else ops.make_conv_desc([x], wp, co, k, y, groups=g, in_scale=sc, in_act=True)
     f = lambda: ops.conv3d_wgrad(d, gy, (co, ci // g, k, k, k))
     f(); torch.cuda.synchronize()
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
