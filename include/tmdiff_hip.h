@@ -183,8 +183,9 @@ size_t tmdiff_conv3d_wino_packed_bytes(int32_t Cout, int32_t Cin, int32_t groups
 int tmdiff_conv3d_wino_pack_weights(const float* w, float* packed, int32_t Cout, int32_t Cin, int32_t groups,
                                     int32_t mode, int32_t planes, tmdiff_stream_t stream);
 /* Multi-tensor form, ONE launch for every (weight, mode) of a network (the finetune step re-packs the Winograd weights of its
- * ~50 convolutions in both forms after every optimizer step).  `entries_dev` is a DEVICE array; workgroup k packs elements
- * [chunk_index_dev[k] * tmdiff_conv3d_wino_pack_weights_multi_chunk(), ...) of entry chunk_tensor_dev[k].  Cout / Cin / groups are
+ * ~50 convolutions in both forms after every optimizer step).  `entries_dev` is a DEVICE array; workgroup k packs weight rows
+ * [chunk_index_dev[k] * tmdiff_conv3d_wino_pack_weights_multi_chunk(), ...) of entry chunk_tensor_dev[k] (a row = the 27 taps of one
+ * (output, input channel) pair: numel(w) / 27 rows per entry).  Cout / Cin / groups are
  * those of the weight tensor w = [Cout, Cin/groups, 3,3,3]; mode / planes as tmdiff_conv3d_wino_pack_weights. */
 typedef struct tmdiff_wino_pack_entry {
   const float* w;

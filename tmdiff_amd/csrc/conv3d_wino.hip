@@ -502,14 +502,17 @@ int launch(WinoArgs& a, hipStream_t st) {
 // (column order inside a 64-channel tile as tmdiff_conv3d_pack_weights: channel c at (c % 32) * 2 + c / 32; mode | 2: natural
 // column order, for the 32-channel tiles of conv3d_wf.hip; mode | 1: the data-gradient form -- this convolution's (co, ci) are
 // the forward one's (ci, co), every tap mirrored)
+// One thread packs one WEIGHT ROW: the 27 taps of one (output column, input channel) pair -- 108 contiguous bytes in, 9 x NP
+// values out, each of them in a run of consecutive columns written by consecutive lanes.  (One thread per packed ELEMENT read
+// three words 36 bytes apart for every element, lanes a whole weight row apart: the re-pack of a finetune step took 0.9 ms.)
+// row index r = (g * cin_g + ci) * cout_g + col of THIS convolution (for the data-gradient form the forward weight's
+// dimensions swapped).
 template <int NP>
-__device__ __forceinline__ float wino_pack_one(const float* __restrict__ w, long i, int cout_g, int cin_g, int mode) {
+__device__ __forceinline__ void wino_pack_row(const float* __restrict__ w, float* __restrict__ packed, long r, int cout_g, int cin_g, int mode) {
 #pragma clang fp contract(off)     // (the single- and the multi-tensor kernel must give the same bits: no per-site FMA fusion)
   using M = WM<NP>;
-  const int col = (int)(i % cout_g);
-  long r = i / cout_g;
-  const int k = (int)(r % NP); r /= NP;
-  const int tap9 = (int)(r % 9); r /= 9;
+  const int col = (int)(r % cout_g);
+  r /= cout_g;
   const int ci = (int)(r % cin_g);
   const int g = (int)(r / cin_g);
   int co = col;
@@ -517,40 +520,41 @@ __device__ __forceinline__ float wino_pack_one(const float* __restrict__ w, long
     const int tile = col / 64, j = col % 64;
     co = tile * 64 + (j % 2) * 32 + j / 2;
   }
-  float g3[3];
-  if ((mode & 1) == 0) {
-    const float* wk = w + (((long)g * cout_g + co) * cin_g + ci) * 27 + tap9;
-    g3[0] = wk[0], g3[1] = wk[9], g3[2] = wk[18];
-  } else {
-    const float* wk = w + (((long)g * cin_g + ci) * cout_g + co) * 27 + (8 - tap9);
-    g3[0] = wk[18], g3[1] = wk[9], g3[2] = wk[0];
-  }
-  float u = 0.f;
+  const bool dg = (mode & 1) != 0;
+  const float* wk = dg ? w + (((long)g * cin_g + ci) * cout_g + co) * 27 : w + (((long)g * cout_g + co) * cin_g + ci) * 27;
+  float t[27];
 #pragma unroll
-  for (int kk = 0; kk < NP; ++kk)
-    if (kk == k) u = M::G[kk][0] * g3[0] + M::G[kk][1] * g3[1] + M::G[kk][2] * g3[2];
-  return u;
+  for (int i = 0; i < 27; ++i) t[i] = wk[i];
+  float* dst = packed + (((long)g * cin_g + ci) * 9) * NP * cout_g + col;
+#pragma unroll
+  for (int tap9 = 0; tap9 < 9; ++tap9) {
+    // forward form: taps (dn, tap9); data-gradient form: the mirrored taps (2 - dn, 8 - tap9)
+    const float g0 = dg ? t[18 + 8 - tap9] : t[tap9], g1 = dg ? t[9 + 8 - tap9] : t[9 + tap9], g2 = dg ? t[8 - tap9] : t[18 + tap9];
+#pragma unroll
+    for (int k = 0; k < NP; ++k) dst[((long)tap9 * NP + k) * cout_g] = M::G[k][0] * g0 + M::G[k][1] * g1 + M::G[k][2] * g2;
+  }
 }
 
 template <int NP>
 __global__ void __launch_bounds__(256) wino_pack_weights_kernel(const float* __restrict__ w, float* __restrict__ packed, int cout_g,
-                                                                int cin_g, int mode, long total) {
-  for (long i = blockIdx.x * 256L + threadIdx.x; i < total; i += 256L * gridDim.x) packed[i] = wino_pack_one<NP>(w, i, cout_g, cin_g, mode);
+                                                                int cin_g, int mode, long rows) {
+  for (long r = blockIdx.x * 256L + threadIdx.x; r < rows; r += 256L * gridDim.x) wino_pack_row<NP>(w, packed, r, cout_g, cin_g, mode);
 }
 
-// Multi-tensor form: every (weight, mode) of a network in ONE launch.  Workgroup k packs elements
-// [chunk_index[k] * WINO_MT_CHUNK, + WINO_MT_CHUNK) of entry chunk_tensor[k] (the element order of wino_pack_weights_kernel).
-constexpr int WINO_MT_CHUNK = 4096;
+// Multi-tensor form: every (weight, mode) of a network in ONE launch.  Workgroup k packs weight rows
+// [chunk_index[k] * WINO_MT_CHUNK, + WINO_MT_CHUNK) of entry chunk_tensor[k].
+constexpr int WINO_MT_CHUNK = 256;
 __global__ void __launch_bounds__(256) wino_pack_weights_multi_kernel(const tmdiff_wino_pack_entry* __restrict__ entries,
                                                                       const int32_t* __restrict__ chunk_tensor,
                                                                       const int32_t* __restrict__ chunk_index) {
   const tmdiff_wino_pack_entry e = entries[chunk_tensor[blockIdx.x]];
   // Cout / Cin of THIS convolution (for the data-gradient form the forward weight's dimensions swapped)
   const int cout_g = ((e.mode & 1) ? e.Cin : e.Cout) / e.groups, cin_g = ((e.mode & 1) ? e.Cout : e.Cin) / e.groups;
-  const long total = (long)cin_g * 9 * e.planes * cout_g * e.groups;
-  const long lo = (long)chunk_index[blockIdx.x] * WINO_MT_CHUNK;
-  for (long i = lo + threadIdx.x; i < lo + WINO_MT_CHUNK && i < total; i += 256)
-    e.packed[i] = e.planes == 6 ? wino_pack_one<6>(e.w, i, cout_g, cin_g, e.mode) : wino_pack_one<4>(e.w, i, cout_g, cin_g, e.mode);
+  const long rows = (long)cin_g * cout_g * e.groups;
+  const long r = (long)chunk_index[blockIdx.x] * WINO_MT_CHUNK + threadIdx.x;
+  if (r >= rows) return;
+  if (e.planes == 6) wino_pack_row<6>(e.w, e.packed, r, cout_g, cin_g, e.mode);
+  else wino_pack_row<4>(e.w, e.packed, r, cout_g, cin_g, e.mode);
 }
 
 bool wino_ok(const tmdiff_conv3d_desc* d) {
@@ -609,13 +613,13 @@ extern "C" int tmdiff_conv3d_wino_pack_weights(const float* w, float* packed, in
                  "conv3d_wino_pack_weights: Cout=%d Cin=%d groups=%d (Cout/groups a multiple of 32)", Cout, Cin, groups);
   TMDIFF_REQUIRE(mode >= 0 && mode <= 3, "conv3d_wino_pack_weights: mode=%d (bit 0: data-gradient form, bit 1: natural column order)", mode);
   TMDIFF_REQUIRE(planes == 4 || planes == 6, "conv3d_wino_pack_weights: planes=%d (tmdiff_conv3d_wino_planes)", planes);
-  const long total = (long)(Cin / groups) * 9 * planes * Cout;
-  long blocks = (total + 255) / 256;
+  const long rows = (long)(Cin / groups) * Cout;
+  long blocks = (rows + 255) / 256;
   if (blocks > 4096) blocks = 4096;
   if (planes == 6)
-    wino_pack_weights_kernel<6><<<(int)blocks, 256, 0, as_stream(stream)>>>(w, packed, Cout / groups, Cin / groups, mode, total);
+    wino_pack_weights_kernel<6><<<(int)blocks, 256, 0, as_stream(stream)>>>(w, packed, Cout / groups, Cin / groups, mode, rows);
   else
-    wino_pack_weights_kernel<4><<<(int)blocks, 256, 0, as_stream(stream)>>>(w, packed, Cout / groups, Cin / groups, mode, total);
+    wino_pack_weights_kernel<4><<<(int)blocks, 256, 0, as_stream(stream)>>>(w, packed, Cout / groups, Cin / groups, mode, rows);
   return check_launch("conv3d_wino_pack_weights");
 }
 

@@ -495,12 +495,21 @@ extern "C" int tmdiff_conv3d_wgrad_wino(const tmdiff_conv3d_desc* d, const float
     if (rc) return rc;
     segs[0] = xp; segc[0] = d->Cin; nseg = 1;
   }
-  int rc = launch_transform(d, p, segs, segc, nseg, d->Cin, p.CiP, 1, xh, st);
-  if (rc) return rc;
-  const float* gseg[3] = {g, nullptr, nullptr};
-  const int gc[3] = {d->Cout, 0, 0};
-  rc = launch_transform(d, p, gseg, gc, 1, d->Cout, p.CoP, 0, gh, st);
-  if (rc) return rc;
+  // (timing experiments: TMDIFF_WW_PHASES = bit mask of the phases that run -- 1 transform passes, 2 accumulation, 4 reduction;
+  //  anything but 7 leaves dw wrong or stale)
+  static const int phases = [] {
+    const char* e = getenv("TMDIFF_WW_PHASES");
+    return e ? atoi(e) : 7;
+  }();
+  int rc = TMDIFF_OK;
+  if (phases & 1) {
+    rc = launch_transform(d, p, segs, segc, nseg, d->Cin, p.CiP, 1, xh, st);
+    if (rc) return rc;
+    const float* gseg[3] = {g, nullptr, nullptr};
+    const int gc[3] = {d->Cout, 0, 0};
+    rc = launch_transform(d, p, gseg, gc, 1, d->Cout, p.CoP, 0, gh, st);
+    if (rc) return rc;
+  }
 
   WwArgs a;
   a.xh = xh; a.gh = gh; a.ws = part;
@@ -510,12 +519,15 @@ extern "C" int tmdiff_conv3d_wgrad_wino(const tmdiff_conv3d_desc* d, const float
   const long blocks = (long)d->groups * 6 * p.splits * p.tiles_co * p.tiles_ci;
   TMDIFF_REQUIRE(blocks > 0 && blocks < 0x7fffffffL, "conv3d_wgrad_wino: grid of %ld blocks", blocks);
   a.total_blocks = (unsigned)blocks;
-  if (p.bw == 16)
-    ww_gemm_kernel<8, 16><<<(unsigned)blocks, 256, 0, st>>>(a);
-  else
-    ww_gemm_kernel<8, 8><<<(unsigned)blocks, 256, 0, st>>>(a);
-  rc = check_launch("conv3d_wgrad_wino");
-  if (rc) return rc;
+  if (phases & 2) {
+    if (p.bw == 16)
+      ww_gemm_kernel<8, 16><<<(unsigned)blocks, 256, 0, st>>>(a);
+    else
+      ww_gemm_kernel<8, 8><<<(unsigned)blocks, 256, 0, st>>>(a);
+    rc = check_launch("conv3d_wgrad_wino");
+    if (rc) return rc;
+  }
+  if (!(phases & 4)) return TMDIFF_OK;
   const int cout_g = d->Cout / d->groups, cin_g = d->Cin / d->groups;
   const long rblocks = (long)d->groups * cout_g * ((cin_g + 63) / 64) * 9;
   ww_reduce_kernel<<<(unsigned)rblocks, 256, 0, st>>>(part, dw, p.splits, d->groups, cout_g, cin_g, p.CoP, p.CiP);

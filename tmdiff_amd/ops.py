@@ -116,7 +116,7 @@ class WinoPackedWeights:
         ent, ct, ci = bytearray(), [], []
         for n, ((_, mode), (w, g, out, _)) in enumerate(self.items.items()):
             ent += struct.pack("<QQiiiiii", w.data_ptr(), out.data_ptr(), w.shape[0], w.shape[1] * g, g, mode, 6, 0)
-            nck = (out.numel() + chunk - 1) // chunk
+            nck = (w.numel() // 27 + chunk - 1) // chunk          # (chunks of weight rows: 27 taps each)
             ct += [n] * nck
             ci += list(range(nck))
         dev = next(iter(self.items.values()))[0].device
