@@ -280,6 +280,10 @@ int tmdiff_conv3d_wgrad_wino_supported(const tmdiff_conv3d_desc* d);
 size_t tmdiff_conv3d_wgrad_wino_workspace_bytes(const tmdiff_conv3d_desc* d);
 int tmdiff_conv3d_wgrad_wino(const tmdiff_conv3d_desc* d, const float* g, float* dw, void* workspace,
                              tmdiff_stream_t stream);
+/* ... and dbias[Cout] = d->bias_scale * sum_{b,pos} g on the side (the pass that transforms g sums it up as it reads; fixed
+ * summation order).  dbias NULL = tmdiff_conv3d_wgrad_wino. */
+int tmdiff_conv3d_wgrad_wino_bias(const tmdiff_conv3d_desc* d, const float* g, float* dw, float* dbias, void* workspace,
+                                  tmdiff_stream_t stream);
 
 /* out[c] = scale * sum_{b, p} x[b, c, p]   (x is [B, C, P]); bias gradients. */
 int tmdiff_channel_sum(const float* x, float* out, int32_t B, int32_t C, int64_t P, float scale,

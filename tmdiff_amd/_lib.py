@@ -78,6 +78,7 @@ SIGNATURES = {
     "tmdiff_conv3d_wgrad_wino_supported": (C.c_int, [C.POINTER(Conv3dDesc)]),
     "tmdiff_conv3d_wgrad_wino_workspace_bytes": (C.c_size_t, [C.POINTER(Conv3dDesc)]),
     "tmdiff_conv3d_wgrad_wino": (C.c_int, [C.POINTER(Conv3dDesc), vp, vp, vp, vp]),
+    "tmdiff_conv3d_wgrad_wino_bias": (C.c_int, [C.POINTER(Conv3dDesc), vp, vp, vp, vp, vp]),
     "tmdiff_channel_sum": (C.c_int, [vp, vp, C.c_int32, C.c_int32, C.c_int64, C.c_float, vp]),
     "tmdiff_conv3d_prologue_bwd": (C.c_int, [C.POINTER(Conv3dDesc), vp, vp * 3, C.c_int32 * 3, vp, vp, vp]),
     "tmdiff_conv3d_prologue_bwd_workspace_bytes": (C.c_size_t, [C.POINTER(Conv3dDesc)]),

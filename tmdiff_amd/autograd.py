@@ -19,6 +19,7 @@ import os as _os
 # pass (0.6 ms of launches) is paid back inside the MFMA stream -- so the separate pass stays the default.
 _WINOGRAD = _os.environ.get("TMDIFF_WINOGRAD", "1") != "0"     # experiments: "0" = direct kernels for every convolution
 _WGRAD_BIAS = _os.environ.get("TMDIFF_WGRAD_BIAS", "0") == "1"
+_WGRAD_WINO_BIAS = _os.environ.get("TMDIFF_WGRAD_WINO_BIAS", "1") != "0"   # experiments: "0" = a channel-sum kernel beside the Winograd weight gradient
 
 
 class DropSpec(tuple):
@@ -111,7 +112,7 @@ class _FusedConv3d(torch.autograd.Function):
                                   in_act=act, in_mask=mask, drop=ctx.drop)
         if need[1]:   # x' kept by the forward: a plain single-tensor input, no prologue pass inside the weight gradient
             desc_w = ops.make_conv_desc([xp], 0, cout, ksize, dummy, groups=groups) if xp is not None else desc
-            if has_bias and need[2] and _WGRAD_BIAS:      # the bias gradient rides along in the weight-gradient kernel
+            if has_bias and need[2] and (_WGRAD_BIAS or (_WGRAD_WINO_BIAS and ops.wgrad_wino_takes(desc_w))):   # the bias gradient rides along in the weight-gradient kernel
                 desc_w.bias_scale = bias_scale
                 d_w, d_bias = ops.conv3d_wgrad(desc_w, g, tuple(w.shape), want_bias=True)
             else:

@@ -75,6 +75,7 @@ struct WwTransformArgs {
   int halo;                // 1: x^ = B^T x (6 input bands, array rows / columns shifted by one); 0: g^ = G' g (4 input bands)
   float* out;
   int wchunks, cchunks;
+  float* bias_part;        // g^ pass only: [workgroup of this channel chunk][CP] sums of the operand over the workgroup's elements, or NULL
 };
 
 constexpr int TR_W = 64;   // columns per workgroup
@@ -103,6 +104,7 @@ __global__ void __launch_bounds__(256) ww_transform_kernel(const WwTransformArgs
     const int segc = seg == 0 ? a.seg_c[0] : (seg == 1 ? a.seg_c[1] : a.seg_c[2]);
     const float* src = (seg == 0 ? a.seg_x[0] : (seg == 1 ? a.seg_x[1] : a.seg_x[2])) + ((long)b * segc + cs) * a.N * hw + (long)h * a.W;
     const bool c_ok = row_ok && cl < a.cg;
+    float bsum = 0.f;        // (bias gradient on the side: this pass reads every element of g exactly once)
 #pragma unroll
     for (int it = 0; it < 2; ++it) {
       const int wl = it * 32 + wq * 4, w = wc * TR_W + wl;
@@ -113,6 +115,7 @@ __global__ void __launch_bounds__(256) ww_transform_kernel(const WwTransformArgs
         float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
         if (c_ok && w < a.W && n >= 0 && n < a.N && (a.halo || j < 4)) v = *reinterpret_cast<const float4*>(src + (long)n * hw + w);
         d[j][0] = v.x, d[j][1] = v.y, d[j][2] = v.z, d[j][3] = v.w;
+        bsum += (v.x + v.y) + (v.z + v.w);
       }
 #pragma unroll
       for (int e = 0; e < 4; ++e) {
@@ -140,6 +143,13 @@ __global__ void __launch_bounds__(256) ww_transform_kernel(const WwTransformArgs
 #pragma unroll
         for (int k = 0; k < 6; ++k) tile[(k * TR_W + wl + e) * 33 + c] = o[k];
       }
+    }
+    if (a.bias_part) {       // the eight lanes of a channel are neighbours: fixed-order butterfly, lane 0 of the eight writes
+      bsum += __shfl_xor(bsum, 1, 64);
+      bsum += __shfl_xor(bsum, 2, 64);
+      bsum += __shfl_xor(bsum, 4, 64);
+      const long blk = (((long)b * a.T + t) * gridDim.y + blockIdx.y) * a.wchunks + wc;     // (per group: the group is in the column)
+      if (wq == 0) a.bias_part[blk * a.groups * a.CP + (long)g * a.CP + cl] = bsum;
     }
   }
   __syncthreads();
@@ -347,11 +357,29 @@ __global__ void __launch_bounds__(256, 2) ww_gemm_kernel(const WwArgs a) {
 // dw[co][ci][dn][dh][dw] = sum_k A'^T[dn][k] sum_split ws[split][g][k][(dh, dw)][co][ci],  A'^T = [1 1 1 1 1 0; 0 1 -1 2 -2 0; 0 1 1 4 4 1].
 // One workgroup = one (output channel, (dh, dw)) x 64 input channels; its four thread groups each add every fourth split
 // (six planes = six independent sums in flight), then the four group sums are added in group order: a fixed summation order.
+// Workgroups past the weight tiles finish the bias gradient: dbias[c] = bias_scale * sum of the g^ pass's per-workgroup sums
+// (32 channels per workgroup, eight slices of the list per channel added in slice order).
 __global__ void __launch_bounds__(256) ww_reduce_kernel(const float* __restrict__ ws, float* __restrict__ dw, int splits, int groups,
-                                                        int cout_g, int cin_g, int CoP, int CiP) {
+                                                        int cout_g, int cin_g, int CoP, int CiP, int wblocks,
+                                                        const float* __restrict__ bias_part, float* __restrict__ dbias, int nbias,
+                                                        float bias_scale) {
   __shared__ float part[4][6][64];
   const int cchunks = (cin_g + 63) / 64;
   int id = blockIdx.x;
+  if (id >= wblocks) {
+    const int c = (id - wblocks) * 32 + (threadIdx.x & 31), sl = threadIdx.x >> 5;       // c: index into [groups][CoP]
+    float t = 0.f;
+    for (int i = sl; i < nbias; i += 8) t += bias_part[(long)i * groups * CoP + c];
+    float* red = &part[0][0][0];
+    red[sl * 32 + (threadIdx.x & 31)] = t;
+    __syncthreads();
+    if (sl == 0) {
+      for (int i = 1; i < 8; ++i) t += red[i * 32 + threadIdx.x];
+      const int g = c / CoP, cl = c % CoP;
+      if (cl < cout_g) dbias[g * cout_g + cl] = bias_scale * t;
+    }
+    return;
+  }
   const int tap = id % 9; id /= 9;
   const int cc = id % cchunks; id /= cchunks;
   const int co = id % cout_g;
@@ -388,7 +416,8 @@ struct WwPlan {
   int Hb, Wb, CiP, CoP, Q;
   int tiles_co, tiles_ci, nbh, nbw, nboxes, splits, bps;
   bool needs_xp;
-  size_t xh_floats, gh_floats, part_floats, xp_floats;
+  size_t xh_floats, gh_floats, part_floats, bias_floats, xp_floats;
+  int nbias;                 // workgroups of the g^ pass per channel chunk
 };
 
 bool ww_shape_ok(const tmdiff_conv3d_desc* d) {
@@ -429,6 +458,8 @@ WwPlan ww_plan(const tmdiff_conv3d_desc* d) {
   p.xh_floats = (size_t)d->groups * 6 * p.Q * (p.Hb + 2) * (p.Wb + 2) * p.CiP;
   p.gh_floats = (size_t)d->groups * 6 * p.Q * p.Hb * p.Wb * p.CoP;
   p.part_floats = (size_t)p.splits * d->groups * 54 * p.CoP * p.CiP;
+  p.nbias = p.Hb * d->B * p.T * ((d->W + TR_W - 1) / TR_W);
+  p.bias_floats = (size_t)p.nbias * d->groups * p.CoP;
   p.xp_floats = p.needs_xp ? ((size_t)d->B * d->Cin * d->N * d->H * d->W + 3) / 4 * 4 : 0;
   return p;
 }
@@ -440,12 +471,12 @@ bool ww_fits(const tmdiff_conv3d_desc* d, const WwPlan& p) {
 }
 
 int launch_transform(const tmdiff_conv3d_desc* d, const WwPlan& p, const float* const* seg_x, const int* seg_c, int nseg, int C,
-                     int CP, int halo, float* out, hipStream_t st) {
+                     int CP, int halo, float* out, float* bias_part, hipStream_t st) {
   WwTransformArgs t;
   for (int i = 0; i < 3; ++i) { t.seg_x[i] = i < nseg ? seg_x[i] : nullptr; t.seg_c[i] = i < nseg ? seg_c[i] : 0; }
   t.nseg = nseg;
   t.B = d->B; t.cg = C / d->groups; t.groups = d->groups; t.N = d->N; t.H = d->H; t.W = d->W; t.T = p.T;
-  t.CP = CP; t.Hb = p.Hb; t.Wb = p.Wb; t.halo = halo; t.out = out;
+  t.CP = CP; t.Hb = p.Hb; t.Wb = p.Wb; t.halo = halo; t.out = out; t.bias_part = bias_part;
   t.wchunks = (d->W + TR_W - 1) / TR_W; t.cchunks = CP / 32;
   const dim3 grid((unsigned)(t.wchunks * t.cchunks), (unsigned)(p.Hb + 2 * halo), (unsigned)(d->B * d->groups * p.T));
   ww_transform_kernel<<<grid, 256, 0, st>>>(t);
@@ -462,11 +493,16 @@ extern "C" int tmdiff_conv3d_wgrad_wino_supported(const tmdiff_conv3d_desc* d) {
 extern "C" size_t tmdiff_conv3d_wgrad_wino_workspace_bytes(const tmdiff_conv3d_desc* d) {
   if (!ww_shape_ok(d)) return 0;
   const WwPlan p = ww_plan(d);
-  return (p.xh_floats + p.gh_floats + p.part_floats + p.xp_floats) * sizeof(float);
+  return (p.xh_floats + p.gh_floats + p.part_floats + p.bias_floats + p.xp_floats) * sizeof(float);
 }
 
 extern "C" int tmdiff_conv3d_wgrad_wino(const tmdiff_conv3d_desc* d, const float* g, float* dw, void* workspace,
                                         tmdiff_stream_t stream) {
+  return tmdiff_conv3d_wgrad_wino_bias(d, g, dw, nullptr, workspace, stream);
+}
+
+extern "C" int tmdiff_conv3d_wgrad_wino_bias(const tmdiff_conv3d_desc* d, const float* g, float* dw, float* dbias, void* workspace,
+                                             tmdiff_stream_t stream) {
   using namespace tmdiff;
   TMDIFF_REQUIRE(d && g && dw && workspace, "conv3d_wgrad_wino: NULL pointer");
   if (!ww_shape_ok(d))
@@ -485,7 +521,8 @@ extern "C" int tmdiff_conv3d_wgrad_wino(const tmdiff_conv3d_desc* d, const float
   float* xh = static_cast<float*>(workspace);
   float* gh = xh + p.xh_floats;
   float* part = gh + p.gh_floats;
-  float* xp = part + p.part_floats;
+  float* bias_part = part + p.part_floats;
+  float* xp = bias_part + p.bias_floats;
 
   const float* segs[3] = {d->seg_x[0], d->seg_x[1], d->seg_x[2]};
   int segc[3] = {d->seg_c[0], d->seg_c[1], d->seg_c[2]};
@@ -503,11 +540,11 @@ extern "C" int tmdiff_conv3d_wgrad_wino(const tmdiff_conv3d_desc* d, const float
   }();
   int rc = TMDIFF_OK;
   if (phases & 1) {
-    rc = launch_transform(d, p, segs, segc, nseg, d->Cin, p.CiP, 1, xh, st);
+    rc = launch_transform(d, p, segs, segc, nseg, d->Cin, p.CiP, 1, xh, nullptr, st);
     if (rc) return rc;
     const float* gseg[3] = {g, nullptr, nullptr};
     const int gc[3] = {d->Cout, 0, 0};
-    rc = launch_transform(d, p, gseg, gc, 1, d->Cout, p.CoP, 0, gh, st);
+    rc = launch_transform(d, p, gseg, gc, 1, d->Cout, p.CoP, 0, gh, dbias ? bias_part : nullptr, st);
     if (rc) return rc;
   }
 
@@ -530,6 +567,8 @@ extern "C" int tmdiff_conv3d_wgrad_wino(const tmdiff_conv3d_desc* d, const float
   if (!(phases & 4)) return TMDIFF_OK;
   const int cout_g = d->Cout / d->groups, cin_g = d->Cin / d->groups;
   const long rblocks = (long)d->groups * cout_g * ((cin_g + 63) / 64) * 9;
-  ww_reduce_kernel<<<(unsigned)rblocks, 256, 0, st>>>(part, dw, p.splits, d->groups, cout_g, cin_g, p.CoP, p.CiP);
+  const long bblocks = dbias ? (long)d->groups * p.CoP / 32 : 0;
+  ww_reduce_kernel<<<(unsigned)(rblocks + bblocks), 256, 0, st>>>(part, dw, p.splits, d->groups, cout_g, cin_g, p.CoP, p.CiP, (int)rblocks,
+                                                                  bias_part, dbias, p.nbias, d->bias_scale);
   return check_launch("conv3d_wgrad_wino(reduce)");
 }

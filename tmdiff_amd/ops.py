@@ -823,6 +823,12 @@ def q_sample(x0, noise, a, out=None):
 _WGRAD_WINO = os.environ.get("TMDIFF_WGRAD_WINO", "1") != "0"   # experiments: "0" = every weight gradient on the direct kernel
 
 
+def wgrad_wino_takes(desc):
+    """True when conv3d_wgrad runs this weight gradient in the Winograd domain (its g pass then sums the bias gradient on
+    the side for free)."""
+    return bool(_WGRAD_WINO and desc.ksize == 3 and lib.tmdiff_conv3d_wgrad_wino_supported(C.byref(desc)))
+
+
 def conv3d_wgrad(desc, g, weight_shape, want_bias=False):
     """dL/dw [Cout, Cin/g, k,k,k] for the convolution described by `desc` (a filled Conv3dDesc) given g = dL/dy; with
     want_bias also dL/dbias = desc.bias_scale * sum_{b,pos} g, accumulated inside the same kernel: returns (dw, dbias)."""
@@ -832,9 +838,10 @@ def conv3d_wgrad(desc, g, weight_shape, want_bias=False):
         _count("conv3d_wgrad_wino", 2.0 * desc.B * desc.Cout * (desc.Cin // desc.groups) * 13.5 * desc.N * desc.H * desc.W)
         nbytes = lib.tmdiff_conv3d_wgrad_wino_workspace_bytes(C.byref(desc))
         ws = _workspace(g.device, max(16, nbytes), "wgrad")
-        check(lib.tmdiff_conv3d_wgrad_wino(C.byref(desc), _chk(g, "g"), dw.data_ptr(), ws.data_ptr(), stream_ptr()),
-              "conv3d_wgrad_wino")
-        return (dw, channel_sum(g, desc.bias_scale)) if want_bias else dw
+        db = torch.empty(weight_shape[0], device=g.device, dtype=torch.float32) if want_bias else None
+        check(lib.tmdiff_conv3d_wgrad_wino_bias(C.byref(desc), _chk(g, "g"), dw.data_ptr(), _chk(db, "db"), ws.data_ptr(),
+                                                stream_ptr()), "conv3d_wgrad_wino")
+        return (dw, db) if want_bias else dw
     _count("conv3d_wgrad", 2.0 * desc.B * desc.Cout * (desc.Cin // desc.groups) * desc.ksize ** 3 * desc.N * desc.H * desc.W)
     nbytes = lib.tmdiff_conv3d_wgrad_workspace_bytes(C.byref(desc))
     ws = _workspace(g.device, max(4, nbytes), "wgrad")
