@@ -519,6 +519,8 @@ def conv3d_wf(segs, w_packed, cout, emit=None, keep_y=True, fallback=None, group
     ok = _WF and n in (4, 8) and w % 4 == 0 and cg % 32 == 0 and (cin // groups) % 2 == 0 and kw.get("in_mask") is None
     # (tiles of th x 16 positions: a plane that leaves much of every tile empty goes to the fallback)
     fill = (h * w) / float(((h + th - 1) // th) * th * (8 if pair else ((w + 15) // 16) * 16))
+    if pair:
+        fill *= b / (2.0 * ((b + 1) // 2))        # (an odd batch leaves the last pair's second half empty: B = 1 is half a tile)
     if n == 8 and w == 8 and not pair:
         fill = 0.0
     if fallback is not None and (not ok or blocks < _WINO_MIN_BLOCKS or fill < _WF_MIN_FILL):

@@ -31,6 +31,9 @@ for name, ci, co, h, k, g, cnt in LAYERS:
     e1.record(); torch.cuda.synchronize()
     ms = e0.elapsed_time(e1) / REPS
     fl = 2.0 * B * co * (ci // g) * k ** 3 * 8 * h * h
-    print(f"{name:16s} {ms:8.3f} ms  {fl / ms / 1e9:7.1f} TFLOP/s  ({fl / ms / 1e9 / 157.3 * 100:5.1f}% of fp32 MFMA peak)  x{cnt}", flush=True)
-    tot_t += ms * cnt; tot_f += fl * cnt
-print(f"weighted total: {tot_t:.2f} ms for {tot_f / 1e12:.2f} TFLOP -> {tot_f / tot_t / 1e9:.1f} TFLOP/s (incl. prologue apply + reduce)")
+    wino = ops.wgrad_wino_takes(d)            # F(3,4) along the bands: half the multiply-adds are executed
+    ex = fl / (2.0 if wino else 1.0)
+    print(f"{name:16s} {ms:8.3f} ms  {fl / ms / 1e9:7.1f} TFLOP/s direct-order, {ex / ms / 1e9:6.1f} executed ({ex / ms / 1e9 / 157.3 * 100:5.1f}% of fp32 MFMA peak, "
+          f"{'winograd' if wino else 'direct'}, passes and reduction included)  x{cnt}", flush=True)
+    tot_t += ms * cnt; tot_f += fl * cnt; tot_e = (tot_e if "tot_e" in dir() else 0.0) + ex * cnt
+print(f"weighted total: {tot_t:.2f} ms for {tot_f / 1e12:.2f} TFLOP direct-order -> {tot_f / tot_t / 1e9:.1f} TFLOP/s direct-order, {tot_e / tot_t / 1e9:.1f} executed")

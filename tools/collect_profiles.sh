@@ -8,7 +8,9 @@ bash tools/bench_traffic.sh $TAG > $O/traffic.log 2>&1; echo "traffic rc=$?"
 python3 tools/bench_configs.py c1 c3 c4 2>&1 | grep config > $O/configs.txt
 python3 tools/bench_attention.py 2>&1 | grep -v amdgpu > $O/attention.txt
 python3 tools/bench_hbm_kernels.py 2>&1 | grep -v amdgpu > $O/hbm_kernels.txt
-python3 tools/bench_wgrad.py 8 3 2>&1 | grep -v amdgpu > $O/wgrad_b8.txt
+python3 tools/bench_wgrad.py 8 5 plain 2>&1 | grep -v amdgpu > $O/wgrad_b8.txt
+TMDIFF_WGRAD_WINO=0 python3 tools/bench_wgrad.py 8 5 plain 2>&1 | grep -v amdgpu > $O/wgrad_b8_direct.txt
+for ph in 1 2 4; do echo "== TMDIFF_WW_PHASES=$ph (1: the two transform passes, 2: the accumulation kernel, 4: the reduction; alone, results stale)"; TMDIFF_WW_PHASES=$ph python3 tools/bench_wgrad.py 8 20 plain 2>&1 | grep -v amdgpu | cut -c1-48; done > $O/wgrad_b8_phases.txt
 python3 tools/bench_conv.py 32 3 fp32 2>&1 | grep -v amdgpu > $O/conv_layers_fp32.txt
 python3 tools/bench_conv.py 32 3 bf16 2>&1 | grep -v amdgpu > $O/conv_layers_bf16.txt
 python3 tools/bench_conv_ll.py 32 5 2>&1 | grep -v amdgpu > $O/conv_ll.txt
@@ -25,12 +27,12 @@ for v in 1 2 3; do [ -f tools/lib_wfab$v.so ] && { echo "== TMDIFF_WF_ABLATE=$v 
 python3 tools/bench_bf16_dma.py 32 10 2>&1 | grep -v amdgpu > $O/conv_bf16_packed.txt
 # (diagnostic build with s_memtime stamps: tools/build_variant.sh stamps "-DTMDIFF_BF16_STAMPS=1" conv3d_bf16, before the call)
 [ -f tools/lib_stamps.so ] && TMDIFF_HIP_LIB=tools/lib_stamps.so python3 tools/bf16_stamps.py 32 2>&1 | grep -v amdgpu > $O/conv_bf16_stamps.txt
-bash tools/run_pmc.sh ${TAG}_final/pmc_wgrad "bench_wgrad.py 8 1"
+bash tools/run_pmc.sh ${TAG}_final/pmc_wgrad "bench_wgrad.py 8 1 plain"
 bash tools/run_pmc.sh ${TAG}_final/pmc_attention "bench_attention.py"
 bash tools/run_pmc.sh ${TAG}_final/pmc_conv_fp32 fp32
 bash tools/run_pmc.sh ${TAG}_final/pmc_conv_ll "bench_conv_ll.py 32 1"
 bash tools/run_pmc.sh ${TAG}_final/pmc_conv_wino "bench_conv_wino.py 32 1"
 cd /tmp && export TMPDIR=/tmp
-rocprofv3 --kernel-trace --stats -d $O/prof_train -o p --output-format csv -- python3 $R/bench.py --mode train --steps 6 --warmup 2 > /dev/null 2>&1; echo "train prof rc=$?"
-rocprofv3 --kernel-trace --stats -d $O/prof_bf16 -o p --output-format csv -- python3 $R/tools/prof_bf16_step.py 10 > /dev/null 2>&1; echo "bf16 prof rc=$?"
+timeout -k 10 400 rocprofv3 --kernel-trace --stats -d $O/prof_train -o p --output-format csv -- python3 $R/bench.py --mode train --steps 6 --warmup 2 > /dev/null 2>&1; echo "train prof rc=$?"
+timeout -k 10 400 rocprofv3 --kernel-trace --stats -d $O/prof_bf16 -o p --output-format csv -- python3 $R/tools/prof_bf16_step.py 10 > /dev/null 2>&1; echo "bf16 prof rc=$?"
 TMDIFF_BENCH_BACKEND=gloo timeout -k 10 300 python3 $R/bench.py --gpus 2 --mode train --steps 4 --warmup 2 > $O/train_2rank_gloo.json 2> /dev/null; echo "2-rank rc=$?"

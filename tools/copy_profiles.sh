@@ -4,7 +4,7 @@ TAG=${1:-r03}; R=gpurun_out/${TAG}_final
 cp gpurun_out/${TAG}_traffic.json profiles/${TAG}_bench_traffic.json
 cp gpurun_out/${TAG}_traffic/stats/p_kernel_stats.csv profiles/${TAG}_bench_kernel_stats.csv
 cp $R/prof_train/p_kernel_stats.csv profiles/${TAG}_train_step_kernel_stats.csv
-cp $R/wgrad_b8.txt profiles/${TAG}_wgrad_b8.txt; cp $R/pmc_wgrad.txt profiles/${TAG}_wgrad_pmc.txt
+cp $R/wgrad_b8.txt profiles/${TAG}_wgrad_b8.txt; cp $R/wgrad_b8_direct.txt profiles/${TAG}_wgrad_b8_direct.txt; cp $R/wgrad_b8_phases.txt profiles/${TAG}_wgrad_b8_phases.txt; cp $R/pmc_wgrad.txt profiles/${TAG}_wgrad_pmc.txt
 cp $R/conv_layers_fp32.txt profiles/${TAG}_conv_layers_fp32.txt; cp $R/conv_layers_bf16.txt profiles/${TAG}_conv_layers_bf16.txt
 cp $R/pmc_conv_fp32.txt profiles/${TAG}_conv_fp32_pmc.txt
 cp $R/attention.txt profiles/${TAG}_attention.txt; cp $R/pmc_attention.txt profiles/${TAG}_attention_pmc.txt
