@@ -215,7 +215,7 @@ def parity_check(dev):
             "what": "10-step DDPM chain (T=10 cosine) on two 8x64x64 tiles, ch 32-256, shared CPU noise: fused image of the "
                     "HIP path vs the CPU oracle, with the production kernel family forced onto this small batch "
                     "(conv3d_wf_fwd = Winograd F(4,3) with in-kernel input transform, conv3d_wino*_fwd = transform pass + "
-                    "Winograd kernel, conv3d_ll_fwd = composed Conv_0 + LL; conv3d_fwd* = direct kernels, the 8x8 level "
+                    "Winograd kernel, conv3d_ll_fwd = composed Conv_0 + LL, conv3d_wfll_fwd = the same with Winograd on top; conv3d_fwd* = direct kernels, the 8x8 level "
                     "here); budget PSNR >= 60 dB (tests/test_gpu_sampling.py hold full-width 50- and 1000-step chains of "
                     "the reference to the same on these kernels)"}
 
@@ -538,7 +538,8 @@ def main():
         # block as one strided convolution, csrc/conv3d_ll.hip) executes 48 of the 4 x 27 multiply-adds per output
         # ... and a conv3d_wino{4,2}_fwd launch (Winograd F(4,3) / F(2,3) along the band axis, csrc/conv3d_wino.hip; its
         # input-transform pass is timed apart) 54 of the 4 x 27 per four output bands / 36 of the 2 x 27 per pair
-        ref_factor = {"conv3d_ll_fwd": 108.0 / 48.0, "conv3d_wino2_fwd": 1.5, "conv3d_wino4_fwd": 2.0, "conv3d_wf_fwd": 2.0}   # F(2,3) / F(4,3)
+        ref_factor = {"conv3d_ll_fwd": 108.0 / 48.0, "conv3d_wfll_fwd": 108.0 / 24.0, "conv3d_wino2_fwd": 1.5, "conv3d_wino4_fwd": 2.0,
+                      "conv3d_wf_fwd": 2.0}   # composed LL (+ F(4,3) on top) / F(2,3) / F(4,3)
         fl3_ref = fl3 + sum(fl * (ref_factor[what] - 1.0) for (k, what), (n, ms, fl) in conv_by_entry.items()
                             if k == 3 and what in ref_factor)
         traffic, traffic_src = load_traffic()

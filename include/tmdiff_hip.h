@@ -101,6 +101,10 @@ typedef struct tmdiff_conv3d_desc {
    * mask tensor exists.  in_mask (a caller-supplied mask tensor, parity runs) must then be NULL.  fp32 entry points only. */
   uint64_t drop_seed;
   float drop_p;
+  /* != 0 (tmdiff_conv3d_wf_fwd only, even H, W % 4 == 0, a grid that does not split its input channels): y2 is written in
+   * "space to depth" form [B, 4 Cout, N, H/2, W/2], channel 4 co + 2 ph + pw holding y2[co][n][2i + ph][2j + pw] -- the input
+   * form of tmdiff_conv3d_wfll_fwd (the down blocks' Conv_0 + LL band, Hyper_unet_general.py:371-372, :389, :396). */
+  int32_t y2_s2d;
 } tmdiff_conv3d_desc;
 
 /* w [Cout, Cin/groups, k, k, k] (PyTorch layout) -> packed [g][ci][tap][co] used by the
@@ -225,6 +229,19 @@ int64_t tmdiff_conv3d_wf_blocks(const tmdiff_conv3d_desc* d);     /* workgroups 
 size_t tmdiff_conv3d_wf_splitk_workspace_bytes(const tmdiff_conv3d_desc* d);
 size_t tmdiff_conv3d_wf_workspace_bytes(const tmdiff_conv3d_desc* d);
 int tmdiff_conv3d_wf_fwd(const tmdiff_conv3d_desc* d, void* workspace, tmdiff_stream_t stream);
+/* `Conv_0` (3x3x3) of a down block and the halved Haar LL band of its output as ONE convolution (as tmdiff_conv3d_ll_fwd: same
+ * descriptor -- H, W the INPUT extents, outputs at half of them, bias multiplied by 2 * ll_scale) WITH Winograd F(4,3) along the
+ * bands on top: the LL band acts on (h, w) only, so the composed 3x4x4 stride-2 kernel keeps its three band taps -- 16 x 6 / 4 =
+ * 24 multiply-adds per output instead of 48 (and 108 for the convolution + DWT pair).  seg_x[0] is the producer's SPACE-TO-DEPTH
+ * second output (y2_s2d above: [B, 4 Cin, N, H/2, W/2]); on it the composed kernel is a stride-1 convolution with 2 x 2 of the
+ * 3 x 3 taps per virtual channel, which the kernel of tmdiff_conv3d_wf_fwd runs with a 24-step K loop.  8-band tensors, W % 8 == 0,
+ * Cout % 32 == 0; weights from tmdiff_conv3d_wfll_pack_weights (Cin x 96 x Cout floats). */
+int tmdiff_conv3d_wfll_supported(const tmdiff_conv3d_desc* d);
+size_t tmdiff_conv3d_wfll_packed_bytes(int32_t Cout, int32_t Cin);
+int tmdiff_conv3d_wfll_pack_weights(const float* w, float* packed, int32_t Cout, int32_t Cin, float ll_scale,
+                                    tmdiff_stream_t stream);
+size_t tmdiff_conv3d_wfll_splitk_workspace_bytes(const tmdiff_conv3d_desc* d);
+int tmdiff_conv3d_wfll_fwd(const tmdiff_conv3d_desc* d, float ll_scale, tmdiff_stream_t stream);
 
 /* ---- bf16 compute / fp32 accumulate (WorldView-3 inference) --------------------------
  * Same descriptor and fused prologue / epilogue as tmdiff_conv3d_fwd; activations, bias, residual and output stay

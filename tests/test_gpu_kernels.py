@@ -598,6 +598,63 @@ def test_conv3d_ll_is_conv_then_halved_ll_band(ops, case):
 
 
 @pytest.mark.parametrize("case", [
+    # B, Cin, Cout, H, W   (8 bands; H, W of the full-resolution input)
+    (2, 8, 32, 16, 32),       # whole tiles of the half-resolution output (8 x 16)
+    (1, 6, 64, 24, 40),       # ragged tiles (12 x 20 output), two channel tiles
+    (3, 16, 32, 16, 16),      # 8 x 8 output planes: pair mode, odd batch
+    (1, 64, 32, 16, 32),      # one tile: split over the input channels (whole pairs of row-parity chunks per range)
+    (4, 32, 64, 32, 32),
+])
+def test_conv3d_ll_with_winograd_along_the_bands(ops, case):
+    """tmdiff_conv3d_wfll_fwd: Conv_0 + halved LL band as one convolution with F(4,3) along the bands, on the space-to-depth
+    second output of its producer (tmdiff_conv3d_wf_fwd with y2_s2d): the producer's s2d output is its plain second output
+    rearranged (bit for bit), the composed convolution agrees with the CPU convolution + LL band (fp64), with conv3d_ll and
+    with the convolution + DWT pair; bias, residual, scale and second output."""
+    B, cin, cout, H, W = case
+    N = 8
+    torch.manual_seed(5 + cin + W)
+    # ---- the producer: a 3x3x3 convolution whose second output feeds the down block
+    xin = torch.randn(B, 2, N, H, W)                   # (one chunk of input channels: a small grid cannot split it)
+    wprod = torch.randn(cin, 2, 3, 3, 3) / (2 * 27) ** 0.5
+    sh2, sc2 = torch.randn(B, cin) * 0.3, torch.rand(B, cin) + 0.5
+    wpp = ops.pack_conv_weight_wino(cu(wprod), groups=1, mode=2, planes=6) if cin % 32 == 0 else None
+    if wpp is not None:
+        em = dict(act=True, shift=cu(sh2), scale=cu(sc2))
+        y_a, plain = ops.conv3d_wf([cu(xin)], wpp, cin, emit=em)
+        y_b, s2d = ops.conv3d_wf([cu(xin)], wpp, cin, emit=dict(em, s2d=True))
+        assert torch.equal(y_a, y_b)
+        want = plain.view(B, cin, N, H // 2, 2, W // 2, 2).permute(0, 1, 4, 6, 2, 3, 5).reshape(B, 4 * cin, N, H // 2, W // 2)
+        assert torch.equal(s2d, want), "space-to-depth second output != the plain one rearranged"
+        x = plain.cpu()
+    else:
+        x = torch.randn(B, cin, N, H, W)
+    xs = cu(x).view(B, cin, N, H // 2, 2, W // 2, 2).permute(0, 1, 4, 6, 2, 3, 5).reshape(B, 4 * cin, N, H // 2, W // 2).contiguous()
+    # ---- the composed convolution
+    w, bias = torch.randn(cout, cin, 3, 3, 3) / (cin * 27) ** 0.5, torch.randn(cout)
+    res = torch.randn(B, cout, N, H // 2, W // 2)
+    t2, c2 = torch.randn(B, cout) * 0.3, torch.rand(B, cout) + 0.5
+    full = F.conv3d(x.double(), w.double(), bias.double(), padding=1)
+    ll = (0.25 * (full[..., 0::2, 0::2] + full[..., 0::2, 1::2] + full[..., 1::2, 0::2] + full[..., 1::2, 1::2])).float()
+    wq = ops.pack_conv_weight_wfll(cu(w), 0.5)
+    before = None
+    y = ops.conv3d_wf_ll(xs, wq, cout, 0.5, bias=cu(bias))
+    assert_close(y, ll, 2e-5, 2e-6, "conv3d_wf_ll")
+    if cout % 64 == 0 and cin % 2 == 0:
+        old = ops.conv3d_ll(cu(x), ops.pack_conv_weight_ll(cu(w), 0.5), cout, 0.5, bias=cu(bias))
+        assert_close(y, old.cpu(), 1e-5, 2e-6, "conv3d_wf_ll vs conv3d_ll")
+    want = (ll + res) * 0.7071
+    v = want + t2[:, :, None, None, None]
+    want2 = v * torch.sigmoid(v) * c2[:, :, None, None, None]
+    y, y2 = ops.conv3d_wf_ll(xs, wq, cout, 0.5, bias=cu(bias), residual=cu(res), out_scale=0.7071,
+                             emit=dict(act=True, shift=cu(t2), scale=cu(c2)))
+    assert_close(y, want, 2e-5, 2e-6, "conv3d_wf_ll + residual")
+    assert_close(y2, want2, 2e-5, 2e-6, "conv3d_wf_ll second output")
+    only = ops.conv3d_wf_ll(xs, wq, cout, 0.5, bias=cu(bias), residual=cu(res), out_scale=0.7071, keep_y=False,
+                            emit=dict(act=True, shift=cu(t2), scale=cu(c2)))
+    assert torch.equal(only, y2)
+
+
+@pytest.mark.parametrize("case", [
     # B, segs, Cout, N, H, W, groups
     (2, (8,), 64, 8, 16, 16, 1),          # 64-channel tiles, whole tiles
     (1, (6,), 32, 4, 12, 20, 1),          # 32-channel tiles, ragged in t / h / w, odd chunk count

@@ -163,7 +163,7 @@ def _assert_production_kernels_ran(counts, steps):
     # + kernel -- both F(4,3))
     wino = counts["conv3d_wf_fwd"] + counts["conv3d_wino4_fwd"]
     assert wino >= 20 * steps and counts["conv3d_wf_fwd"] >= 8 * steps, dict(counts)
-    assert counts["conv3d_ll_fwd"] == 3 * steps, dict(counts)
+    assert counts["conv3d_ll_fwd"] + counts["conv3d_wfll_fwd"] == 3 * steps, dict(counts)    # (wfll: with Winograd on top)
     direct = counts["conv3d_fwd"] + counts["conv3d_fwd_staged"]
     assert direct <= 8 * steps, dict(counts)
 

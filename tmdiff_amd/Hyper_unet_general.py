@@ -345,7 +345,7 @@ class WavBEST(nn.Module):
         dev = params[0].device
         if dev.type != "cuda":
             raise RuntimeError("tmdiff_amd.WavBEST runs on the HIP kernels only: move the module to a GPU (.cuda())")
-        prep = {"key": key, "w": {}, "w_ll": {}, "w_wino": {}, "bf16": set(), "freqs": self._freqs_cpu.to(dev)}
+        prep = {"key": key, "w": {}, "w_ll": {}, "w_wfll": {}, "w_wino": {}, "bf16": set(), "freqs": self._freqs_cpu.to(dev)}
         for name, m in self.named_modules():
             if isinstance(m, nn.Conv3d) and m.in_channels > 1 and m.out_channels > 1:
                 w = m.weight.detach().float().contiguous()
@@ -368,6 +368,10 @@ class WavBEST(nn.Module):
                 m = self.get_submodule(blk + ".down.Conv_0")
                 if ops.ll_conv_supported(m.out_channels, m.in_channels, m.kernel_size[0], m.groups):
                     prep["w_ll"][blk + ".down.Conv_0"] = ops.pack_conv_weight_ll(m.weight.detach().float().contiguous(), 0.5)
+                    # ... and with Winograd along the bands on top (conv3d_wf's composed-LL mode), for the launches whose producer
+                    # can hand over its second output in space-to-depth form (_ll_s2d)
+                    if _WINOGRAD and ops._WFLL and m.out_channels % 32 == 0:
+                        prep["w_wfll"][blk + ".down.Conv_0"] = ops.pack_conv_weight_wfll(m.weight.detach().float().contiguous(), 0.5)
         shift, scale = [], []
         for name, m in self.named_modules():
             if isinstance(m, ResBlockModulateBEST):
@@ -463,16 +467,33 @@ class WavBEST(nn.Module):
             out = self._conv(P, name + ".conv21", [t1], use_bias=False, in_act=True, residual=res, **sc, **kw)
         return out if emit is not None else (out, None)
 
+    def _ll_s2d(self, P, blk, h):
+        """True when the main branch's down block `blk` runs Conv_0 + LL as conv3d_wf_ll: its weights exist, the ResBlock in
+        front ends in a conv3d_wf launch that does not split its input channels (only that epilogue writes the space-to-depth
+        form), and the composed convolution's own grid is taken by the kernel.  h: the ResBlock's input."""
+        if not _EPILOGUE_FUSE or P["w_wfll"].get(blk + ".down.Conv_0") is None:
+            return False
+        c21, c0 = blk + ".conv20.conv21", self.get_submodule(blk + ".down.Conv_0")
+        if P["w_wino"].get(c21) is None or c21 in P["bf16"] or (blk + ".conv20.conv20") in P["bf16"]:
+            return False
+        m21 = self.get_submodule(c21)
+        b, _, n, hh, ww = h.shape
+        takes, split = ops.wf_route(b, m21.in_channels, m21.out_channels, n, hh, ww, m21.groups)
+        return bool(takes and split == 1 and m21.out_channels == c0.in_channels and
+                    ops.wfll_route(b, c0.in_channels, c0.out_channels, n, hh, ww))
+
     def _conv0(self, P, name, x, pre):
         """Conv_0 of a wavelet block on SiLU(x): from the producer's second output when there is one."""
         if pre is None:
             return self._conv(P, name + ".Conv_0", [x], in_act=True)
         return self._conv(P, name + ".Conv_0", [pre], x_bf16_shape=tuple(x.shape[2:]) if pre.dtype == torch.int16 else None)
 
-    def _down(self, P, S, name, x, flag, want_high, pre=None, emit=None, fuse=False):
+    def _down(self, P, S, name, x, flag, want_high, pre=None, emit=None, fuse=False, pre_s2d=False):
         """WaveletUPorDown(down=True) (ref :369-414); /2 folded into the DWT, LL-only when the
-        caller drops the high bands.  Returns (out, out2, bands)."""
-        w_ll = None if want_high or pre is None or pre.dtype != torch.float32 else P["w_ll"].get(name + ".Conv_0")
+        caller drops the high bands.  Returns (out, out2, bands).  pre_s2d: `pre` is in space-to-depth form (_ll_s2d)."""
+        w_ll = None if want_high or pre is None or pre.dtype != torch.float32 else P["w_wfll" if pre_s2d else "w_ll"].get(name + ".Conv_0")
+        assert not pre_s2d or w_ll is not None
+        conv_ll = ops.conv3d_wf_ll if pre_s2d else ops.conv3d_ll
         hh = None if w_ll is not None else self._conv0(P, name, x, pre)
         # The reference runs the 1x1x1 Conv_2 at full resolution and keeps the halved LL band of its output (:390, :396).
         # Both are linear and act on different axes (channels / the 2x2 pixel block), and the halved LL band of a
@@ -489,10 +510,10 @@ class WavBEST(nn.Module):
             c0 = self.get_submodule(name + ".Conv_0")
             if fuse:
                 pro = self._spec(P, S, shift=None if flag else name + ".Dense_0", scale=name + ".dense1")
-                hll = ops.conv3d_ll(pre, w_ll, c0.out_channels, 0.5, bias=c0.bias.detach(), emit=pro, keep_y=False)
+                hll = conv_ll(pre, w_ll, c0.out_channels, 0.5, bias=c0.bias.detach(), emit=pro, keep_y=False)
                 out = self._conv(P, name + ".Conv_1", [hll], use_bias=False, residual=xll, **kw)
             else:
-                hll = ops.conv3d_ll(pre, w_ll, c0.out_channels, 0.5, bias=c0.bias.detach())
+                hll = conv_ll(pre, w_ll, c0.out_channels, 0.5, bias=c0.bias.detach())
                 sh = {} if flag else self._shift(P, S, name + ".Dense_0")
                 out = self._conv(P, name + ".Conv_1", [hll], use_bias=False, in_act=True, residual=xll,
                                  **self._scale(P, S, name + ".dense1"), **sh, **kw)
@@ -657,9 +678,12 @@ class WavBEST(nn.Module):
             h, hp = out if fuse_c else (out, None)
         hs = [h]
         for dn, nxt in (("down1", "down2.conv20"), ("down2", "down3.conv20"), ("down3", "middle1")):
-            h, ha = self._resblock(P, S, dn + ".conv20", [h], flag=False, pre=hp, emit=spec())
+            # Conv_0 + LL with Winograd on top: the ResBlock hands its second output over in space-to-depth form
+            sp = spec()
+            s2d = sp is not None and self._ll_s2d(P, dn, h)
+            h, ha = self._resblock(P, S, dn + ".conv20", [h], flag=False, pre=hp, emit=dict(sp, s2d=True) if s2d else sp)
             h, hp, _ = self._down(P, S, dn + ".down", h, flag=False, want_high=False, pre=ha,
-                                  emit=spec(shift=nxt + ".dense1"), fuse=fuse)
+                                  emit=spec(shift=nxt + ".dense1"), fuse=fuse, pre_s2d=s2d)
             hs.append(h)
         h, _ = self._resblock(P, S, "middle1", [hs[3]], flag=False, pre=hp)
         for lvl, upn in ((3, "up1"), (2, "up2"), (1, "up3")):

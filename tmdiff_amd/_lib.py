@@ -29,7 +29,7 @@ class Conv3dDesc(C.Structure):
         ("y2", vp), ("y2_shift", vp), ("y2_scale", vp), ("y2_shift_stride", C.c_int32), ("y2_scale_stride", C.c_int32),
         ("y2_act", C.c_int32), ("y2_bf16", C.c_int32), ("x_bf16", C.c_int32),
         ("splitk_ws", vp), ("splitk_ws_bytes", C.c_int64),
-        ("drop_seed", C.c_uint64), ("drop_p", C.c_float),
+        ("drop_seed", C.c_uint64), ("drop_p", C.c_float), ("y2_s2d", C.c_int32),
     ]
 
 
@@ -75,6 +75,11 @@ SIGNATURES = {
     "tmdiff_conv3d_wgrad_workspace_bytes": (C.c_size_t, [C.POINTER(Conv3dDesc)]),
     "tmdiff_conv3d_wgrad": (C.c_int, [C.POINTER(Conv3dDesc), vp, vp, vp, vp]),
     "tmdiff_conv3d_wgrad_bias": (C.c_int, [C.POINTER(Conv3dDesc), vp, vp, vp, vp, vp]),
+    "tmdiff_conv3d_wfll_supported": (C.c_int, [C.POINTER(Conv3dDesc)]),
+    "tmdiff_conv3d_wfll_packed_bytes": (C.c_size_t, [C.c_int32, C.c_int32]),
+    "tmdiff_conv3d_wfll_pack_weights": (C.c_int, [vp, vp, C.c_int32, C.c_int32, C.c_float, vp]),
+    "tmdiff_conv3d_wfll_splitk_workspace_bytes": (C.c_size_t, [C.POINTER(Conv3dDesc)]),
+    "tmdiff_conv3d_wfll_fwd": (C.c_int, [C.POINTER(Conv3dDesc), C.c_float, vp]),
     "tmdiff_conv3d_wgrad_wino_supported": (C.c_int, [C.POINTER(Conv3dDesc)]),
     "tmdiff_conv3d_wgrad_wino_workspace_bytes": (C.c_size_t, [C.POINTER(Conv3dDesc)]),
     "tmdiff_conv3d_wgrad_wino": (C.c_int, [C.POINTER(Conv3dDesc), vp, vp, vp, vp]),

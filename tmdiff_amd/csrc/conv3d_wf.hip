@@ -64,6 +64,7 @@ struct WfArgs {
   const float* y2_shift;
   const float* y2_scale;
   int y2_shift_stride, y2_scale_stride, y2_act;
+  int y2_s2d;                 // the second output in "space to depth" form (see epilogue_wf)
   int tiles_h, tiles_w, tiles_co;
   unsigned total_blocks;
   int vec4;
@@ -120,7 +121,14 @@ __device__ __forceinline__ void stagger_start(int cycles, unsigned first_round) 
 // row holds [0, image 0, 0, 0, image 1, 0] (20 columns: each image its own zero halo, written once and never touched again),
 // and a lane of the second image reads its operands 2 columns further right.  An 8x16 tile over one 8-column plane would be
 // half empty.
-template <int TT, int TH, int TW, bool PAIR = false>
+// LLM (`Conv_0` + halved LL band as one convolution, with Winograd along the bands on top): the input is the producer's
+// space-to-depth second output X[(c, ph, pw)][n][i][j] = x'[c][n][2i + ph][2j + pw], four virtual channels per real one at half
+// the resolution.  The composed 3x4x4 stride-2 kernel (conv3d_ll.hip) is, per virtual channel, a stride-1 convolution with
+// 2 x 2 of the 3 x 3 taps: rows {0, +1} (ph = 0) or {-1, 0} (ph = 1), columns likewise by pw.  A chunk = the two virtual
+// channels (pw = 0, 1) of one (c, ph): everything up to the V planes is the plain kernel on X; the K loop has 4 taps x 6 planes
+// = 24 steps instead of 54 (row taps by the chunk's parity = its stage, column taps by the lane's K half = pw), i.e.
+// 16 x 6 / 4 = 24 multiply-adds per output where conv3d_ll executes 48 and the convolution + DWT pair 108.
+template <int TT, int TH, int TW, bool PAIR = false, bool LLM = false>
 struct GeoF {
   static constexpr int NP = 6, MO = 4, NB = TT * MO, KC = 2, CO = 32, NS = 2;
   static constexpr int HH = TH + 2;
@@ -142,7 +150,7 @@ struct GeoF {
   static constexpr int V_ELEMS = (TT - 1) * TSTRIDE + NP * HH * PW;       // one channel
   static_assert(!SPLIT || (TSTRIDE % 32 == 16 && TSTRIDE >= NP * HH * PW), "tile stride");
   static constexpr int V_FLOATS = KC * V_ELEMS;
-  static constexpr int W_TAPS = 9 * NP;
+  static constexpr int W_TAPS = (LLM ? 4 : 9) * NP;
   static constexpr int W_FLOATS = KC * W_TAPS * CO;
   static constexpr int W_UNITS = W_FLOATS / 4;
   static constexpr int WP = (W_UNITS + 63) / 64, WK = (WP + 3) / 4;
@@ -169,12 +177,14 @@ template <bool Y, bool RES, bool Y2, bool FULL, int TT, int TH, int TW, bool PAI
 __device__ __forceinline__ void epilogue_wf(const WfArgs& a, f32x16 (&out)[8], float bias_l, float sh2_l, float sc2_l, int b, int g,
                                             int co0, int h0, int w0, int wv, int lane, long plane, float* T, float* ydst,
                                             float oscale, float sh2_m = 0.f, float sc2_m = 1.f, bool pimg_ok = true) {
+#pragma clang fp contract(off)   // (every instantiation rounds alike: without y the compiler would fuse "* scale" and "+ shift")
   constexpr int MO = 4, DEPTH = 3;
   const int l31 = lane & 31, khalf = lane >> 5, tq = lane & 7, tc = lane >> 3;
   const int hw = a.H * a.W;
   const long cbase = ((long)b * a.Cout + g * a.cout_g + co0 + tc) * plane;
-  int toff[2];
+  int toff[2], s2off[2];
   bool tok[2];
+  const long qplane = plane >> 2;
 #pragma unroll
   for (int s = 0; s < 2; ++s) {
     // the lane's four positions 4 tq .. 4 tq + 3 of sub-tile s (see the operand offsets of the kernel): band tile, row, column
@@ -184,10 +194,14 @@ __device__ __forceinline__ void epilogue_wf(const WfArgs& a, f32x16 (&out)[8], f
       const int img = (tq & 3) >> 1, w = 4 * (tq & 1);
       tok[s] = h < a.H && (img == 0 || pimg_ok);
       toff[s] = tok[s] ? img * a.Cout * (int)plane + (MO * bt) * hw + h * a.W + w : 0;
+      s2off[s] = tok[s] ? img * a.Cout * (int)plane + (h & 1) * 2 * (int)qplane + (MO * bt) * (hw >> 2) + (h >> 1) * (a.W >> 1) + (w >> 1) : 0;
     } else {
       const int w = w0 + 4 * (tq & 3);
       tok[s] = FULL || (h < a.H && w < a.W);                    // (W % 4 == 0: the four positions stand or fall together)
       toff[s] = tok[s] ? (MO * bt) * hw + h * a.W + w : 0;
+      // space-to-depth form of the second output: channel (co, ph, pw) = 4 co + 2 ph + pw at half the resolution -- the channel
+      // base is the same (4 channels of a quarter plane each); the lane's four columns are two of either column parity
+      s2off[s] = tok[s] ? (h & 1) * 2 * (int)qplane + (MO * bt) * (hw >> 2) + (h >> 1) * (a.W >> 1) + (w >> 1) : 0;
     }
   }
   float bias_t[4], sh2_t[4], sc2_t[4];
@@ -240,23 +254,31 @@ __device__ __forceinline__ void epilogue_wf(const WfArgs& a, f32x16 (&out)[8], f
           const float xa = tmdiff::silu_f(x);
           u[e] = (a.y2_act ? xa : x) * sc2_t[j];
         }
-        if (FULL || tok[s]) *reinterpret_cast<float4*>(a.y2 + o) = make_float4(u[0], u[1], u[2], u[3]);
+        if (a.y2_s2d) {
+          const long o2 = cbase + (long)(8 * j) * plane + (long)n * (hw >> 2) + s2off[s];
+          if (FULL || tok[s]) {
+            *reinterpret_cast<float2*>(a.y2 + o2) = make_float2(u[0], u[2]);
+            *reinterpret_cast<float2*>(a.y2 + o2 + qplane) = make_float2(u[1], u[3]);
+          }
+        } else if (FULL || tok[s]) {
+          *reinterpret_cast<float4*>(a.y2 + o) = make_float4(u[0], u[1], u[2], u[3]);
+        }
       }
     }
     __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
   });
 }
 
-template <int TT, int TH, int TW, bool PAIR>
+template <int TT, int TH, int TW, bool PAIR, bool LLM>
 __global__ void __launch_bounds__(256, 2) conv3d_wf_kernel(const WfArgs a) {
-  using G = GeoF<TT, TH, TW, PAIR>;
+  using G = GeoF<TT, TH, TW, PAIR, LLM>;
   constexpr int NP = G::NP, MO = G::MO, NB = G::NB, KC = G::KC, CO = G::CO, NS = G::NS, HH = G::HH, RQ = G::RQ, PW = G::PW;
   constexpr int W_TAPS = G::W_TAPS;
   __shared__ __attribute__((aligned(16))) float lds[2 * G::STAGE + G::RAW_FLOATS];
   float* const st0 = lds;
   float* const st1 = lds + G::STAGE;
   float* const raw = lds + 2 * G::STAGE;
-  static_assert(2 * G::STAGE + G::RAW_FLOATS >= 4 * 4096, "the epilogue borrows 16 KB of LDS per wave");
+  static_assert(2 * G::STAGE + G::RAW_FLOATS >= 4 * 1024, "the epilogue borrows 4 KB of LDS per wave");
 
   const int tid = threadIdx.x;
   const int lane = tid & 63, wv = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -382,8 +404,9 @@ __global__ void __launch_bounds__(256, 2) conv3d_wf_kernel(const WfArgs a) {
   // column l31 = (band tile l31 >> 4, column l31 & 15).  N = 4: wave wv owns rows 4 wv .. 4 wv + 3, sub-tile s = two rows of 16.
   // Either way sub-tile 1 lies a constant behind sub-tile 0: one base address, one ds_read2_b32 for both.
   constexpr int SUB_STEP = G::SPLIT ? PW : 2 * PW;
+  // (LLM: the K half is the column parity pw; its two column taps are V columns {+1, +2} (pw = 0) or {0, +1} (pw = 1))
   const int boff = khalf * G::V_ELEMS + (G::SPLIT ? (l31 >> 4) * G::TSTRIDE + (2 * wv) * PW + (l31 & 15) + (PAIR ? 2 * ((l31 & 15) >> 3) : 0)
-                                                  : (4 * wv + (l31 >> 4)) * PW + (l31 & 15));
+                                                  : (4 * wv + (l31 >> 4)) * PW + (l31 & 15)) + (LLM ? 1 - khalf : 0);
   const int aoff = G::V_FLOATS + khalf * W_TAPS * CO + l31;
 
   float bias_l, sh2_l, sc2_l, sh2_m = 0.f, sc2_m = 1.f;
@@ -426,10 +449,12 @@ __global__ void __launch_bounds__(256, 2) conv3d_wf_kernel(const WfArgs a) {
   // work items between the MFMAs of a chunk (slot = K-step after whose MFMAs the item is placed)
   // (no LDS-DMA is outstanding when the raw box is read: the compiler puts vmcnt(0) in front of LDS reads that a pending
   // DMA might alias)
-  constexpr int SLOT_COL0 = 0, COL_STEP = 6, SLOT_W0 = 20, SLOT_RAW0 = 26, STEP = 2;
-  static_assert(SLOT_COL0 + NTR * COL_STEP <= SLOT_W0 + 1 && SLOT_W0 + G::WK <= SLOT_RAW0 && SLOT_RAW0 + G::XK * STEP <= KSTEPS - 8,
+  // (LLM: 24 K-steps; the raw pieces go out right behind the last transform task, the weights behind them)
+  constexpr int SLOT_COL0 = 0, COL_STEP = LLM ? 4 : 6, SLOT_W0 = LLM ? 12 : 20, SLOT_RAW0 = LLM ? 14 : 26, STEP = LLM ? 1 : 2;
+  static_assert(SLOT_COL0 + NTR * COL_STEP <= SLOT_W0 + 1 && SLOT_W0 + G::WK <= SLOT_RAW0 && SLOT_RAW0 + G::XK * STEP <= KSTEPS - (LLM ? 4 : 8),
                 "work items in order, raw pieces early enough to land");
-  auto mfma_chunk = [&](const float* st, int c1, int c2, float* st_next) __attribute__((always_inline)) {
+  auto mfma_chunk = [&](auto phc, const float* st, int c1, int c2, float* st_next) __attribute__((always_inline)) {
+    constexpr int PH = decltype(phc)::value;      // LLM: row parity of this chunk's virtual channels (its row taps)
     // st: the stage of this chunk; c1 / c2: the chunks whose weights / raw box are requested now (next, next but one)
     // operands are fetched two K-steps (four MFMAs) ahead: the weights of two consecutive K-steps by ONE ds_read2_b32 (their
     // rows lie 32 floats apart), the two sub-tiles' positions by another
@@ -441,7 +466,8 @@ __global__ void __launch_bounds__(256, 2) conv3d_wf_kernel(const WfArgs a) {
     };
     auto fetch_b = [&](auto ksc) __attribute__((always_inline)) {
       constexpr int ks = decltype(ksc)::value;
-      constexpr int k = ks % NP, dh = (ks / NP) / 3, dw = (ks / NP) % 3;
+      constexpr int k = ks % NP;
+      constexpr int dh = LLM ? (ks / NP) / 2 + (PH == 0 ? 1 : 0) : (ks / NP) / 3, dw = LLM ? (ks / NP) % 2 : (ks / NP) % 3;
       constexpr int toff = (k * HH + dh) * PW + dw;
 #pragma unroll
       for (int s = 0; s < NS; ++s) bv[ks % 3][s] = st[boff + toff + s * SUB_STEP];
@@ -470,11 +496,12 @@ __global__ void __launch_bounds__(256, 2) conv3d_wf_kernel(const WfArgs a) {
     });
   };
 
+  // (LLM: chunk (c, ph) has index 2 c + ph and every range of chunks starts at an even one: stage 0 <-> ph = 0)
   for (int c = 0; c < nchunks; c += 2) {
-    mfma_chunk(st0, c + 1 < nchunks ? c + 1 : 0, c + 2 < nchunks ? c + 2 : 0, st1);
+    mfma_chunk(std::integral_constant<int, 0>{}, st0, c + 1 < nchunks ? c + 1 : 0, c + 2 < nchunks ? c + 2 : 0, st1);
     __syncthreads();
     if (c + 1 < nchunks) {
-      mfma_chunk(st1, c + 2 < nchunks ? c + 2 : 0, c + 3 < nchunks ? c + 3 : 0, st0);
+      mfma_chunk(std::integral_constant<int, 1>{}, st1, c + 2 < nchunks ? c + 2 : 0, c + 3 < nchunks ? c + 3 : 0, st0);
       __syncthreads();
     }
   }
@@ -533,7 +560,7 @@ __global__ void __launch_bounds__(256, 2) conv3d_wf_kernel(const WfArgs a) {
 #endif
 }
 
-template <int TT, int TH, int TW, bool PAIR = false>
+template <int TT, int TH, int TW, bool PAIR = false, bool LLM = false>
 int launch(WfArgs& a, hipStream_t st) {
   a.tiles_h = (a.H + TH - 1) / TH;
   a.tiles_w = PAIR ? 1 : (a.W + TW - 1) / TW;
@@ -547,7 +574,7 @@ int launch(WfArgs& a, hipStream_t st) {
   }();
   a.first_round = 512;
   a.stagger = blocks > 512 ? (int)(stagger_chunks * 2.0 * 54 * 2 * 64) : 0;
-  conv3d_wf_kernel<TT, TH, TW, PAIR><<<(unsigned)blocks, 256, 0, st>>>(a);
+  conv3d_wf_kernel<TT, TH, TW, PAIR, LLM><<<(unsigned)blocks, 256, 0, st>>>(a);
   return tmdiff::check_launch("conv3d_wf_fwd");
 }
 
@@ -576,7 +603,8 @@ long wf_tiles(const tmdiff_conv3d_desc* d) {
 
 // split-K factor for grids that cannot fill the chip (two workgroups per CU are resident): the smallest divisor of the chunk
 // count that brings the grid to 384 workgroups (as plan_conv3), at least two chunks per range; TMDIFF_SPLITK=0: never
-int wf_ksplit(const tmdiff_conv3d_desc* d) {
+// (pairs: the ranges must hold whole pairs of chunks -- the composed-LL mode, whose chunks alternate in row parity)
+int wf_ksplit(const tmdiff_conv3d_desc* d, bool pairs = false) {
   static const long target = [] {
     const char* e = getenv("TMDIFF_SPLITK");
     return e ? atol(e) : 384L;
@@ -586,7 +614,7 @@ int wf_ksplit(const tmdiff_conv3d_desc* d) {
   if (target <= 0 || tiles >= target) return 1;
   int best = 1;
   for (int s = 2; s <= nchunks / 2; ++s) {
-    if (nchunks % s) continue;
+    if (nchunks % s || (pairs && (nchunks / s) % 2)) continue;
     best = s;
     if (tiles * s >= target) break;
   }
@@ -620,7 +648,10 @@ extern "C" size_t tmdiff_conv3d_wf_workspace_bytes(const tmdiff_conv3d_desc* d) 
   return (size_t)d->B * d->Cin * d->N * d->H * d->W * sizeof(float);
 }
 
-extern "C" int tmdiff_conv3d_wf_fwd(const tmdiff_conv3d_desc* d, void* workspace, tmdiff_stream_t stream) {
+namespace {
+// llm: the composed Conv_0 + LL mode (d then describes the convolution on the space-to-depth tensor: 4 x the channels, half the
+// extents); bias_mul: factor on the bias (2 * ll_scale there, 1 otherwise)
+int wf_forward(const tmdiff_conv3d_desc* d, void* workspace, tmdiff_stream_t stream, bool llm, float bias_mul) {
   using namespace tmdiff;
   TMDIFF_REQUIRE(d != nullptr, "conv3d_wf_fwd: NULL descriptor");
   if (!wf_shape_ok(d))
@@ -651,26 +682,128 @@ extern "C" int tmdiff_conv3d_wf_fwd(const tmdiff_conv3d_desc* d, void* workspace
   a.B = d->B; a.N = d->N; a.H = d->H; a.W = d->W;
   a.Cin = d->Cin; a.Cout = d->Cout; a.groups = d->groups; a.cin_g = d->Cin / d->groups; a.cout_g = d->Cout / d->groups;
   a.x = x; a.wp = d->w_packed;
-  a.bias = d->bias; a.bias_scale = d->bias_scale;
+  a.bias = d->bias; a.bias_scale = d->bias_scale * bias_mul;
   a.residual = d->residual; a.out_scale = d->out_scale; a.y = d->y;
   a.y2 = d->y2; a.y2_shift = d->y2_shift; a.y2_scale = d->y2_scale; a.y2_act = d->y2_act;
+  a.y2_s2d = d->y2 && d->y2_s2d ? 1 : 0;
+  if (a.y2_s2d) TMDIFF_REQUIRE(d->H % 2 == 0 && d->W % 4 == 0, "conv3d_wf_fwd: the space-to-depth second output needs even H and W %% 4 == 0");
   a.y2_shift_stride = d->y2_shift_stride > 0 ? d->y2_shift_stride : (d->y2_shift_stride < 0 ? 0 : d->Cout);
   a.y2_scale_stride = d->y2_scale_stride > 0 ? d->y2_scale_stride : (d->y2_scale_stride < 0 ? 0 : d->Cout);
   a.vec4 = 1;
   a.stamps = TMDIFF_WF_STAMPS ? static_cast<unsigned long long*>(d->splitk_ws) : nullptr;
   a.ksplit = 1; a.split_chunks = a.cin_g / 2; a.part = nullptr;
   if (!TMDIFF_WF_STAMPS) {
-    const int ks = wf_ksplit(d);
+    const int ks = wf_ksplit(d, llm);
     const size_t need = (size_t)ks * d->B * d->Cout * d->N * d->H * d->W * sizeof(float);
+    if (ks > 1 && a.y2_s2d)
+      return fail(TMDIFF_E_UNSUPPORTED, "conv3d_wf_fwd: a grid that splits its input channels cannot write the space-to-depth second output");
     if (ks > 1 && d->splitk_ws && (size_t)d->splitk_ws_bytes >= need && aligned16(d->splitk_ws)) {
       a.ksplit = ks; a.split_chunks = a.cin_g / 2 / ks; a.part = static_cast<float*>(d->splitk_ws);
     }
   }
   if (wf_pair(d))
     TMDIFF_REQUIRE(((long)d->Cin + 2) * d->N * d->H * d->W < (1L << 29), "conv3d_wf_fwd: sample too large for 32-bit offsets");
-  const int rc = wf_pair(d) ? launch<2, 8, 16, true>(a, st) : (d->N == 8 ? launch<2, 8, 16>(a, st) : launch<1, 16, 16>(a, st));
+  int rc;
+  if (llm) rc = wf_pair(d) ? launch<2, 8, 16, true, true>(a, st) : launch<2, 8, 16, false, true>(a, st);
+  else rc = wf_pair(d) ? launch<2, 8, 16, true>(a, st) : (d->N == 8 ? launch<2, 8, 16>(a, st) : launch<1, 16, 16>(a, st));
   if (rc || !a.part) return rc;
   SplitKReduceArgs r{a.part, a.ksplit, d->B, d->Cout, (long)d->N * d->H * d->W, d->bias, d->bias_scale, d->residual,
                      d->out_scale, d->y, d->y2, d->y2_shift, d->y2_scale, a.y2_shift_stride, a.y2_scale_stride, d->y2_act};
   return launch_splitk_reduce(r, st);
+}
+
+// the descriptor of the composed-LL convolution as the kernel sees it: the space-to-depth input has 4 x the channels at half
+// the extents; outputs at the halved extents
+bool wfll_desc(const tmdiff_conv3d_desc* d, tmdiff_conv3d_desc* e) {
+  if (!d || d->ksize != 3 || d->groups != 1 || d->nseg != 1 || d->N != 8 || d->H <= 0 || d->W <= 0 || d->H % 2 || d->W % 8) return false;
+  if (d->in_shift || d->in_scale || d->in_act || d->in_mask || d->drop_p > 0.f || d->x_bf16 || d->y2_bf16 || d->y2_s2d) return false;
+  if (d->Cin <= 0 || d->Cout <= 0 || d->Cout % 32 || d->seg_c[0] != d->Cin) return false;
+  *e = *d;
+  e->H = d->H / 2; e->W = d->W / 2; e->Cin = 4 * d->Cin; e->seg_c[0] = 4 * d->Cin;
+  return wf_shape_ok(e);
+}
+
+// F(4,3) weight transform G (6 x 3), as WM<6> of conv3d_wino.hip
+__constant__ float kG6[6][3] = {{0.25f, 0.f, 0.f},           {-1.f / 6.f, -1.f / 6.f, -1.f / 6.f}, {-1.f / 6.f, 1.f / 6.f, -1.f / 6.f},
+                                {1.f / 24.f, 1.f / 12.f, 1.f / 6.f}, {1.f / 24.f, -1.f / 12.f, 1.f / 6.f}, {0.f, 0.f, 1.f}};
+
+// One thread = one (co, ci) weight row (27 taps): the composed 3 x 4 x 4 kernel W'[dn][a][b] = s * sum_{P,Q in {0,1}} W[dn][a-P][b-Q]
+// (conv3d_ll.hip), its four (a, b) taps per (row parity ph, column parity pw) -- a = 1 + 2 i (ph = 0) or 2 i (ph = 1), b likewise
+// -- and G along dn:  packed[ci][ph][pw][i * 2 + j][k][co].
+__global__ void __launch_bounds__(256) wfll_pack_kernel(const float* __restrict__ w, float* __restrict__ packed, int Cout, int Cin, float s) {
+  const long r = blockIdx.x * 256L + threadIdx.x;
+  if (r >= (long)Cout * Cin) return;
+  const int co = (int)(r % Cout), ci = (int)(r / Cout);
+  const float* wk = w + ((long)co * Cin + ci) * 27;
+  float t[27];
+#pragma unroll
+  for (int i = 0; i < 27; ++i) t[i] = wk[i];
+#pragma unroll
+  for (int ph = 0; ph < 2; ++ph)
+#pragma unroll
+    for (int pw = 0; pw < 2; ++pw)
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+          const int a4 = ph == 0 ? 1 + 2 * i : 2 * i, b4 = pw == 0 ? 1 + 2 * j : 2 * j;
+          float c3[3];
+#pragma unroll
+          for (int dn = 0; dn < 3; ++dn) {
+            float acc = 0.f;
+#pragma unroll
+            for (int P = 0; P < 2; ++P)
+#pragma unroll
+              for (int Q = 0; Q < 2; ++Q) {
+                const int dh = a4 - P, dw = b4 - Q;
+                if (dh >= 0 && dh < 3 && dw >= 0 && dw < 3) acc += t[dn * 9 + dh * 3 + dw];
+              }
+            c3[dn] = s * acc;
+          }
+#pragma unroll
+          for (int k = 0; k < 6; ++k)
+            packed[(((((long)ci * 2 + ph) * 2 + pw) * 4 + i * 2 + j) * 6 + k) * Cout + co] = kG6[k][0] * c3[0] + kG6[k][1] * c3[1] + kG6[k][2] * c3[2];
+        }
+}
+
+}  // namespace
+
+extern "C" int tmdiff_conv3d_wf_fwd(const tmdiff_conv3d_desc* d, void* workspace, tmdiff_stream_t stream) {
+  return wf_forward(d, workspace, stream, false, 1.f);
+}
+
+/* ---- Conv_0 + halved LL band as one convolution WITH Winograd along the bands (see GeoF, LLM) ------------------------------ */
+extern "C" int tmdiff_conv3d_wfll_supported(const tmdiff_conv3d_desc* d) {
+  tmdiff_conv3d_desc e;
+  return wfll_desc(d, &e) ? 1 : 0;
+}
+
+extern "C" size_t tmdiff_conv3d_wfll_packed_bytes(int32_t Cout, int32_t Cin) {
+  if (Cout <= 0 || Cin <= 0 || Cout % 32) return 0;
+  return (size_t)Cin * 96 * Cout * sizeof(float);
+}
+
+extern "C" int tmdiff_conv3d_wfll_pack_weights(const float* w, float* packed, int32_t Cout, int32_t Cin, float ll_scale,
+                                               tmdiff_stream_t stream) {
+  using namespace tmdiff;
+  TMDIFF_REQUIRE(w && packed && aligned16(packed), "conv3d_wfll_pack_weights: NULL / unaligned pointer");
+  TMDIFF_REQUIRE(Cout > 0 && Cin > 0 && Cout % 32 == 0, "conv3d_wfll_pack_weights: Cout=%d (multiple of 32) Cin=%d", Cout, Cin);
+  const long rows = (long)Cout * Cin;
+  wfll_pack_kernel<<<(unsigned)((rows + 255) / 256), 256, 0, as_stream(stream)>>>(w, packed, Cout, Cin, ll_scale * 0.5f);
+  return check_launch("conv3d_wfll_pack_weights");
+}
+
+extern "C" size_t tmdiff_conv3d_wfll_splitk_workspace_bytes(const tmdiff_conv3d_desc* d) {
+  tmdiff_conv3d_desc e;
+  if (!wfll_desc(d, &e) || d->B <= 0) return 0;
+  const int ks = wf_ksplit(&e, true);
+  return ks > 1 ? (size_t)ks * e.B * e.Cout * e.N * e.H * e.W * sizeof(float) : 0;
+}
+
+extern "C" int tmdiff_conv3d_wfll_fwd(const tmdiff_conv3d_desc* d, float ll_scale, tmdiff_stream_t stream) {
+  using namespace tmdiff;
+  tmdiff_conv3d_desc e;
+  if (!wfll_desc(d, &e))
+    return fail(TMDIFF_E_UNSUPPORTED, "conv3d_wfll_fwd: one plain fp32 space-to-depth input, 3x3x3, groups 1, 8 bands, even H, W %% 8 == 0, Cout %% 32 == 0");
+  return wf_forward(&e, nullptr, stream, true, 2.f * ll_scale);
 }

@@ -187,13 +187,15 @@ def pack_conv_weight_bf16(w, groups=1):
 def make_conv_desc(segs, w_packed, cout, ksize, y, groups=1, bias=None, bias_scale=1.0, in_shift=None, in_scale=None,
                    shift_stride=0, scale_stride=0, in_act=False, in_mask=None, residual=None, out_scale=1.0,
                    y2=None, y2_shift=None, y2_scale=None, y2_shift_stride=0, y2_scale_stride=0, y2_act=False,
-                   x_bf16_shape=None, drop=None, out_div=1):
+                   x_bf16_shape=None, drop=None, out_div=1, y2_s2d=False, x_s2d=False):
     """Fill a tmdiff_conv3d_desc.  `segs` = list of 1..3 tensors [B, c_i, N, H, W] (concat-free input).
     in_shift / in_scale may be tensors or raw (ptr) ints into a projection bank.  y may be None when only the second
     output y2 = act2(y + y2_shift) * y2_scale (the consumer's prologue, same pointer conventions) is wanted.
     A y2 of dtype int16 is written as bf16 units [B, Cout/8, N*H*W, 8]; x_bf16_shape = (N, H, W) says that segs[0] is
     such a tensor (bf16 entry point only).  drop = (seed, p): in-kernel dropout of the prologue output (no mask tensor).
-    out_div = 2: outputs / residual at half the H and W of the input (tmdiff_conv3d_ll_fwd)."""
+    out_div = 2: outputs / residual at half the H and W of the input (tmdiff_conv3d_ll_fwd).  y2_s2d: y2 in space-to-depth
+    form [B, 4 Cout, N, H/2, W/2] (tmdiff_conv3d_wf_fwd only); x_s2d: segs[0] is such a tensor and the descriptor is that of
+    the convolution on the full-resolution tensor it stands for (tmdiff_conv3d_wfll_fwd)."""
     d = Conv3dDesc()
     if drop is not None:
         if in_mask is not None:
@@ -210,6 +212,15 @@ def make_conv_desc(segs, w_packed, cout, ksize, y, groups=1, bias=None, bias_sca
         d.Cin = xp.shape[1] * 8
         d.Cout, d.groups, d.ksize, d.nseg = cout, groups, ksize, 1
         d.seg_c[0], d.seg_x[0], d.x_bf16 = d.Cin, xp.data_ptr(), 1
+    elif x_s2d:
+        xs = segs[0]
+        if len(segs) != 1 or xs.dim() != 5 or xs.shape[1] % 4:
+            raise ValueError("conv3d: a space-to-depth input is one tensor [B, 4 Cin, N, H/2, W/2]")
+        b, c4, n, h, w = xs.shape
+        h, w = 2 * h, 2 * w
+        d.B, d.N, d.H, d.W = b, n, h, w
+        d.Cin, d.Cout, d.groups, d.ksize, d.nseg = c4 // 4, cout, groups, ksize, 1
+        d.seg_c[0], d.seg_x[0] = c4 // 4, _chk(xs, "segment 0")
     else:
         b, _, n, h, w = segs[0].shape
         d.B, d.N, d.H, d.W = b, n, h, w
@@ -237,8 +248,9 @@ def make_conv_desc(segs, w_packed, cout, ksize, y, groups=1, bias=None, bias_sca
     d.out_scale = out_scale
     y2_packed = y2 is not None and y2.dtype == torch.int16
     for t, nm in ((y, "y"), (None if y2_packed else y2, "y2")):
-        if t is not None and tuple(t.shape) != oshape:
-            raise ValueError(f"conv3d: {nm} shape {tuple(t.shape)} != {oshape}")
+        want = (b, 4 * cout, n, h // (2 * out_div), w // (2 * out_div)) if (y2_s2d and nm == "y2") else oshape
+        if t is not None and tuple(t.shape) != want:
+            raise ValueError(f"conv3d: {nm} shape {tuple(t.shape)} != {want}")
     if y2_packed and (tuple(y2.shape) != (b, cout // 8, n * h * w, 8) or not (y2.is_cuda and y2.is_contiguous())):
         raise ValueError(f"conv3d: packed y2 shape {tuple(y2.shape)} != {(b, cout // 8, n * h * w, 8)}")
     if y is None and y2 is None:
@@ -250,6 +262,7 @@ def make_conv_desc(segs, w_packed, cout, ksize, y, groups=1, bias=None, bias_sca
     d.y2_shift_stride, d.y2_scale_stride = y2_shift_stride, y2_scale_stride
     d.y2_act = 1 if y2_act else 0
     d.y2_bf16 = 1 if y2_packed else 0
+    d.y2_s2d = 1 if (y2_s2d and y2 is not None) else 0
     return d
 
 
@@ -488,18 +501,11 @@ _WF_PAIR = os.environ.get("TMDIFF_WF_PAIR", "1") != "0"          # experiments: 
 _WF_SPLITK = os.environ.get("TMDIFF_WF_SPLITK", "1") != "0"      # experiments: "0" = small grids go to the fallback kernels
 
 
-def conv3d_wf(segs, w_packed, cout, emit=None, keep_y=True, fallback=None, groups=1, w_packed_fn=None, xp_out=None, **kw):
-    """conv3d(segs, ...) (fp32, 3x3x3) through the Winograd F(4,3)-along-the-bands kernel that transforms its input INSIDE the
-    kernel (csrc/conv3d_wf.hip; 8- or 4-band tensors, the whole band axis in one workgroup): no transformed copy of the input,
-    no transform pass -- an input that is one plain tensor is read as it stands, any other (prologue, segments, dropout) goes
-    through one elementwise prologue pass first (its output lands in xp_out when given: the finetune path keeps it for the
-    weight gradient).  Same keyword arguments and return convention as conv3d_wino; w_packed / w_packed_fn() = the weights
-    from pack_conv_weight_wino(w, groups, mode | 2, planes=6).  fallback() runs instead when the shape is not taken or the
-    grid is too small for a kernel without split-K."""
-    b, _, n, h, w = segs[0].shape
-    dev = segs[0].device
+def wf_route(b, cin, cout, n, h, w, groups=1, masked=False):
+    """(taken, split): whether conv3d_wf runs a convolution of these extents itself (else its fallback does) and into how many
+    ranges it splits the input channels (1 = no split-K).  The rules of csrc/conv3d_wf.hip (tmdiff_conv3d_wf_blocks) plus the
+    host's: grids below _WINO_MIN_BLOCKS workgroups and planes that leave much of every 8 x 16 tile empty go to the fallback."""
     cg = cout // groups
-    cin = sum(s_.shape[1] for s_ in segs)
     th = 8 if n == 8 else 16
     # (8 bands x 8 columns: two images side by side in one 8 x 16 tile -- the kernel's pair mode)
     pair = _WF_PAIR and n == 8 and w == 8
@@ -515,24 +521,44 @@ def conv3d_wf(segs, w_packed, cout, emit=None, keep_y=True, fallback=None, group
                 split = s_
                 if tiles * s_ >= 384:
                     break
-    blocks = tiles * (split if _WF_SPLITK else 1)
-    ok = _WF and n in (4, 8) and w % 4 == 0 and cg % 32 == 0 and (cin // groups) % 2 == 0 and kw.get("in_mask") is None
+    if not _WF_SPLITK:
+        split = 1
+    blocks = tiles * split
+    ok = _WF and n in (4, 8) and w % 4 == 0 and cg % 32 == 0 and (cin // groups) % 2 == 0 and not masked
     # (tiles of th x 16 positions: a plane that leaves much of every tile empty goes to the fallback)
     fill = (h * w) / float(((h + th - 1) // th) * th * (8 if pair else ((w + 15) // 16) * 16))
     if pair:
         fill *= b / (2.0 * ((b + 1) // 2))        # (an odd batch leaves the last pair's second half empty: B = 1 is half a tile)
     if n == 8 and w == 8 and not pair:
         fill = 0.0
-    if fallback is not None and (not ok or blocks < _WINO_MIN_BLOCKS or fill < _WF_MIN_FILL):
+    return bool(ok and blocks >= _WINO_MIN_BLOCKS and fill >= _WF_MIN_FILL), split
+
+
+def conv3d_wf(segs, w_packed, cout, emit=None, keep_y=True, fallback=None, groups=1, w_packed_fn=None, xp_out=None, **kw):
+    """conv3d(segs, ...) (fp32, 3x3x3) through the Winograd F(4,3)-along-the-bands kernel that transforms its input INSIDE the
+    kernel (csrc/conv3d_wf.hip; 8- or 4-band tensors, the whole band axis in one workgroup): no transformed copy of the input,
+    no transform pass -- an input that is one plain tensor is read as it stands, any other (prologue, segments, dropout) goes
+    through one elementwise prologue pass first (its output lands in xp_out when given: the finetune path keeps it for the
+    weight gradient).  Same keyword arguments and return convention as conv3d_wino; w_packed / w_packed_fn() = the weights
+    from pack_conv_weight_wino(w, groups, mode | 2, planes=6).  fallback() runs instead when the shape is not taken or the
+    grid is too small for a kernel without split-K."""
+    b, _, n, h, w = segs[0].shape
+    dev = segs[0].device
+    cin = sum(s_.shape[1] for s_ in segs)
+    s2d = bool(emit is not None and emit.get("s2d"))
+    takes, split = wf_route(b, cin, cout, n, h, w, groups, kw.get("in_mask") is not None)
+    if s2d and ((fallback is not None and not takes) or split > 1 or h % 2 or w % 4):
+        raise ValueError("conv3d_wf: this launch cannot write a space-to-depth second output (ask wf_route first)")
+    if fallback is not None and not takes:
         return fallback()            # unsupported extents, or a grid too small even with its input channels split
     if w_packed is None:
         w_packed = w_packed_fn()
     y = torch.empty(b, cout, n, h, w, device=dev, dtype=torch.float32) if keep_y else None
     y2 = None
     if emit is not None:
-        y2 = torch.empty(b, cout, n, h, w, device=dev, dtype=torch.float32)
+        y2 = torch.empty((b, 4 * cout, n, h // 2, w // 2) if s2d else (b, cout, n, h, w), device=dev, dtype=torch.float32)
         kw = dict(kw, y2_act=emit.get("act", False), y2_shift=emit.get("shift"), y2_scale=emit.get("scale"),
-                  y2_shift_stride=emit.get("shift_stride", 0), y2_scale_stride=emit.get("scale_stride", 0))
+                  y2_shift_stride=emit.get("shift_stride", 0), y2_scale_stride=emit.get("scale_stride", 0), y2_s2d=s2d)
     elif y is None:
         raise ValueError("conv3d_wf: keep_y=False needs emit=")
     d = make_conv_desc(segs, w_packed, cout, 3, y, y2=y2, groups=groups, **kw)
@@ -615,6 +641,63 @@ def conv3d_ll(x, w_packed, cout, ll_scale=0.5, emit=None, keep_y=True, **kw):
     e1.record()
     # EXECUTED flops: 48 multiply-adds per (ci, co, output position) -- the pair it replaces would execute 4 x 27
     TIMER.records.append((e0, e1, 2.0 * b * cout * d.Cin * 48 * n * (h // 2) * (w // 2), 3, "conv3d_ll_fwd", _tag(d)))
+    return ret
+
+
+_WFLL = os.environ.get("TMDIFF_WFLL", "1") != "0"    # experiments: "0" = the composed Conv_0 + LL convolution stays on conv3d_ll
+
+
+def pack_conv_weight_wfll(w, ll_scale=0.5):
+    """Weights of conv3d_wf_ll: the composed 3x4x4 kernel of conv3d_ll split by row / column parity (2 x 2 taps per virtual
+    channel of the space-to-depth input) and transformed along the bands (F(4,3)): [Cin, 2, 2, 4, 6, Cout] floats."""
+    cout, cin = w.shape[0], w.shape[1]
+    out = torch.empty(cin * 96 * cout, device=w.device, dtype=torch.float32)
+    check(lib.tmdiff_conv3d_wfll_pack_weights(_chk(w.detach(), "w"), out.data_ptr(), cout, cin, float(ll_scale), stream_ptr()),
+          "conv3d_wfll_pack_weights")
+    return out
+
+
+def wfll_route(b, cin, cout, n, h, w):
+    """True when conv3d_wf_ll takes the composed Conv_0 + LL convolution of a [b, cin, n, h, w] input (h, w: full resolution)."""
+    if not (_WFLL and n == 8 and h % 2 == 0 and w % 8 == 0 and cout % 32 == 0):
+        return False
+    takes, _ = wf_route(b, 4 * cin, cout, n, h // 2, w // 2)
+    return takes
+
+
+def conv3d_wf_ll(x_s2d, w_packed, cout, ll_scale=0.5, emit=None, keep_y=True, **kw):
+    """conv3d_ll (Conv_0 + halved LL band as one convolution) with Winograd F(4,3) along the bands on top
+    (tmdiff_conv3d_wfll_fwd): x_s2d is the producer's space-to-depth second output [B, 4 Cin, N, H/2, W/2]
+    (conv3d_wf(..., emit=dict(..., s2d=True))), w_packed from pack_conv_weight_wfll; result and conventions as conv3d_ll."""
+    b, c4, n, h2, w2 = x_s2d.shape
+    dev = x_s2d.device
+    oshape = (b, cout, n, h2, w2)
+    y = torch.empty(oshape, device=dev, dtype=torch.float32) if keep_y else None
+    y2 = None
+    if emit is not None:
+        y2 = torch.empty(oshape, device=dev, dtype=torch.float32)
+        kw = dict(kw, y2_act=emit.get("act", False), y2_shift=emit.get("shift"), y2_scale=emit.get("scale"),
+                  y2_shift_stride=emit.get("shift_stride", 0), y2_scale_stride=emit.get("scale_stride", 0))
+    elif y is None:
+        raise ValueError("conv3d_wf_ll: keep_y=False needs emit=")
+    d = make_conv_desc([x_s2d], w_packed, cout, 3, y, y2=y2, out_div=2, x_s2d=True, **kw)
+    if not lib.tmdiff_conv3d_wfll_supported(C.byref(d)):
+        raise ValueError("conv3d_wf_ll: shape not supported")
+    nsk = lib.tmdiff_conv3d_wfll_splitk_workspace_bytes(C.byref(d)) if _WF_SPLITK else 0
+    if nsk:
+        d.splitk_ws, d.splitk_ws_bytes = _workspace(dev, nsk, "splitk").data_ptr(), nsk
+    ret = y if y2 is None else ((y, y2) if y is not None else y2)
+    # EXECUTED flops: 16 taps x 6 planes per tile of four bands = 24 multiply-adds per (ci, co, output position)
+    fl = 2.0 * b * cout * d.Cin * 24 * n * h2 * w2
+    _count("conv3d_wfll_fwd", fl)
+    if TIMER is None:
+        check(lib.tmdiff_conv3d_wfll_fwd(C.byref(d), float(ll_scale), stream_ptr()), "conv3d_wfll_fwd")
+        return ret
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    check(lib.tmdiff_conv3d_wfll_fwd(C.byref(d), float(ll_scale), stream_ptr()), "conv3d_wfll_fwd")
+    e1.record()
+    TIMER.records.append((e0, e1, fl, 3, "conv3d_wfll_fwd", _tag(d)))
     return ret
 
 

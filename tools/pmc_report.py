@@ -22,7 +22,7 @@ main = load(sys.argv[1])
 fetch = load(sys.argv[2]) if len(sys.argv) > 2 else {}
 write = load(sys.argv[3]) if len(sys.argv) > 3 else {}
 import re
-KEY = re.compile(r"(conv3d_\w+_kernel|wino_input_kernel|conv1_\w+_kernel|pack_x_bf16_kernel|prologue_\w+_kernel|wgrad_reduce_kernel|splitk_reduce_kernel|attn_\w+|flash\w*)")
+KEY = re.compile(r"(conv3d_\w+_kernel|ww_\w+_kernel|wino_input_kernel|conv1_\w+_kernel|pack_x_bf16_kernel|prologue_\w+_kernel|wgrad_reduce_kernel|splitk_reduce_kernel|attn_\w+|flash\w*)")
 fl = [e for e in fetch.values() if KEY.search(e["name"])]
 wl = [e for e in write.values() if KEY.search(e["name"])]
 i = 0
