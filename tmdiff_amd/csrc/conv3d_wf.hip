@@ -601,13 +601,13 @@ long wf_tiles(const tmdiff_conv3d_desc* d) {
   return units * d->groups * ((d->H + th - 1) / th) * (d->Cout / d->groups / 32);
 }
 
-// split-K factor for grids that cannot fill the chip (two workgroups per CU are resident): the smallest divisor of the chunk
-// count that brings the grid to 384 workgroups (as plan_conv3), at least two chunks per range; TMDIFF_SPLITK=0: never
+// split-K factor for grids that cannot fill the chip: the smallest divisor of the chunk count that brings the grid to 256
+// workgroups (TMDIFF_SPLITK=<n>: to n), at least two chunks per range; TMDIFF_SPLITK=0: never
 // (pairs: the ranges must hold whole pairs of chunks -- the composed-LL mode, whose chunks alternate in row parity)
 int wf_ksplit(const tmdiff_conv3d_desc* d, bool pairs = false) {
   static const long target = [] {
     const char* e = getenv("TMDIFF_SPLITK");
-    return e ? atol(e) : 384L;
+    return e ? atol(e) : 256L;      // (one workgroup per CU unsplit beats two halves + a reduction: 384 cost 2 % of the finetune step)
   }();
   const long tiles = wf_tiles(d);
   const int nchunks = d->Cin / d->groups / 2;

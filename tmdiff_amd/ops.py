@@ -498,6 +498,7 @@ def conv3d_wino(segs, w_packed, cout, emit=None, keep_y=True, fallback=None, gro
 _WF = os.environ.get("TMDIFF_WF", "1") != "0"    # experiments: "0" = never the in-kernel-transform Winograd kernel (conv3d_wf)
 _WF_MIN_FILL = float(os.environ.get("TMDIFF_WF_MIN_FILL", "0.7"))
 _WF_PAIR = os.environ.get("TMDIFF_WF_PAIR", "1") != "0"          # experiments: "0" = 8-column planes go to the fallback kernels
+_WF_SPLIT_TARGET = int(os.environ.get("TMDIFF_SPLITK", "256") or 0)   # as the library reads it (csrc/conv3d_wf.hip, wf_ksplit)
 _WF_SPLITK = os.environ.get("TMDIFF_WF_SPLITK", "1") != "0"      # experiments: "0" = small grids go to the fallback kernels
 
 
@@ -511,15 +512,15 @@ def wf_route(b, cin, cout, n, h, w, groups=1, masked=False):
     pair = _WF_PAIR and n == 8 and w == 8
     units = (b + 1) // 2 if pair else b * ((w + 15) // 16)
     tiles = units * groups * ((h + th - 1) // th) * (cg // 32) if cg % 32 == 0 else 0
-    # small grids split their input channels over workgroups (the smallest divisor of the chunk count that reaches 384
+    # small grids split their input channels over workgroups (the smallest divisor of the chunk count that reaches 256
     # workgroups, at least two chunks per range: tmdiff_conv3d_wf_blocks) -- single images, the deep levels of a local batch
     nchunks = (cin // groups) // 2
     split = 1
-    if 0 < tiles < 384:
+    if 0 < tiles < _WF_SPLIT_TARGET:
         for s_ in range(2, nchunks // 2 + 1):
             if nchunks % s_ == 0:
                 split = s_
-                if tiles * s_ >= 384:
+                if tiles * s_ >= _WF_SPLIT_TARGET:
                     break
     if not _WF_SPLITK:
         split = 1

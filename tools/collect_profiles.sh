@@ -2,9 +2,11 @@
 # collect_profiles.sh [TAG]: everything profiles/ holds for a round, in one GPU call (~4 min).  Outputs land in
 # gpurun_out/${TAG}_final/ (scratch); copy the summaries into profiles/ afterwards (tools/README.md).
 R=$PWD; TAG=${1:-r03}; O=$R/gpurun_out/${TAG}_final; mkdir -p $O
+# (the PMC traffic first: bench.py reads profiles/${TAG}_bench_traffic.json back into roofline.traffic and marks it stale when it
+#  was collected from other sources)
+bash tools/bench_traffic.sh $TAG > $O/traffic.log 2>&1; echo "traffic rc=$?"
 python3 bench.py --steps 20 --warmup 3 > $O/bench_line.json 2> $O/bench.err; echo "bench rc=$?"
 python3 bench.py --mode train --steps 10 --warmup 3 > $O/bench_train_line.json 2>> $O/bench.err; echo "train rc=$?"
-bash tools/bench_traffic.sh $TAG > $O/traffic.log 2>&1; echo "traffic rc=$?"
 python3 tools/bench_configs.py c1 c3 c4 2>&1 | grep config > $O/configs.txt
 python3 tools/bench_attention.py 2>&1 | grep -v amdgpu > $O/attention.txt
 python3 tools/bench_hbm_kernels.py 2>&1 | grep -v amdgpu > $O/hbm_kernels.txt
