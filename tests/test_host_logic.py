@@ -358,3 +358,38 @@ def test_winograd_transform_choice_and_sizes():
     assert lib.tmdiff_conv3d_wino_packed_bytes(48, 32, 1, 6) == 0                          # Cout / groups not a multiple of 32
     assert lib.tmdiff_conv3d_wino_packed_bytes(64, 32, 1, 5) == 0                          # planes is 4 or 6
     assert lib.tmdiff_conv3d_ll_packed_bytes(64, 32) == 32 * 48 * 64 * 4
+
+
+def test_kernel_routing_rules_and_support_queries():
+    """Host-side routing of the round-3 kernels (no GPU): which launches conv3d_wf takes itself and how it splits its input
+    channels (the benchmark's shapes), when the composed Conv_0 + LL convolution runs with Winograd on top, the packed sizes of
+    its weights, and the support queries of the Winograd-domain weight gradient."""
+    import ctypes as C
+    from tmdiff_amd import _lib, ops
+    L = _lib.lib
+    # benchmark batch (B = 32): every level is taken unsplit or with a split that still fills the chip
+    assert ops.wf_route(32, 64, 64, 8, 64, 64) == (True, 1)
+    assert ops.wf_route(32, 256, 256, 8, 16, 16) == (True, 1)                 # 512 tiles
+    taken, split = ops.wf_route(32, 256, 256, 8, 8, 8)                        # pair mode: 16 pairs x 8 channel tiles = 128
+    assert taken and split == 2
+    assert ops.wf_route(32, 64, 64, 8, 16, 16)[1] == 2                        # 128 tiles of a 64-channel layer
+    # a single image at the 8x8 level is half a pair: the fallback kernels; odd band counts and masks too
+    assert not ops.wf_route(1, 256, 256, 8, 8, 8)[0]
+    assert not ops.wf_route(32, 64, 64, 6, 64, 64)[0] and not ops.wf_route(32, 64, 64, 8, 64, 64, masked=True)[0]
+    # composed Conv_0 + LL with Winograd on top: 8 bands, W % 8 == 0, Cout % 32 == 0
+    assert ops.wfll_route(32, 64, 64, 8, 64, 64) and ops.wfll_route(32, 256, 256, 8, 16, 16)
+    assert not ops.wfll_route(32, 64, 64, 4, 64, 64) and not ops.wfll_route(32, 64, 48, 8, 64, 64)
+    assert L.tmdiff_conv3d_wfll_packed_bytes(64, 32) == 32 * 96 * 64 * 4 and L.tmdiff_conv3d_wfll_packed_bytes(48, 32) == 0
+    # Winograd-domain weight gradient: N % 4 == 0, W % 4 == 0, 3x3x3
+    d = _lib.Conv3dDesc()
+    d.B, d.N, d.H, d.W, d.Cin, d.Cout, d.groups, d.ksize, d.nseg = 8, 8, 64, 64, 64, 64, 1, 3, 1
+    d.seg_c[0] = 64
+    assert L.tmdiff_conv3d_wgrad_wino_supported(C.byref(d)) == 1
+    ws = L.tmdiff_conv3d_wgrad_wino_workspace_bytes(C.byref(d))
+    xh = 6 * 16 * 66 * 66 * 64 * 4                    # x^: six planes x (b, tile) x padded plane x channels
+    gh = 6 * 16 * 64 * 64 * 64 * 4
+    assert ws > xh + gh and ws < 2 * (xh + gh)
+    for field, bad in (("N", 6), ("W", 62), ("ksize", 1), ("groups", 2)):
+        e = _lib.Conv3dDesc.from_buffer_copy(d)
+        setattr(e, field, bad)
+        assert L.tmdiff_conv3d_wgrad_wino_supported(C.byref(e)) == 0, field
