@@ -654,6 +654,26 @@ def test_conv3d_ll_with_winograd_along_the_bands(ops, case):
     assert torch.equal(only, y2)
 
 
+@pytest.mark.parametrize("shape", [(3, 8, 8), (2, 12, 20), (4, 16, 8)])
+def test_space_to_depth_second_output_in_every_tile_mode(ops, shape):
+    """desc.y2_s2d of tmdiff_conv3d_wf_fwd: pair mode (8-column planes, odd batch), ragged tiles -- always the plain second
+    output rearranged, bit for bit, and the first output untouched."""
+    B, H, W = shape
+    torch.manual_seed(B + H + W)
+    x, w = torch.randn(B, 2, 8, H, W), torch.randn(32, 2, 3, 3, 3) / 54 ** 0.5
+    res = torch.randn(B, 32, 8, H, W)
+    sh2, sc2 = torch.randn(B, 32) * 0.3, torch.rand(B, 32) + 0.5
+    wp = ops.pack_conv_weight_wino(cu(w), groups=1, mode=2, planes=6)
+    em = dict(act=True, shift=cu(sh2), scale=cu(sc2))
+    y_a, plain = ops.conv3d_wf([cu(x)], wp, 32, emit=em, residual=cu(res), out_scale=0.5)
+    y_b, s2d = ops.conv3d_wf([cu(x)], wp, 32, emit=dict(em, s2d=True), residual=cu(res), out_scale=0.5)
+    assert torch.equal(y_a, y_b)
+    want = plain.view(B, 32, 8, H // 2, 2, W // 2, 2).permute(0, 1, 4, 6, 2, 3, 5).reshape(B, 128, 8, H // 2, W // 2)
+    assert torch.equal(s2d, want)
+    only = ops.conv3d_wf([cu(x)], wp, 32, emit=dict(em, s2d=True), residual=cu(res), out_scale=0.5, keep_y=False)
+    assert torch.equal(only, s2d)
+
+
 @pytest.mark.parametrize("case", [
     # B, segs, Cout, N, H, W, groups
     (2, (8,), 64, 8, 16, 16, 1),          # 64-channel tiles, whole tiles

@@ -143,15 +143,7 @@ __global__ void __launch_bounds__(256) prologue_apply_kernel(const ApplyArgs a) 
   }
 }
 
-__device__ const float kZeroWord = 0.f;  // DMA source of zero padding / out-of-range channels
-
-__device__ __forceinline__ void dma_word(const float* src, float* dst) {
-#if defined(__HIP_DEVICE_COMPILE__)  // the builtin exists in the device pass only
-  __builtin_amdgcn_global_load_lds(src, dst, 4, 0, 0);  // 64 lanes x 4 bytes -> dst + lane*4 (dst wave-uniform)
-#endif
-}
-
-// The same through a buffer descriptor (round 3, as conv3d_wf.hip): base + size in scalar registers, the per-lane address
+// One dword per lane by LDS-DMA through a buffer descriptor (as conv3d_wf.hip): base + size in scalar registers, the per-lane address
 // one 32-bit byte offset; an offset at or beyond the size -- kOutsideW, or anything at all when the size is 0 (a channel row
 // beyond the tensor) -- reads as zero.  A piece then costs its wave no VALU instruction (the pointer form: a compare, a
 // 64-bit add and a 64-bit select per piece, ~180 per box against 224 MFMAs).

@@ -272,7 +272,7 @@ __device__ __forceinline__ void epilogue_wf(const WfArgs& a, f32x16 (&out)[8], f
 template <int TT, int TH, int TW, bool PAIR, bool LLM>
 __global__ void __launch_bounds__(256, 2) conv3d_wf_kernel(const WfArgs a) {
   using G = GeoF<TT, TH, TW, PAIR, LLM>;
-  constexpr int NP = G::NP, MO = G::MO, NB = G::NB, KC = G::KC, CO = G::CO, NS = G::NS, HH = G::HH, RQ = G::RQ, PW = G::PW;
+  constexpr int NP = G::NP, MO = G::MO, KC = G::KC, CO = G::CO, NS = G::NS, HH = G::HH, RQ = G::RQ, PW = G::PW;
   constexpr int W_TAPS = G::W_TAPS;
   __shared__ __attribute__((aligned(16))) float lds[2 * G::STAGE + G::RAW_FLOATS];
   float* const st0 = lds;
