@@ -80,12 +80,21 @@ struct WwTransformArgs {
 
 constexpr int TR_W = 64;   // columns per workgroup
 
-__global__ void __launch_bounds__(256) ww_transform_kernel(const WwTransformArgs a) {
+struct WwTransformPair {
+  WwTransformArgs x, g;    // both operands in one launch: blockIdx.z < zx belongs to x^, the rest to g^
+  int zx;
+};
+
+__global__ void __launch_bounds__(256) ww_transform_kernel(const WwTransformPair pr) {
   __shared__ float tile[6 * TR_W * 33];
   const int tid = threadIdx.x;
+  const bool is_x = (int)blockIdx.z < pr.zx;
+  const WwTransformArgs& a = is_x ? pr.x : pr.g;
+  // (the grid is the envelope of the two operands' grids: workgroups outside this operand's own have nothing to do)
+  if ((int)blockIdx.x >= a.wchunks * a.cchunks || (int)blockIdx.y >= a.Hb + 2 * a.halo) return;
   const int wc = blockIdx.x % a.wchunks, cc = blockIdx.x / a.wchunks;
   const int hp = blockIdx.y;
-  int z = blockIdx.z;
+  int z = is_x ? blockIdx.z : blockIdx.z - pr.zx;
   const int t = z % a.T; z /= a.T;
   const int g = z % a.groups;
   const int b = z / a.groups;
@@ -148,7 +157,7 @@ __global__ void __launch_bounds__(256) ww_transform_kernel(const WwTransformArgs
       bsum += __shfl_xor(bsum, 1, 64);
       bsum += __shfl_xor(bsum, 2, 64);
       bsum += __shfl_xor(bsum, 4, 64);
-      const long blk = (((long)b * a.T + t) * gridDim.y + blockIdx.y) * a.wchunks + wc;     // (per group: the group is in the column)
+      const long blk = (((long)b * a.T + t) * (a.Hb + 2 * a.halo) + blockIdx.y) * a.wchunks + wc;     // (per group: the group is in the column)
       if (wq == 0) a.bias_part[blk * a.groups * a.CP + (long)g * a.CP + cl] = bsum;
     }
   }
@@ -390,6 +399,7 @@ __global__ void __launch_bounds__(256) ww_reduce_kernel(const float* __restrict_
   float m[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
   if (ci < cin_g) {
     const float* src = ws + (((long)g * 6) * 9 + tap) * tile + (long)co * CiP + ci;
+#pragma unroll 4      // (the loads of four splits in flight; the additions stay in split order)
     for (int s = sg; s < splits; s += 4) {
       const float* p = src + (long)s * groups * 54 * tile;
 #pragma unroll
@@ -467,20 +477,29 @@ WwPlan ww_plan(const tmdiff_conv3d_desc* d) {
 bool ww_fits(const tmdiff_conv3d_desc* d, const WwPlan& p) {
   // 32-bit byte offsets inside one (group, k) array; grid limits of the transform pass
   const size_t xk = (size_t)p.Q * (p.Hb + 2) * (p.Wb + 2) * p.CiP * 4, gk = (size_t)p.Q * p.Hb * p.Wb * p.CoP * 4;
-  return xk < (1ull << 31) && gk < (1ull << 31) && (long)d->B * d->groups * p.T <= 65535 && p.Hb + 2 <= 65535;
+  return xk < (1ull << 31) && gk < (1ull << 31) && 2L * d->B * d->groups * p.T <= 65535 && p.Hb + 2 <= 65535;
 }
 
-int launch_transform(const tmdiff_conv3d_desc* d, const WwPlan& p, const float* const* seg_x, const int* seg_c, int nseg, int C,
-                     int CP, int halo, float* out, float* bias_part, hipStream_t st) {
+WwTransformArgs transform_args(const tmdiff_conv3d_desc* d, const WwPlan& p, const float* const* seg_x, const int* seg_c, int nseg, int C,
+                               int CP, int halo, float* out, float* bias_part) {
   WwTransformArgs t;
   for (int i = 0; i < 3; ++i) { t.seg_x[i] = i < nseg ? seg_x[i] : nullptr; t.seg_c[i] = i < nseg ? seg_c[i] : 0; }
   t.nseg = nseg;
   t.B = d->B; t.cg = C / d->groups; t.groups = d->groups; t.N = d->N; t.H = d->H; t.W = d->W; t.T = p.T;
   t.CP = CP; t.Hb = p.Hb; t.Wb = p.Wb; t.halo = halo; t.out = out; t.bias_part = bias_part;
   t.wchunks = (d->W + TR_W - 1) / TR_W; t.cchunks = CP / 32;
-  const dim3 grid((unsigned)(t.wchunks * t.cchunks), (unsigned)(p.Hb + 2 * halo), (unsigned)(d->B * d->groups * p.T));
-  ww_transform_kernel<<<grid, 256, 0, st>>>(t);
-  return tmdiff::check_launch(halo ? "conv3d_wgrad_wino(x transform)" : "conv3d_wgrad_wino(g transform)");
+  return t;
+}
+
+// both transform passes as ONE launch (a weight gradient is four launches; the finetune step has 51 of them)
+int launch_transforms(const tmdiff_conv3d_desc* d, const WwPlan& p, const WwTransformArgs& tx, const WwTransformArgs& tg, hipStream_t st) {
+  WwTransformPair pr;
+  pr.x = tx; pr.g = tg;
+  pr.zx = d->B * d->groups * p.T;
+  const int gx = tx.wchunks * (tx.cchunks > tg.cchunks ? tx.cchunks : tg.cchunks);
+  const dim3 grid((unsigned)gx, (unsigned)(p.Hb + 2), (unsigned)(2 * pr.zx));
+  ww_transform_kernel<<<grid, 256, 0, st>>>(pr);
+  return tmdiff::check_launch("conv3d_wgrad_wino(transform passes)");
 }
 
 }  // namespace
@@ -540,11 +559,10 @@ extern "C" int tmdiff_conv3d_wgrad_wino_bias(const tmdiff_conv3d_desc* d, const 
   }();
   int rc = TMDIFF_OK;
   if (phases & 1) {
-    rc = launch_transform(d, p, segs, segc, nseg, d->Cin, p.CiP, 1, xh, nullptr, st);
-    if (rc) return rc;
     const float* gseg[3] = {g, nullptr, nullptr};
     const int gc[3] = {d->Cout, 0, 0};
-    rc = launch_transform(d, p, gseg, gc, 1, d->Cout, p.CoP, 0, gh, dbias ? bias_part : nullptr, st);
+    rc = launch_transforms(d, p, transform_args(d, p, segs, segc, nseg, d->Cin, p.CiP, 1, xh, nullptr),
+                           transform_args(d, p, gseg, gc, 1, d->Cout, p.CoP, 0, gh, dbias ? bias_part : nullptr), st);
     if (rc) return rc;
   }
 
