@@ -8,6 +8,8 @@
   configs[4]  mixed GF-2 (4 bands) / WV-3 (8 bands) sub-batches with per-sample prompts at full width, tiled scene.
 """
 import numpy as np
+import os
+
 import pytest
 import torch
 
@@ -304,8 +306,9 @@ def test_config4_finetune_step_vs_oracle_autograd():
     for lt, (lo, lh, _) in res.items():
         assert abs(lo - lh) <= 1e-5 * abs(lo), (lt, lo, lh)
     cnt = res["l2"][2]
-    assert (cnt.get("conv3d_wf_fwd", 0) + cnt.get("conv3d_wino4_fwd", 0) + cnt.get("conv3d_wino2_fwd", 0) >= 40 and
-            cnt.get("conv3d_ll_fwd", 0) == 3), cnt
+    if os.environ.get("TMDIFF_WINOGRAD", "1") != "0" and os.environ.get("TMDIFF_LL_COMPOSE", "1") != "0":   # (experiment switches off)
+        assert (cnt.get("conv3d_wf_fwd", 0) + cnt.get("conv3d_wino4_fwd", 0) + cnt.get("conv3d_wino2_fwd", 0) >= 40 and
+                cnt.get("conv3d_ll_fwd", 0) == 3), cnt
     ref_g = dict(ref_net.named_parameters())
     hip_g = dict(net.named_parameters())
     report = []
