@@ -228,6 +228,11 @@ int64_t tmdiff_conv3d_wf_blocks(const tmdiff_conv3d_desc* d);     /* workgroups 
  * in a fixed order and applies the epilogue, as for tmdiff_conv3d_fwd */
 size_t tmdiff_conv3d_wf_splitk_workspace_bytes(const tmdiff_conv3d_desc* d);
 size_t tmdiff_conv3d_wf_workspace_bytes(const tmdiff_conv3d_desc* d);
+/* The launch plan for a convolution of these extents without a descriptor (host-side routing): returns the split-K factor
+ * (1 = none) and writes the number of output tiles (workgroups = tiles x factor); 0 = shape not taken.  llm != 0: the composed
+ * Conv_0 + LL mode of tmdiff_conv3d_wfll_fwd (Cin, H, W those of the space-to-depth tensor). */
+int32_t tmdiff_conv3d_wf_plan(int32_t B, int32_t Cin, int32_t Cout, int32_t N, int32_t H, int32_t W, int32_t groups, int32_t llm,
+                              int64_t* tiles);
 int tmdiff_conv3d_wf_fwd(const tmdiff_conv3d_desc* d, void* workspace, tmdiff_stream_t stream);
 /* `Conv_0` (3x3x3) of a down block and the halved Haar LL band of its output as ONE convolution (as tmdiff_conv3d_ll_fwd: same
  * descriptor -- H, W the INPUT extents, outputs at half of them, bias multiplied by 2 * ll_scale) WITH Winograd F(4,3) along the

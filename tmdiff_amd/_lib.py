@@ -75,6 +75,7 @@ SIGNATURES = {
     "tmdiff_conv3d_wgrad_workspace_bytes": (C.c_size_t, [C.POINTER(Conv3dDesc)]),
     "tmdiff_conv3d_wgrad": (C.c_int, [C.POINTER(Conv3dDesc), vp, vp, vp, vp]),
     "tmdiff_conv3d_wgrad_bias": (C.c_int, [C.POINTER(Conv3dDesc), vp, vp, vp, vp, vp]),
+    "tmdiff_conv3d_wf_plan": (C.c_int32, [C.c_int32] * 8 + [C.POINTER(C.c_int64)]),
     "tmdiff_conv3d_wfll_supported": (C.c_int, [C.POINTER(Conv3dDesc)]),
     "tmdiff_conv3d_wfll_packed_bytes": (C.c_size_t, [C.c_int32, C.c_int32]),
     "tmdiff_conv3d_wfll_pack_weights": (C.c_int, [vp, vp, C.c_int32, C.c_int32, C.c_float, vp]),

@@ -602,22 +602,30 @@ long wf_tiles(const tmdiff_conv3d_desc* d) {
 }
 
 // split-K factor for grids that cannot fill the chip: the smallest divisor of the chunk count that brings the grid to 256
-// workgroups (TMDIFF_SPLITK=<n>: to n), at least two chunks per range; TMDIFF_SPLITK=0: never
-// (pairs: the ranges must hold whole pairs of chunks -- the composed-LL mode, whose chunks alternate in row parity)
+// workgroups (TMDIFF_SPLITK=<n>: to n; one workgroup per CU unsplit beats two halves + a reduction kernel for short K loops:
+// 384 cost 2 % of the finetune step), at least two chunks per range -- and once more by two where that still leaves fewer
+// than 384 workgroups and a range is LONG (>= 2500 K-steps: the composed-LL launches of the 16x16 / 8x8 levels, 550 -> 472 us):
+// a workgroup alone on its CU leaves 15 % of the matrix pipe idle, which a long loop pays for the reduction several times over.
+// TMDIFF_SPLITK=0: never.  pairs: the ranges must hold whole pairs of chunks (the composed-LL mode, whose chunks alternate in
+// row parity).
 int wf_ksplit(const tmdiff_conv3d_desc* d, bool pairs = false) {
   static const long target = [] {
     const char* e = getenv("TMDIFF_SPLITK");
-    return e ? atol(e) : 256L;      // (one workgroup per CU unsplit beats two halves + a reduction: 384 cost 2 % of the finetune step)
+    return e ? atol(e) : 256L;
   }();
   const long tiles = wf_tiles(d);
   const int nchunks = d->Cin / d->groups / 2;
-  if (target <= 0 || tiles >= target) return 1;
+  const int ksteps = pairs ? 24 : 54;
+  if (target <= 0 || tiles <= 0) return 1;
+  auto ok = [&](int s) { return s >= 1 && nchunks % s == 0 && nchunks / s >= 2 && !(pairs && (nchunks / s) % 2); };
   int best = 1;
-  for (int s = 2; s <= nchunks / 2; ++s) {
-    if (nchunks % s || (pairs && (nchunks / s) % 2)) continue;
-    best = s;
-    if (tiles * s >= target) break;
-  }
+  if (tiles < target)
+    for (int s = 2; s <= nchunks / 2; ++s) {
+      if (!ok(s)) continue;
+      best = s;
+      if (tiles * s >= target) break;
+    }
+  if (tiles * best < 384 && ok(2 * best) && (long)(nchunks / (2 * best)) * ksteps >= 2500) best *= 2;
   return best;
 }
 
@@ -628,6 +636,20 @@ bool wf_plain(const tmdiff_conv3d_desc* d) {
 }  // namespace
 
 extern "C" int tmdiff_conv3d_wf_supported(const tmdiff_conv3d_desc* d) { return wf_shape_ok(d) ? 1 : 0; }
+
+/* the launch plan of tmdiff_conv3d_wf_fwd for a convolution of these extents, without a descriptor (host-side routing): returns
+ * the split-K factor (1 = none; what the launch does when the split-K workspace is lent) and writes the number of output tiles
+ * (workgroups = tiles x factor); 0 = shape not taken.  llm != 0: the composed Conv_0 + LL mode (Cin, H, W those of the
+ * space-to-depth tensor: 4 x the channels, half the extents). */
+extern "C" int32_t tmdiff_conv3d_wf_plan(int32_t B, int32_t Cin, int32_t Cout, int32_t N, int32_t H, int32_t W, int32_t groups,
+                                         int32_t llm, int64_t* tiles) {
+  tmdiff_conv3d_desc d = {};
+  d.B = B; d.N = N; d.H = H; d.W = W; d.Cin = Cin; d.Cout = Cout; d.groups = groups; d.ksize = 3; d.nseg = 1; d.seg_c[0] = Cin;
+  if (tiles) *tiles = 0;
+  if (B <= 0 || !wf_shape_ok(&d)) return 0;
+  if (tiles) *tiles = wf_tiles(&d);
+  return wf_ksplit(&d, llm != 0);
+}
 
 /* workgroups of the grid when the split-K workspace is lent (tiles x split factor) */
 extern "C" int64_t tmdiff_conv3d_wf_blocks(const tmdiff_conv3d_desc* d) {

@@ -498,41 +498,32 @@ def conv3d_wino(segs, w_packed, cout, emit=None, keep_y=True, fallback=None, gro
 _WF = os.environ.get("TMDIFF_WF", "1") != "0"    # experiments: "0" = never the in-kernel-transform Winograd kernel (conv3d_wf)
 _WF_MIN_FILL = float(os.environ.get("TMDIFF_WF_MIN_FILL", "0.7"))
 _WF_PAIR = os.environ.get("TMDIFF_WF_PAIR", "1") != "0"          # experiments: "0" = 8-column planes go to the fallback kernels
-_WF_SPLIT_TARGET = int(os.environ.get("TMDIFF_SPLITK", "256") or 0)   # as the library reads it (csrc/conv3d_wf.hip, wf_ksplit)
 _WF_SPLITK = os.environ.get("TMDIFF_WF_SPLITK", "1") != "0"      # experiments: "0" = small grids go to the fallback kernels
 
 
-def wf_route(b, cin, cout, n, h, w, groups=1, masked=False):
+def wf_route(b, cin, cout, n, h, w, groups=1, masked=False, llm=False):
     """(taken, split): whether conv3d_wf runs a convolution of these extents itself (else its fallback does) and into how many
-    ranges it splits the input channels (1 = no split-K).  The rules of csrc/conv3d_wf.hip (tmdiff_conv3d_wf_blocks) plus the
-    host's: grids below _WINO_MIN_BLOCKS workgroups and planes that leave much of every 8 x 16 tile empty go to the fallback."""
-    cg = cout // groups
-    th = 8 if n == 8 else 16
-    # (8 bands x 8 columns: two images side by side in one 8 x 16 tile -- the kernel's pair mode)
-    pair = _WF_PAIR and n == 8 and w == 8
-    units = (b + 1) // 2 if pair else b * ((w + 15) // 16)
-    tiles = units * groups * ((h + th - 1) // th) * (cg // 32) if cg % 32 == 0 else 0
-    # small grids split their input channels over workgroups (the smallest divisor of the chunk count that reaches 256
-    # workgroups, at least two chunks per range: tmdiff_conv3d_wf_blocks) -- single images, the deep levels of a local batch
-    nchunks = (cin // groups) // 2
-    split = 1
-    if 0 < tiles < _WF_SPLIT_TARGET:
-        for s_ in range(2, nchunks // 2 + 1):
-            if nchunks % s_ == 0:
-                split = s_
-                if tiles * s_ >= _WF_SPLIT_TARGET:
-                    break
+    ranges it splits the input channels (1 = no split-K).  The kernel's own plan (tmdiff_conv3d_wf_plan) plus the host's rules:
+    grids below _WINO_MIN_BLOCKS workgroups and planes that leave much of every 8 x 16 tile empty go to the fallback.
+    llm: the composed Conv_0 + LL mode (cin, h, w those of the space-to-depth tensor)."""
+    if cin % groups or cout % groups or masked or not _WF:
+        return False, 1
+    tiles = C.c_int64(0)
+    split = lib.tmdiff_conv3d_wf_plan(b, cin, cout, n, h, w, groups, 1 if llm else 0, C.byref(tiles))
+    if split == 0:
+        return False, 1
     if not _WF_SPLITK:
         split = 1
-    blocks = tiles * split
-    ok = _WF and n in (4, 8) and w % 4 == 0 and cg % 32 == 0 and (cin // groups) % 2 == 0 and not masked
+    th = 8 if n == 8 else 16
+    # (8 bands x 8 columns: two images side by side in one 8 x 16 tile -- the kernel's pair mode)
+    pair = n == 8 and w == 8
+    if pair and not _WF_PAIR:
+        return False, 1
     # (tiles of th x 16 positions: a plane that leaves much of every tile empty goes to the fallback)
     fill = (h * w) / float(((h + th - 1) // th) * th * (8 if pair else ((w + 15) // 16) * 16))
     if pair:
         fill *= b / (2.0 * ((b + 1) // 2))        # (an odd batch leaves the last pair's second half empty: B = 1 is half a tile)
-    if n == 8 and w == 8 and not pair:
-        fill = 0.0
-    return bool(ok and blocks >= _WINO_MIN_BLOCKS and fill >= _WF_MIN_FILL), split
+    return bool(tiles.value * split >= _WINO_MIN_BLOCKS and fill >= _WF_MIN_FILL), split
 
 
 def conv3d_wf(segs, w_packed, cout, emit=None, keep_y=True, fallback=None, groups=1, w_packed_fn=None, xp_out=None, **kw):
@@ -662,7 +653,7 @@ def wfll_route(b, cin, cout, n, h, w):
     """True when conv3d_wf_ll takes the composed Conv_0 + LL convolution of a [b, cin, n, h, w] input (h, w: full resolution)."""
     if not (_WFLL and n == 8 and h % 2 == 0 and w % 8 == 0 and cout % 32 == 0):
         return False
-    takes, _ = wf_route(b, 4 * cin, cout, n, h // 2, w // 2)
+    takes, _ = wf_route(b, 4 * cin, cout, n, h // 2, w // 2, llm=True)
     return takes
 
 
