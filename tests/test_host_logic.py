@@ -371,8 +371,10 @@ def test_kernel_routing_rules_and_support_queries():
     assert ops.wf_route(32, 64, 64, 8, 64, 64) == (True, 1)
     assert ops.wf_route(32, 256, 256, 8, 16, 16) == (True, 1)                 # 512 tiles
     taken, split = ops.wf_route(32, 256, 256, 8, 8, 8)                        # pair mode: 16 pairs x 8 channel tiles = 128
-    assert taken and split == 2
-    assert ops.wf_route(32, 64, 64, 8, 16, 16)[1] == 2                        # 128 tiles of a 64-channel layer
+    assert taken and split == 4                                               # (to 256, then once more: ranges of 32 chunks are long)
+    assert ops.wf_route(32, 64, 64, 8, 16, 16)[1] == 2                        # 128 tiles of a 64-channel layer: short ranges
+    assert ops.wf_route(32, 128, 128, 8, 16, 16)[1] == 2                      # 256 tiles, 32-chunk ranges: split once
+    assert ops.wf_route(8, 128, 128, 8, 32, 32)[1] == 2 and ops.wf_route(8, 64, 64, 8, 32, 32)[1] == 2
     # a single image at the 8x8 level is half a pair: the fallback kernels; odd band counts and masks too
     assert not ops.wf_route(1, 256, 256, 8, 8, 8)[0]
     assert not ops.wf_route(32, 64, 64, 6, 64, 64)[0] and not ops.wf_route(32, 64, 64, 8, 64, 64, masked=True)[0]

@@ -604,7 +604,8 @@ long wf_tiles(const tmdiff_conv3d_desc* d) {
 // split-K factor for grids that cannot fill the chip: the smallest divisor of the chunk count that brings the grid to 256
 // workgroups (TMDIFF_SPLITK=<n>: to n; one workgroup per CU unsplit beats two halves + a reduction kernel for short K loops:
 // 384 cost 2 % of the finetune step), at least two chunks per range -- and once more by two where that still leaves fewer
-// than 384 workgroups and a range is LONG (>= 2500 K-steps: the composed-LL launches of the 16x16 / 8x8 levels, 550 -> 472 us):
+// than 384 workgroups and a range is LONG (>= 1700 K-steps, i.e. 32 chunks: 128 -> 128 at the 16x16 level; the composed-LL
+// launches of the 16x16 / 8x8 levels, 550 -> 472 us; benchmark step 23.97 -> 23.61 ms, finetune step unchanged):
 // a workgroup alone on its CU leaves 15 % of the matrix pipe idle, which a long loop pays for the reduction several times over.
 // TMDIFF_SPLITK=0: never.  pairs: the ranges must hold whole pairs of chunks (the composed-LL mode, whose chunks alternate in
 // row parity).
@@ -625,7 +626,11 @@ int wf_ksplit(const tmdiff_conv3d_desc* d, bool pairs = false) {
       best = s;
       if (tiles * s >= target) break;
     }
-  if (tiles * best < 384 && ok(2 * best) && (long)(nchunks / (2 * best)) * ksteps >= 2500) best *= 2;
+  static const long long_range = [] {      // (experiments: TMDIFF_SPLITK_LONG=<K-steps per range from which a range counts as long>)
+    const char* e = getenv("TMDIFF_SPLITK_LONG");
+    return e ? atol(e) : 1700L;
+  }();
+  if (tiles * best < 384 && ok(2 * best) && (long)(nchunks / (2 * best)) * ksteps >= long_range) best *= 2;
   return best;
 }
 
