@@ -568,10 +568,12 @@ def main():
                          "frac_with_transforms": round(fl3 / ((ms3 + ms0) * 1e-3) / 1e12 / PEAK_FP32_MFMA, 4) if ms3 > 0 else 0.0,
                          "kernel": "3x3x3 conv launches, fp32 v_mfma_f32_32x32x2_f32.  Dominant: conv3d_wf_kernel (Winograd F(4,3) "
                                    "along the band axis, input transform inside the kernel: 2x fewer multiply-adds, no transform "
-                                   "pass; its prologue pass for three-segment inputs is inside its time).  Others: wino_input_kernel "
-                                   "+ conv3d_wino_kernel (F(2,3) / F(4,3) with a transform pass: the 8x8 level), conv3d_ll_kernel "
-                                   "(Conv_0 + LL band of the main branch's down blocks as one strided convolution), "
-                                   "conv3d_dma_kernel<3,..> / conv3d_mfma_kernel<3,..> (direct), chosen per layer",
+                                   "pass; its prologue pass for three-segment inputs and the reduction kernel of its split-K "
+                                   "launches are inside its time).  At the benchmark batch it runs EVERY 3x3x3 convolution: "
+                                   "conv3d_wf_fwd = the stride-1 ones (8x8 level: two images per tile), conv3d_wfll_fwd = Conv_0 + "
+                                   "LL band of the main branch's down blocks as one convolution with Winograd on top (24 instead of "
+                                   "48 / 108 multiply-adds per output, on the producer's space-to-depth output).  Fallbacks for other "
+                                   "shapes: conv3d_ll_kernel, wino_input_kernel + conv3d_wino_kernel, conv3d_dma / conv3d_mfma (direct)",
                          "flops_counted": "EXECUTED on the matrix pipe (what the roofline bounds); in the reference's operator "
                                           "order the same launches are worth `reference_order_tflops`",
                          "reference_order_tflops": round(fl3_ref / (ms3 * 1e-3) / 1e12, 2) if ms3 > 0 else 0.0,

@@ -506,6 +506,20 @@ def wf_route(b, cin, cout, n, h, w, groups=1, masked=False, llm=False):
     ranges it splits the input channels (1 = no split-K).  The kernel's own plan (tmdiff_conv3d_wf_plan) plus the host's rules:
     grids below _WINO_MIN_BLOCKS workgroups and planes that leave much of every 8 x 16 tile empty go to the fallback.
     llm: the composed Conv_0 + LL mode (cin, h, w those of the space-to-depth tensor)."""
+    key = (b, cin, cout, n, h, w, groups, masked, llm, _WF, _WF_SPLITK, _WF_PAIR, _WINO_MIN_BLOCKS, _WF_MIN_FILL)
+    r = _WF_ROUTES.get(key)
+    if r is None:
+        if len(_WF_ROUTES) > 4096:
+            _WF_ROUTES.clear()
+        r = _WF_ROUTES[key] = _wf_route(b, cin, cout, n, h, w, groups, masked, llm)
+    return r
+
+
+_WF_ROUTES = {}      # (the plan is a pure function of the extents: one library call per distinct shape, not per launch)
+
+
+def _wf_route(b, cin, cout, n, h, w, groups=1, masked=False, llm=False):
+    """wf_route without the cache."""
     if cin % groups or cout % groups or masked or not _WF:
         return False, 1
     tiles = C.c_int64(0)
