@@ -239,7 +239,7 @@ int tmdiff_conv3d_wf_fwd(const tmdiff_conv3d_desc* d, void* workspace, tmdiff_st
  * bands on top: the LL band acts on (h, w) only, so the composed 3x4x4 stride-2 kernel keeps its three band taps -- 16 x 6 / 4 =
  * 24 multiply-adds per output instead of 48 (and 108 for the convolution + DWT pair).  seg_x[0] is the producer's SPACE-TO-DEPTH
  * second output (y2_s2d above: [B, 4 Cin, N, H/2, W/2]); on it the composed kernel is a stride-1 convolution with 2 x 2 of the
- * 3 x 3 taps per virtual channel, which the kernel of tmdiff_conv3d_wf_fwd runs with a 24-step K loop.  8-band tensors, W % 8 == 0,
+ * 3 x 3 taps per virtual channel, which the kernel of tmdiff_conv3d_wf_fwd runs with a 24-step K loop.  8- and 4-band tensors, W % 8 == 0,
  * Cout % 32 == 0; weights from tmdiff_conv3d_wfll_pack_weights (Cin x 96 x Cout floats). */
 int tmdiff_conv3d_wfll_supported(const tmdiff_conv3d_desc* d);
 size_t tmdiff_conv3d_wfll_packed_bytes(int32_t Cout, int32_t Cin);

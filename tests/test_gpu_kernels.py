@@ -604,14 +604,16 @@ def test_conv3d_ll_is_conv_then_halved_ll_band(ops, case):
     (3, 16, 32, 16, 16),      # 8 x 8 output planes: pair mode, odd batch
     (1, 64, 32, 16, 32),      # one tile: split over the input channels (whole pairs of row-parity chunks per range)
     (4, 32, 64, 32, 32),
+    (2, 32, 32, 32, 32, 4),   # 4-band tensors (GF-2 / QuickBird): one band tile, 16 x 16 positions
+    (1, 6, 32, 24, 40, 4),    # ... ragged
 ])
 def test_conv3d_ll_with_winograd_along_the_bands(ops, case):
     """tmdiff_conv3d_wfll_fwd: Conv_0 + halved LL band as one convolution with F(4,3) along the bands, on the space-to-depth
     second output of its producer (tmdiff_conv3d_wf_fwd with y2_s2d): the producer's s2d output is its plain second output
     rearranged (bit for bit), the composed convolution agrees with the CPU convolution + LL band (fp64), with conv3d_ll and
     with the convolution + DWT pair; bias, residual, scale and second output."""
-    B, cin, cout, H, W = case
-    N = 8
+    B, cin, cout, H, W = case[:5]
+    N = case[5] if len(case) > 5 else 8
     torch.manual_seed(5 + cin + W)
     # ---- the producer: a 3x3x3 convolution whose second output feeds the down block
     xin = torch.randn(B, 2, N, H, W)                   # (one chunk of input channels: a small grid cannot split it)

@@ -380,7 +380,7 @@ def test_kernel_routing_rules_and_support_queries():
     assert not ops.wf_route(32, 64, 64, 6, 64, 64)[0] and not ops.wf_route(32, 64, 64, 8, 64, 64, masked=True)[0]
     # composed Conv_0 + LL with Winograd on top: 8 bands, W % 8 == 0, Cout % 32 == 0
     assert ops.wfll_route(32, 64, 64, 8, 64, 64) and ops.wfll_route(32, 256, 256, 8, 16, 16)
-    assert not ops.wfll_route(32, 64, 64, 4, 64, 64) and not ops.wfll_route(32, 64, 48, 8, 64, 64)
+    assert ops.wfll_route(32, 64, 64, 4, 64, 64) and not ops.wfll_route(32, 64, 64, 6, 64, 64) and not ops.wfll_route(32, 64, 48, 8, 64, 64)
     assert L.tmdiff_conv3d_wfll_packed_bytes(64, 32) == 32 * 96 * 64 * 4 and L.tmdiff_conv3d_wfll_packed_bytes(48, 32) == 0
     # Winograd-domain weight gradient: N % 4 == 0, W % 4 == 0, 3x3x3
     d = _lib.Conv3dDesc()

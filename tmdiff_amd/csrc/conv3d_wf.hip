@@ -731,7 +731,7 @@ int wf_forward(const tmdiff_conv3d_desc* d, void* workspace, tmdiff_stream_t str
   if (wf_pair(d))
     TMDIFF_REQUIRE(((long)d->Cin + 2) * d->N * d->H * d->W < (1L << 29), "conv3d_wf_fwd: sample too large for 32-bit offsets");
   int rc;
-  if (llm) rc = wf_pair(d) ? launch<2, 8, 16, true, true>(a, st) : launch<2, 8, 16, false, true>(a, st);
+  if (llm) rc = wf_pair(d) ? launch<2, 8, 16, true, true>(a, st) : (d->N == 8 ? launch<2, 8, 16, false, true>(a, st) : launch<1, 16, 16, false, true>(a, st));
   else rc = wf_pair(d) ? launch<2, 8, 16, true>(a, st) : (d->N == 8 ? launch<2, 8, 16>(a, st) : launch<1, 16, 16>(a, st));
   if (rc || !a.part) return rc;
   SplitKReduceArgs r{a.part, a.ksplit, d->B, d->Cout, (long)d->N * d->H * d->W, d->bias, d->bias_scale, d->residual,
@@ -742,7 +742,7 @@ int wf_forward(const tmdiff_conv3d_desc* d, void* workspace, tmdiff_stream_t str
 // the descriptor of the composed-LL convolution as the kernel sees it: the space-to-depth input has 4 x the channels at half
 // the extents; outputs at the halved extents
 bool wfll_desc(const tmdiff_conv3d_desc* d, tmdiff_conv3d_desc* e) {
-  if (!d || d->ksize != 3 || d->groups != 1 || d->nseg != 1 || d->N != 8 || d->H <= 0 || d->W <= 0 || d->H % 2 || d->W % 8) return false;
+  if (!d || d->ksize != 3 || d->groups != 1 || d->nseg != 1 || (d->N != 8 && d->N != 4) || d->H <= 0 || d->W <= 0 || d->H % 2 || d->W % 8) return false;
   if (d->in_shift || d->in_scale || d->in_act || d->in_mask || d->drop_p > 0.f || d->x_bf16 || d->y2_bf16 || d->y2_s2d) return false;
   if (d->Cin <= 0 || d->Cout <= 0 || d->Cout % 32 || d->seg_c[0] != d->Cin) return false;
   *e = *d;
@@ -831,6 +831,6 @@ extern "C" int tmdiff_conv3d_wfll_fwd(const tmdiff_conv3d_desc* d, float ll_scal
   using namespace tmdiff;
   tmdiff_conv3d_desc e;
   if (!wfll_desc(d, &e))
-    return fail(TMDIFF_E_UNSUPPORTED, "conv3d_wfll_fwd: one plain fp32 space-to-depth input, 3x3x3, groups 1, 8 bands, even H, W %% 8 == 0, Cout %% 32 == 0");
+    return fail(TMDIFF_E_UNSUPPORTED, "conv3d_wfll_fwd: one plain fp32 space-to-depth input, 3x3x3, groups 1, 8 or 4 bands, even H, W %% 8 == 0, Cout %% 32 == 0");
   return wf_forward(&e, nullptr, stream, true, 2.f * ll_scale);
 }

@@ -665,7 +665,7 @@ def pack_conv_weight_wfll(w, ll_scale=0.5):
 
 def wfll_route(b, cin, cout, n, h, w):
     """True when conv3d_wf_ll takes the composed Conv_0 + LL convolution of a [b, cin, n, h, w] input (h, w: full resolution)."""
-    if not (_WFLL and n == 8 and h % 2 == 0 and w % 8 == 0 and cout % 32 == 0):
+    if not (_WFLL and n in (4, 8) and h % 2 == 0 and w % 8 == 0 and cout % 32 == 0):
         return False
     takes, _ = wf_route(b, 4 * cin, cout, n, h // 2, w // 2, llm=True)
     return takes
