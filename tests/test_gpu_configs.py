@@ -329,3 +329,50 @@ def test_config4_finetune_step_vs_oracle_autograd():
         m, l2 = rel_err(p.grad, ref_g[k].grad)
         assert l2 <= 1e-4, (k, m, l2)
     assert n == 272 - 56
+
+
+def test_round3_kernels_at_full_size_properties():
+    """The round-3 kernels at BASELINE sizes, through properties that need no CPU reference: the Winograd-domain weight
+    gradient at the finetune batch (8 tiles of 8x64x64) is linear in the gradient, deterministic and agrees with the direct
+    kernel; the composed Conv_0 + LL convolution with Winograd on top at the benchmark batch (32 tiles) agrees with conv3d_ll,
+    its producer's space-to-depth output with the plain one, and an image gives the same bits wherever it sits in the batch
+    (pair mode at the 8x8 level included)."""
+    from tmdiff_amd import ops
+    torch.manual_seed(31)
+    # ---- weight gradient, 64 -> 64 at 8 x 8x64x64
+    x = torch.randn(8, 64, 8, 64, 64, device="cuda")
+    g1, g2 = torch.randn(8, 64, 8, 64, 64, device="cuda"), torch.randn(8, 64, 8, 64, 64, device="cuda")
+    wshape = (64, 64, 3, 3, 3)
+    dw = lambda g: ops.conv3d_wgrad(ops.make_conv_desc([x], 0, 64, 3, g), g, wshape)
+    a, b, ab = dw(g1), dw(g2), dw(g1 + 0.5 * g2)
+    assert torch.equal(a, dw(g1))
+    scale = float(ab.abs().max())
+    assert float((ab - (a + 0.5 * b)).abs().max()) <= 1e-5 * scale                 # linearity (sums of 262 144 fp32 products)
+    keep, ops._WGRAD_WINO = ops._WGRAD_WINO, False
+    try:
+        direct = dw(g1)
+    finally:
+        ops._WGRAD_WINO = keep
+    assert float((a - direct).norm() / direct.norm()) <= 5e-6                      # both accumulate 262 144 products in fp32
+    del g1, g2, a, b, ab, direct
+    # ---- Conv_0 + LL, 64 -> 64 at 32 x 8x64x64: producer (space-to-depth second output) + composed convolution
+    xin = torch.randn(32, 64, 8, 64, 64, device="cuda")
+    w21 = torch.randn(64, 64, 3, 3, 3, device="cuda") / (64 * 27) ** 0.5
+    w0, bias = torch.randn(64, 64, 3, 3, 3, device="cuda") / (64 * 27) ** 0.5, torch.randn(64, device="cuda")
+    wp = ops.pack_conv_weight_wino(w21, groups=1, mode=2, planes=6)
+    assert ops.wf_route(32, 64, 64, 8, 64, 64) == (True, 1) and ops.wfll_route(32, 64, 64, 8, 64, 64)
+    y, plain = ops.conv3d_wf([xin], wp, 64, emit=dict(act=True))
+    y_, s2d = ops.conv3d_wf([xin], wp, 64, emit=dict(act=True, s2d=True))
+    assert torch.equal(y, y_)
+    assert torch.equal(s2d, plain.view(32, 64, 8, 32, 2, 32, 2).permute(0, 1, 4, 6, 2, 3, 5).reshape(32, 256, 8, 32, 32))
+    out = ops.conv3d_wf_ll(s2d, ops.pack_conv_weight_wfll(w0, 0.5), 64, 0.5, bias=bias)
+    old = ops.conv3d_ll(plain, ops.pack_conv_weight_ll(w0, 0.5), 64, 0.5, bias=bias)
+    assert float((out - old).norm() / old.norm()) <= 2e-6
+    # ---- batch position: image 5 alone in a batch of two identical images, and at the 8x8 level in pair mode
+    for shape in ((8, 64, 64), (8, 8, 8)):
+        c = 64 if shape[1] == 64 else 256
+        xb = torch.randn(32, c, *shape, device="cuda")
+        wq = ops.pack_conv_weight_wino(torch.randn(c, c, 3, 3, 3, device="cuda") / (c * 27) ** 0.5, groups=1, mode=2, planes=6)
+        full = ops.conv3d_wf([xb], wq, c)
+        shuffled = ops.conv3d_wf([xb.flip(0).contiguous()], wq, c).flip(0)
+        assert torch.equal(full, shuffled), shape
