@@ -434,7 +434,7 @@ def test_weight_gradient_in_the_winograd_domain(case):
     assert_close(db.cpu(), (2.0 * g.double().sum(dim=(0, 2, 3, 4))).float(), 1e-5, 1e-5, "dbias beside the Winograd weight gradient")
 
 
-@pytest.mark.parametrize("shape", [(2, 8, 64, 4, 16, 16), (1, 6, 128, 3, 12, 20)])
+@pytest.mark.parametrize("shape", [(2, 8, 64, 4, 16, 16), (1, 6, 128, 3, 12, 20), (8, 16, 64, 8, 32, 64)])
 def test_composed_conv_ll_gradients_vs_cpu_autograd(shape):
     """autograd.conv3d_ll = LL(conv3d(SiLU(x), w) + b) / 2 with the forward as ONE strided convolution on composed weights
     (down blocks whose high bands are dropped): output and the gradients w.r.t. x, w, b against CPU autograd of the
@@ -451,7 +451,15 @@ def test_composed_conv_ll_gradients_vs_cpu_autograd(shape):
     want = 0.25 * (full[..., 0::2, 0::2] + full[..., 0::2, 1::2] + full[..., 1::2, 0::2] + full[..., 1::2, 1::2])
     (want * r).sum().backward()
     xg, wg, bg = (t.detach().cuda().requires_grad_() for t in (x, w, b))
-    got = A.conv3d_ll(xg, wg, bg, 0.5)
+    from tmdiff_amd import ops
+    counts, ops.COUNTS = ops.COUNTS, __import__("collections").Counter()
+    try:
+        got = A.conv3d_ll(xg, wg, bg, 0.5)
+        ran = dict(ops.COUNTS)
+    finally:
+        ops.COUNTS = counts
+    # (the large case is taken by the composed-LL mode of the Winograd kernel, the small ones by conv3d_ll)
+    assert ran.get("conv3d_wfll_fwd", 0) + ran.get("conv3d_ll_fwd", 0) == 1 and (B < 8 or ran.get("conv3d_wfll_fwd", 0) == 1), ran
     (got * r.cuda()).sum().backward()
     assert_close(got.detach(), want.detach(), 2e-5, 2e-6, "conv3d_ll forward")
     assert_close(xg.grad, x.grad, 3e-5, 3e-6, "d/dx")

@@ -308,7 +308,7 @@ def test_config4_finetune_step_vs_oracle_autograd():
     cnt = res["l2"][2]
     if os.environ.get("TMDIFF_WINOGRAD", "1") != "0" and os.environ.get("TMDIFF_LL_COMPOSE", "1") != "0":   # (experiment switches off)
         assert (cnt.get("conv3d_wf_fwd", 0) + cnt.get("conv3d_wino4_fwd", 0) + cnt.get("conv3d_wino2_fwd", 0) >= 40 and
-                cnt.get("conv3d_ll_fwd", 0) == 3), cnt
+                cnt.get("conv3d_ll_fwd", 0) + cnt.get("conv3d_wfll_fwd", 0) == 3), cnt
     ref_g = dict(ref_net.named_parameters())
     hip_g = dict(net.named_parameters())
     report = []

@@ -19,6 +19,7 @@ import os as _os
 # pass (0.6 ms of launches) is paid back inside the MFMA stream -- so the separate pass stays the default.
 _WINOGRAD = _os.environ.get("TMDIFF_WINOGRAD", "1") != "0"     # experiments: "0" = direct kernels for every convolution
 _WGRAD_BIAS = _os.environ.get("TMDIFF_WGRAD_BIAS", "0") == "1"
+_LL_WINO = _os.environ.get("TMDIFF_TRAIN_LL_WINO", "1") != "0"   # experiments: "0" = the finetune forward's Conv_0 + LL stays on conv3d_ll
 _WGRAD_WINO_BIAS = _os.environ.get("TMDIFF_WGRAD_WINO_BIAS", "1") != "0"   # experiments: "0" = a channel-sum kernel beside the Winograd weight gradient
 
 
@@ -166,7 +167,13 @@ class _ConvLL(torch.autograd.Function):
         d.B, d.N, d.H, d.W, d.Cin, d.Cout, d.groups, d.ksize, d.nseg = b, n, h, wd, cin, cout, 1, 3, 1
         d.seg_c[0], d.seg_x[0], d.in_act = cin, x.data_ptr(), 1
         xp = ops.conv3d_prologue(d, tuple(x.shape))
-        y = ops.conv3d_ll(xp, ops.pack_conv_weight_ll(w, ll_scale), cout, ll_scale, bias=bias)
+        if _LL_WINO and ops.wfll_route(b, cin, cout, n, h, wd):
+            # with Winograd along the bands on top (conv3d_wf's composed-LL mode): x' once more in space-to-depth form (a copy:
+            # the weight gradient keeps reading the plain x'; 28.37 -> 28.19 ms per finetune step)
+            xs = xp.view(b, cin, n, h // 2, 2, wd // 2, 2).permute(0, 1, 4, 6, 2, 3, 5).reshape(b, 4 * cin, n, h // 2, wd // 2)
+            y = ops.conv3d_wf_ll(xs, ops.pack_conv_weight_wfll(w, ll_scale), cout, ll_scale, bias=bias)
+        else:
+            y = ops.conv3d_ll(xp, ops.pack_conv_weight_ll(w, ll_scale), cout, ll_scale, bias=bias)
         ctx.ll_scale = ll_scale
         ctx.has_bias = bias is not None
         ctx.save_for_backward(w, x, xp)
