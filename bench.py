@@ -220,6 +220,37 @@ def parity_check(dev):
                     "the reference to the same on these kernels)"}
 
 
+def collective_evidence(dist, world, rank, backend, device=None, device_index=None):
+    """What the process group itself says about the run (`n_gpus` used to be WORLD_SIZE from the environment,
+    not something a collective had confirmed): a SUM all-reduce of a ones tensor ON THE DEVICE (ranks_seen must equal world),
+    and an all-gather of every rank's device index and host PID.  Called right after init_process_group and again after the
+    timed region; rank 0 puts both into the line.  The reference's multi-GPU path is nn.DataParallel over `gpu_ids`
+    (GeneralModel/networks.py:88-92): one replica per listed device, which `device_ids` here evidences."""
+    import torch
+    if dist is None:
+        return {"world": 1, "ranks_seen": 1, "backend": None, "device_ids": [device_index], "pids": [os.getpid()]}
+    one = torch.ones(1, device=device)
+    dist.all_reduce(one, op=dist.ReduceOp.SUM)
+    gdev = device if backend == "nccl" else None          # (gloo gathers host tensors only; its all-reduce takes device ones)
+    mine = torch.tensor([rank, -1 if device_index is None else device_index, os.getpid()], device=gdev, dtype=torch.int64)
+    got = [torch.zeros_like(mine) for _ in range(world)]
+    dist.all_gather(got, mine)
+    got = sorted((int(g[0]), int(g[1]), int(g[2])) for g in got)
+    return {"world": dist.get_world_size(), "ranks_seen": int(round(float(one[0]))), "backend": dist.get_backend(),
+            "ranks": [g[0] for g in got], "device_ids": [g[1] for g in got], "pids": [g[2] for g in got]}
+
+
+def per_rank_ms(dist, world, dt, steps, device=None):
+    """ms per step of every rank (all-gather), beside the MAX the contract asks for."""
+    import torch
+    if dist is None:
+        return [round(dt / steps * 1e3, 3)]
+    mine = torch.tensor([dt / steps * 1e3], device=device if dist.get_backend() == "nccl" else None, dtype=torch.float64)
+    got = [torch.zeros_like(mine) for _ in range(world)]
+    dist.all_gather(got, mine)
+    return [round(float(g[0]), 3) for g in got]
+
+
 def rehearse(world, rank, args):
     """Launcher rehearsal without a GPU (--rehearse; used by tests/test_bench_launcher.py): the same rendezvous,
     barrier-bracketed timed region and MAX-over-ranks reduction as the real run, over gloo, with a token CPU step."""
@@ -232,19 +263,25 @@ def rehearse(world, rank, args):
     if os.environ.get("TMDIFF_BENCH_REHEARSE_FAIL_RANK") == str(rank):     # (tests: a rank that dies before the collective)
         os._exit(7)
     barrier = (lambda: dist.barrier()) if dist is not None else (lambda: None)
+    ev0 = collective_evidence(dist, world, rank, "gloo")
     barrier()
     t0 = time.perf_counter()
     for _ in range(args.steps):
         x = (x @ x) / 64.0
     barrier()
-    tt = torch.tensor([time.perf_counter() - t0], dtype=torch.float64)
+    dt = time.perf_counter() - t0
+    tt = torch.tensor([dt], dtype=torch.float64)
     ranks = torch.tensor([float(rank + 1)])
     if dist is not None:
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         dist.all_reduce(ranks, op=dist.ReduceOp.SUM)          # every rank took part: 1 + 2 + ... + world
+    ev1 = collective_evidence(dist, world, rank, "gloo")
+    ms = per_rank_ms(dist, world, dt, max(args.steps, 1))
     if rank == 0:
-        print(json.dumps({"metric": "launcher rehearsal (no GPU work)", "rehearsal": True, "n_gpus": world,
+        print(json.dumps({"metric": "launcher rehearsal (no GPU work)", "rehearsal": True, "n_gpus": ev1["world"],
                           "steps": args.steps, "warmup": args.warmup, "rank_sum": float(ranks[0]),
+                          "rccl": dict(ev0, after_timed_region=ev1),
+                          "ms_per_step_by_rank": {"min": min(ms), "max": max(ms), "all": ms},
                           "value": round(world * args.steps / float(tt[0]), 3), "unit": "token-steps/s"}), flush=True)
     if dist is not None:
         dist.barrier()
@@ -429,6 +466,10 @@ def main():
         dist.init_process_group(backend, **kw)
     torch.cuda.set_device(local_dev)
     dev = torch.device("cuda", local_dev)
+    # the first collective of the run, on the device: how many ranks the process group really spans, and on which devices
+    evidence = collective_evidence(dist, world, rank, backend, dev, torch.cuda.current_device())
+    if evidence["ranks_seen"] != world:
+        raise SystemExit(f"bench.py: WORLD_SIZE={world} but the all-reduce saw {evidence['ranks_seen']} rank(s)")
 
     from tmdiff_amd import ops
     from tmdiff_amd.Hyper_unet_general import WavBEST
@@ -446,7 +487,7 @@ def main():
         if rank == 0:
             obj = train_object(leg, world, args.steps)
             line = {"metric": "finetune train samples/sec (8-ch 64x64 tiles, local batch 8 per GPU)", "value": obj["value"],
-                    "unit": "samples/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+                    "unit": "samples/s", "n_gpus": evidence["world"], "rccl": evidence, "steps": args.steps, "warmup": args.warmup,
                     "ms_per_step": obj["ms_per_step"], "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
                     "dtype": "f32", "data": "synthetic",
                     "config": {"workload": "BASELINE configs[3]: " + obj["what"], "global_batch": 8 * world,
@@ -483,6 +524,8 @@ def main():
     dt = time.perf_counter() - t0
     assert torch.isfinite(x).all()
     log(f"timed region: {args.steps} steps in {dt:.3f} s")
+    rank_ms = per_rank_ms(dist, world, dt, args.steps, dev)
+    evidence = dict(evidence, after_timed_region=collective_evidence(dist, world, rank, backend, dev, torch.cuda.current_device()))
 
     # ---- the same K steps again with a HIP event pair around every conv launch (roofline object).  Kept out of the
     # run that produces `value`; its wall time is reported so the two can be compared. -------------------------------
@@ -547,8 +590,12 @@ def main():
             "metric": "UNet denoise-steps/sec (8-ch 64x64, batch 32)",
             "value": round(world * args.steps / dt, 4),
             "unit": "batch32-steps/s",
-            "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "n_gpus": evidence["world"], "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(dt / args.steps * 1e3, 3),
+            # what the collectives themselves saw (a device SUM all-reduce of ones + an all-gather of device indices, once
+            # after init_process_group and once after the timed region), and every rank's own step time beside the MAX
+            "rccl": evidence,
+            "ms_per_step_by_rank": {"min": min(rank_ms), "max": max(rank_ms), "all": rank_ms},
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "f32", "data": "synthetic",
             "config": {"workload": "BASELINE configs[1]: batch-32 8-ch 64x64 tiles, DDPM p_sample steps of the "

@@ -23,6 +23,22 @@ def test_gpus_2_spawns_two_ranks():
     assert line["n_gpus"] == 2 and line["rank_sum"] == 3.0 and line["steps"] == 2
 
 
+def test_the_line_carries_what_the_collectives_saw():
+    """n_gpus must come from the process group, with the evidence beside it -- a SUM all-reduce of ones
+    (ranks_seen), the all-gathered rank / device / PID lists, taken after init and again after the timed region, and every
+    rank's own step time beside the MAX.  (The real run adds the same object as `rccl`: same function.)"""
+    line = _run("--gpus", "2", "--rehearse", "--steps", "2", "--warmup", "0")
+    ev = line["rccl"]
+    assert ev["world"] == 2 and ev["ranks_seen"] == 2 and ev["backend"] == "gloo" and ev["ranks"] == [0, 1]
+    assert len(ev["device_ids"]) == 2 and len(set(ev["pids"])) == 2            # two processes, not one counted twice
+    after = ev["after_timed_region"]
+    assert after["ranks_seen"] == 2 and after["pids"] == ev["pids"]
+    ms = line["ms_per_step_by_rank"]
+    assert len(ms["all"]) == 2 and ms["min"] <= ms["max"] and ms["min"] > 0
+    one = _run("--gpus", "1", "--rehearse", "--steps", "1")
+    assert one["rccl"]["ranks_seen"] == 1 and one["rccl"]["world"] == 1 and len(one["ms_per_step_by_rank"]["all"]) == 1
+
+
 def test_gpus_1_stays_single_process():
     line = _run("--gpus", "1", "--rehearse", "--steps", "2")
     assert line["n_gpus"] == 1 and line["rank_sum"] == 1.0
