@@ -177,7 +177,7 @@ def cpu_baseline():
 def parity_check(dev):
     """PSNR(build, oracle) of a short DDPM chain with shared noise (the "PSNR vs ref" half of the metric) ON THE KERNEL FAMILY
     THAT PRODUCED `value`: full-width network, two 8x64x64 tiles, T = 10, with the grid-size threshold that keeps small
-    launches on the direct kernels switched off (ops._WINO_MIN_BLOCKS = 1), so that the chain runs on the Winograd kernels
+    launches on the direct kernels switched off (ops.config.wino_min_blocks = 1), so that the chain runs on the Winograd kernels
     (in-kernel transform where the plane has >= 16 columns, transform pass + kernel below) and the composed Conv_0 + LL
     kernel, as the batch-32 workload does.  The launch counts per C entry point are reported.  The oracle is the checker
     here, as in tests/ and smoke()."""
@@ -203,12 +203,12 @@ def parity_check(dev):
     torch.manual_seed(5)
     with torch.no_grad():
         y_ref = want.p_sample_loop(d, continous=False, prompt="WV3")
-    keep, ops._WINO_MIN_BLOCKS, ops.COUNTS = ops._WINO_MIN_BLOCKS, 1, collections.Counter()
+    keep, ops.config.wino_min_blocks, ops.COUNTS = ops.config.wino_min_blocks, 1, collections.Counter()
     try:
         torch.manual_seed(5)
         y = got.p_sample_loop({k: v.to(dev) for k, v in d.items()}, continous=False, prompt="WV3").cpu()
     finally:
-        counts, ops.COUNTS, ops._WINO_MIN_BLOCKS = dict(ops.COUNTS), None, keep
+        counts, ops.COUNTS, ops.config.wino_min_blocks = dict(ops.COUNTS), None, keep
     k3 = {k: v for k, v in counts.items() if not k.endswith("_k1")}
     return {"psnr_db": round(float(psnr(y, y_ref)), 1), "max_abs_diff": float((y - y_ref).abs().max()),
             "launches_by_entry": k3,

@@ -402,6 +402,32 @@ def main():
         arrs[f"{tag}_y"] = m(randn(180, b, c, n, hw, hw))
     save("attnpp", **arrs)
 
+    # ---- (13) SAM (core/metrics.py:91-112), the one validation metric whose arithmetic is NumPy's and therefore reproducible
+    # here: as the driver calls it (general_sharpening_joint_random_batch_finetune.py:145), on H x W x C float32 arrays in
+    # [0, 1]; also float64 inputs, 4 bands, and pixels that produce NaN (a zero spectrum: 0 / 0) or arccos of a ratio that
+    # rounds above 1 (identical spectra) -- both of which the reference turns into 0 / NaN -> 0.  Inputs are stored (small).
+    if not ONLY or "metrics" in ONLY:
+        ref_shims.install_metrics_stand_ins()
+        import warnings
+        with warnings.catch_warnings():
+            warnings.simplefilter("ignore")
+            from core import metrics as RM
+        arrs = {}
+        rng = np.random.default_rng(2024)
+        cases = {"wv3_f32": (24, 20, 8, np.float32), "gf2_f32": (16, 16, 4, np.float32), "wv3_f64": (12, 10, 8, np.float64)}
+        for tag, (h, w, c, dt) in cases.items():
+            hr = rng.random((h, w, c)).astype(dt)
+            sr = np.clip(hr + 0.05 * rng.standard_normal((h, w, c)), 0.0, 1.0).astype(dt)
+            sr[0, 0] = 0                      # a zero spectrum in the prediction: 0 / 0 = NaN -> counted as angle 0
+            hr[1, 1] = 0                      # ... and in the target
+            sr[2, 2] = hr[2, 2]               # identical spectra: ratio ~ 1 (may round above 1 -> NaN -> 0)
+            sr[3, 3] = 3 * hr[3, 3]           # parallel spectra
+            with np.errstate(all="ignore"):
+                arrs[f"{tag}_sam"] = np.float64(RM.SAM_numpy(sr, hr))          # argument order of the driver
+                arrs[f"{tag}_sam_swapped"] = np.float64(RM.SAM_numpy(hr, sr))
+            arrs[f"{tag}_hr"], arrs[f"{tag}_sr"] = hr, sr
+        save("metrics", **arrs)
+
 
 if __name__ == "__main__":
     main()

@@ -105,3 +105,32 @@ def install(text_embeddings):
             return _to(self, *args, **kwargs)
 
         torch.Tensor.to = to
+
+
+def install_metrics_stand_ins():
+    """Import stand-ins for the third-party modules core/metrics.py imports at module scope and this image lacks
+    (skimage.metrics, sewar; torchvision / cv2 as in install()).  Only ``SAM_numpy`` (core/metrics.py:91-112, pure NumPy) is
+    ever EXECUTED through them: the stand-in functions raise if touched, so SSIM / MPSNR (skimage's arithmetic) cannot be
+    produced by accident -- they stay unpinned."""
+    def absent(name):
+        def f(*a, **k):
+            raise RuntimeError(f"{name} is a stand-in: the real package is not in this image")
+        return f
+
+    sk, skm = types.ModuleType("skimage"), types.ModuleType("skimage.metrics")
+    skm.structural_similarity = absent("skimage.metrics.structural_similarity")
+    skm.peak_signal_noise_ratio = absent("skimage.metrics.peak_signal_noise_ratio")
+    sk.metrics = skm
+    sewar = types.ModuleType("sewar")
+    for fn in ("ssim", "sam", "scc", "ergas", "psnr"):
+        setattr(sewar, fn, absent("sewar." + fn))
+    sys.modules.update({"skimage": sk, "skimage.metrics": skm, "sewar": sewar})
+    if "cv2" not in sys.modules:
+        sys.modules["cv2"] = types.ModuleType("cv2")
+    if "torchvision" not in sys.modules:
+        tv, tvu = types.ModuleType("torchvision"), types.ModuleType("torchvision.utils")
+        tvu.make_grid = absent("torchvision.utils.make_grid")
+        tv.utils = tvu
+        sys.modules.update({"torchvision": tv, "torchvision.utils": tvu})
+    if REFERENCE_ROOT not in sys.path:
+        sys.path.insert(0, REFERENCE_ROOT)

@@ -14,6 +14,8 @@ GOLDEN = os.path.join(ROOT, "tests", "golden")
 
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+    config.addinivalue_line("markers", "fallback: exercises tmdiff_amd.fallback (kernels no BASELINE configuration reaches); "
+                                       "these tests are gpu tests too and run in the same session")
 
 
 def pytest_collection_modifyitems(config, items):

@@ -419,11 +419,11 @@ def test_weight_gradient_in_the_winograd_domain(case):
     l2 = float((dw.cpu().double() - wd.grad).norm() / wd.grad.norm())
     print(f"winograd wgrad {case}: max err / max |dw| {err:.2e}, rel-L2 {l2:.2e}")
     assert err <= 1e-5 and l2 <= 3e-6
-    keep, ops._WGRAD_WINO = ops._WGRAD_WINO, False
+    keep, ops.config.wgrad_wino = ops.config.wgrad_wino, False
     try:
         direct = ops.conv3d_wgrad(d, gd, tuple(wd.shape))
     finally:
-        ops._WGRAD_WINO = keep
+        ops.config.wgrad_wino = keep
     l2d = float((direct.cpu().double() - wd.grad).norm() / wd.grad.norm())
     print(f"   direct kernel rel-L2 {l2d:.2e}")
     assert float((dw - direct).abs().max()) / scale <= 1e-5

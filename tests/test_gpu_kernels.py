@@ -691,6 +691,7 @@ def test_space_to_depth_second_output_in_every_tile_mode(ops, shape):
     (1, (4,), 64, 12, 8, 8, 1),           # N = 12: three tiles, the second tile of the last workgroup is empty
     (1, (4,), 32, 16, 8, 16, 1),          # N = 16: two workgroups along the bands
 ])
+@pytest.mark.fallback
 def test_conv3d_winograd_along_bands(ops, case):
     """tmdiff_conv3d_wino_fwd: Winograd F(4,3) (N % 4 == 0) / F(2,3) along the band axis (input transform pass with the
     prologue + 54- / 36-tap kernel + output transform at the end of the tile) against the CPU convolution (fp64) and the direct HIP kernel; prologue, bias, residual,
@@ -704,16 +705,17 @@ def test_conv3d_winograd_along_bands(ops, case):
     sh, sc = torch.randn(B, cin) * 0.3, torch.rand(B, cin) + 0.5
     res = torch.randn(B, cout, N, H, W)
     sh2, sc2 = torch.randn(B, cout) * 0.3, torch.rand(B, cout) + 0.5
-    wp = ops.pack_conv_weight_wino(cu(w), groups=groups, planes=ops.wino_planes(N))     # F(4,3) for N % 4 == 0, else F(2,3)
+    from tmdiff_amd import fallback, routing
+    wp = ops.pack_conv_weight_wino(cu(w), groups=groups, planes=fallback.wino_planes(N))     # F(4,3) for N % 4 == 0, else F(2,3)
     want = F.conv3d(x.double(), w.double(), bias.double(), padding=1, groups=groups).float()
-    y = ops.conv3d_wino([cu(s_) for s_ in segs], wp, cout, bias=cu(bias), groups=groups)
+    y = fallback.conv3d_wino([cu(s_) for s_ in segs], wp, cout, bias=cu(bias), groups=groups)
     assert_close(y, want, 2e-5, 2e-6, "winograd, plain input")
     xs = x.double() + sh[:, :, None, None, None].double()
     xs = xs * torch.sigmoid(xs) * sc[:, :, None, None, None].double()
     want = ((F.conv3d(xs, w.double(), bias.double(), padding=1, groups=groups) + res.double()) * 0.7071).float()
     v = want + sh2[:, :, None, None, None]
     want2 = v * torch.sigmoid(v) * sc2[:, :, None, None, None]
-    y, y2 = ops.conv3d_wino([cu(s_) for s_ in segs], wp, cout, bias=cu(bias), in_shift=cu(sh), in_scale=cu(sc), in_act=True,
+    y, y2 = fallback.conv3d_wino([cu(s_) for s_ in segs], wp, cout, bias=cu(bias), in_shift=cu(sh), in_scale=cu(sc), in_act=True,
                             residual=cu(res), out_scale=0.7071, emit=dict(act=True, shift=cu(sh2), scale=cu(sc2)), groups=groups)
     assert_close(y, want, 2e-5, 2e-6, "winograd, prologue + residual")
     assert_close(y2, want2, 2e-5, 2e-6, "winograd, second output")
@@ -722,16 +724,25 @@ def test_conv3d_winograd_along_bands(ops, case):
     assert_close(y, direct.cpu(), 1e-5, 1e-6, "winograd vs the direct kernel")
     # in-kernel dropout of the prologue output (finetune path): the same keep mask as the direct kernels, and x' kept
     xp = torch.empty(B, cin, N, H, W, device="cuda")
-    yd = ops.conv3d_wino([cu(s_) for s_ in segs], wp, cout, in_shift=cu(sh), in_act=True, drop=(1234, 0.2), groups=groups, xp_out=xp)
+    yd = fallback.conv3d_wino([cu(s_) for s_ in segs], wp, cout, in_shift=cu(sh), in_act=True, drop=(1234, 0.2), groups=groups, xp_out=xp)
     staged = (cin // groups) % 4 == 0            # (the direct path keeps x' only on its staged kernel)
     xp_d = torch.empty_like(xp) if staged else None
     dd = ops.conv3d([cu(s_) for s_ in segs], ops.pack_conv_weight(cu(w), groups=groups), cout, 3, groups=groups, in_shift=cu(sh),
                     in_act=True, drop=(1234, 0.2), xp_out=xp_d)
     assert 0.1 < float((xp == 0).float().mean()) < 0.3 and (not staged or torch.equal(xp, xp_d))
     assert_close(yd, dd.cpu(), 1e-5, 1e-6, "winograd vs the direct kernel, dropout")
-    # a grid too small for the kernel (no split-K) or an odd band count goes to the fallback
-    marker = object()
-    assert ops.conv3d_wino([cu(s_[:, :, :N - 1]) for s_ in segs], wp, cout, groups=groups, fallback=lambda: marker) is marker
+    # a grid too small for the kernel (no split-K) or an odd band count is routed to the direct kernels; a large grid of a
+    # band count conv3d_wf does not take (not 4 / 8) is what reaches this module
+    assert routing.conv3_family(B, cin, cout, N - 1, H, W, groups) in ("staged", "fused")
+    assert routing.conv3_family(B, cin, cout, N, H, W, groups) in ("staged", "fused", "wf", "wf_pair")     # (small test grids)
+    with ops.config.override(wino_min_blocks=1):
+        fam = routing.conv3_family(B, cin, cout, N, H, W, groups)
+        assert fam == ("wino4" if fallback.wino_planes(N) == 6 else "wino2") if N not in (4, 8) or W < 16 else fam in ("wf", "wf_pair", "wino4", "wino2")
+        if N not in (4, 8):        # ... and ops.conv3d_auto dispatches here, with the same bits
+            weights = ops.ConvWeights(lambda: ops.pack_conv_weight(cu(w), groups=groups), None,
+                                      lambda planes: ops.pack_conv_weight_wino(cu(w), groups=groups, planes=planes))
+            auto = ops.conv3d_auto([cu(s_) for s_ in segs], weights, cout, groups=groups, bias=cu(bias))
+            assert torch.equal(auto, fallback.conv3d_wino([cu(s_) for s_ in segs], wp, cout, bias=cu(bias), groups=groups))
 
 
 @pytest.mark.parametrize("case", [
@@ -787,7 +798,8 @@ def test_conv3d_winograd_in_kernel_transform(ops, case):
     assert torch.equal(only, y2)
     direct = ops.conv3d([cu(s_) for s_ in segs], ops.pack_conv_weight(cu(w), groups=groups), cout, 3, **kw)
     assert_close(y, direct.cpu(), 1e-5, 2e-6, "wf vs the direct kernel")
-    old = ops.conv3d_wino([cu(s_) for s_ in segs], ops.pack_conv_weight_wino(cu(w), groups=groups, planes=ops.wino_planes(N)), cout, **kw)
+    from tmdiff_amd import fallback, routing
+    old = fallback.conv3d_wino([cu(s_) for s_ in segs], ops.pack_conv_weight_wino(cu(w), groups=groups, planes=fallback.wino_planes(N)), cout, **kw)
     assert_close(y, old.cpu(), 1e-5, 2e-6, "wf vs the transform-pass Winograd kernel")
     # in-kernel dropout of the prologue output (finetune path) and the kept x'
     xp = torch.empty(B, cin, N, H, W, device="cuda")
@@ -804,9 +816,11 @@ def test_conv3d_winograd_in_kernel_transform(ops, case):
     if (cout // groups) % 2 == 0 and (cin // groups) % 32 == 0:
         dx = ops.conv3d_wf([cu(g)], ops.pack_conv_weight_wino(cu(w), groups=groups, mode=3, planes=6), cin, groups=groups)
         assert_close(dx, xg.grad.float(), 2e-5, 2e-6, "wf data gradient vs CPU autograd")
-    # an odd band count / a mask tensor goes to the fallback
-    marker = object()
-    assert ops.conv3d_wf([cu(x[:, :, :N - 1])], wp, cout, groups=groups, fallback=lambda: marker) is marker
+    # an odd band count / a mask tensor is never routed here (and the kernel itself refuses the shape)
+    assert routing.conv3_family(B, cin, cout, N - 1, H, W, groups) in ("staged", "fused")
+    assert routing.conv3_family(B, cin, cout, N, H, W, groups, masked=True) in ("staged", "fused")
+    with pytest.raises(ValueError):
+        ops.conv3d_wf([cu(x[:, :, :N - 1])], wp, cout, groups=groups)
 
 
 @pytest.mark.parametrize("case", [
@@ -816,6 +830,7 @@ def test_conv3d_winograd_in_kernel_transform(ops, case):
     (1, 64, 64, 4, 8, 16, 1),             # F(2,3)
     (1, 96, 192, 8, 8, 8, 3),             # groups = 3
 ])
+@pytest.mark.fallback
 def test_conv3d_winograd_data_gradient_weights(ops, case):
     """mode-1 packing of tmdiff_conv3d_wino_pack_weights: the Winograd weights of the DATA-GRADIENT convolution (transposed,
     taps mirrored) straight from the forward weight -- against CPU autograd's grad_input (fp64) and the direct kernel on
@@ -828,8 +843,9 @@ def test_conv3d_winograd_data_gradient_weights(ops, case):
     with torch.enable_grad():             # (the module's fixture runs every test under no_grad)
         F.conv3d(x, w.double(), None, padding=1, groups=groups).backward(g.double())
     want = x.grad.float()
-    wp1 = ops.pack_conv_weight_wino(cu(w), groups=groups, mode=1, planes=ops.wino_planes(N))
-    dx = ops.conv3d_wino([cu(g)], wp1, cin, groups=groups)
+    from tmdiff_amd import fallback
+    wp1 = ops.pack_conv_weight_wino(cu(w), groups=groups, mode=1, planes=fallback.wino_planes(N))
+    dx = fallback.conv3d_wino([cu(g)], wp1, cin, groups=groups)
     assert_close(dx, want, 2e-5, 2e-6, "winograd data gradient vs CPU autograd")
     direct = ops.conv3d([cu(g)], ops.pack_conv_weight(cu(w), groups=groups, mode=1), cin, 3, groups=groups)
     assert_close(dx, direct.cpu(), 1e-5, 2e-6, "winograd data gradient vs the direct kernel")   # (F(4,3): 1e-6 vs fp64 by itself)

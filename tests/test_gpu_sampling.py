@@ -144,12 +144,12 @@ def pair_full():
 @pytest.fixture
 def production_kernels(monkeypatch):
     """The kernel family that produces bench.py's `value` -- Winograd F(4,3) / F(2,3) along the bands and the composed
-    Conv_0 + LL convolution -- forced onto small tiles: `ops._WINO_MIN_BLOCKS` (TMDIFF_WINO_MIN_BLOCKS) normally keeps
+    Conv_0 + LL convolution -- forced onto small tiles: `ops.config.wino_min_blocks` (TMDIFF_WINO_MIN_BLOCKS) normally keeps
     grids of fewer than 256 workgroups on the direct kernels, so chain tests on one or two tiles would never reach them.
     Yields a Counter of convolution launches per C entry point."""
     import collections
     from tmdiff_amd import ops
-    monkeypatch.setattr(ops, "_WINO_MIN_BLOCKS", 1)
+    monkeypatch.setattr(ops.config, "wino_min_blocks", 1)
     counts = collections.Counter()
     monkeypatch.setattr(ops, "COUNTS", counts)
     yield counts

@@ -178,6 +178,62 @@ def test_training_step_with_dropout_runs_and_descends():
     assert min(losses[4:]) < losses[0]
 
 
+def test_packed_weights_follow_a_deep_copy_and_ignore_foreign_weights():
+    """(1) copy.deepcopy of a network that has already trained must not keep the source's Winograd pack -- its
+    device table held the SOURCE network's raw addresses, and the copy's first refresh re-packed the source's memory (a
+    use-after-free once the source is gone).  forward_train, deepcopy, delete the original, forward_train on the copy: same
+    loss and gradients as a fresh network with the same weights.  (2) a convolution on a weight that does not belong to the
+    network whose pack is current is packed on the spot and never registered."""
+    import copy
+    import gc
+    from tmdiff_amd import autograd as A
+    from tmdiff_amd import ops
+    from tmdiff_amd.Hyper_unet_general import WavBEST
+    FULLC = [32, 64, 128, 256]
+    d = case_inputs(991, 8, 8, 32)          # B = 8 at 32x32: the 32x32 / 16x16 levels run conv3d_wf (multi-tensor pack in use)
+    t = torch.arange(1, 9).reshape(8, 1) * 100
+
+    def step(net):
+        net.zero_grad()
+        out = net(cu(d["x_t"]), t.cuda(), cu(d["PAN"]), cu(d["MS"]), "WV3")
+        out.square().mean().backward()
+        return float(out.square().mean()), net.down1.conv20.conv21.weight.grad.clone(), net.up2.up1.Conv_1.weight.grad.clone()
+
+    net = U.fill_weights_(WavBEST(channels=FULLC)).cuda().train()
+    net.requires_grad_(True)
+    for m in net.modules():
+        if isinstance(m, torch.nn.Dropout):
+            m.p = 0.0
+    want = step(net)
+    pack = net.__dict__["_train_pack_wino"]
+    assert len(pack.items) >= 20                              # the pack is really in use at this size
+    twin = copy.deepcopy(net)
+    assert "_train_pack_wino" not in twin.__dict__ and "_train_pack" not in twin.__dict__ and twin._prep is None
+    del net, pack
+    ops.PACKED = ops.WINO_PACKED = None
+    gc.collect()
+    torch.cuda.empty_cache()
+    junk = torch.full((64 << 20,), float("nan"), device="cuda")       # whatever reuses the freed memory is poison
+    got = step(twin)
+    del junk
+    assert got[0] == want[0] and torch.equal(got[1], want[1]) and torch.equal(got[2], want[2])
+    tpack = twin.__dict__["_train_pack_wino"].refresh()      # (the step after the learning one builds the device table)
+    n_items = len(tpack.items)
+    key0 = tpack._table_key
+    assert n_items >= 20 and key0 is not None
+    # (2) a foreign weight while the twin's pack is the current one
+    w = torch.randn(32, 32, 3, 3, 3, device="cuda", requires_grad=True)
+    x = torch.randn(8, 32, 8, 32, 32, device="cuda")
+    with ops.config.override(wino_min_blocks=1):
+        y = A.conv3d([x], w, None)
+        y.sum().backward()
+    assert len(tpack.items) == n_items and tpack._table_key == key0
+    tpack.refresh()
+    assert len(tpack.items) == n_items and tpack._table_key == key0      # nothing to rebuild, nothing kept alive
+    got2 = step(twin)
+    assert got2[0] == want[0] and torch.equal(got2[1], want[1])
+
+
 def test_trainer_wrapper_roundtrip(tmp_path):
     """DDPM wrapper (reference model.py API): train steps, EMA, save -> load into a fresh wrapper, test()."""
     import copy

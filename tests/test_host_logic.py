@@ -158,6 +158,25 @@ def test_metrics_against_direct_formulas():
     assert abs(M.mpsnr(a.permute(2, 0, 1), b.permute(2, 0, 1), hwc=False) - want) < 1e-6
 
 
+def test_sam_against_the_reference_fixture(golden):
+    """N2, the pinnable part: tests/golden/metrics.npz holds SAM_numpy (core/metrics.py:91-112) of the REFERENCE on float32
+    and float64 H x W x C arrays with zero / identical / parallel spectra among the pixels.  Same dtype, same operations:
+    the float32 cases must agree to float32 rounding of the mean (they agree exactly here), float64 likewise."""
+    from tmdiff_amd import metrics as M
+    g = golden("metrics")
+    for tag in ("wv3_f32", "gf2_f32", "wv3_f64"):
+        hr, sr = g[f"{tag}_hr"], g[f"{tag}_sr"]
+        assert abs(M.sam(sr, hr) - float(g[f"{tag}_sam"])) <= 1e-12 * max(1.0, float(g[f"{tag}_sam"])), tag
+        assert abs(M.sam(hr, sr) - float(g[f"{tag}_sam_swapped"])) <= 1e-12, tag
+        # tensors and the [C, H, W] layout go through the same arithmetic
+        assert M.sam(torch.from_numpy(sr), torch.from_numpy(hr)) == M.sam(sr, hr)
+        assert M.sam(np.moveaxis(sr, -1, 0), np.moveaxis(hr, -1, 0), hwc=False) == M.sam(sr, hr)
+    # the dtype matters: the float32 fixture evaluated in float64 is a different number (identical spectra give exactly 0
+    # there, a rounding-sized angle or NaN -> 0 in float32)
+    hr, sr = g["wv3_f32_hr"], g["wv3_f32_sr"]
+    assert M.sam(sr.astype(np.float64), hr.astype(np.float64)) != M.sam(sr, hr)
+
+
 def test_tiling_helpers_roundtrip():
     from tmdiff_amd import tiling as T
     x = torch.arange(2 * 3 * 8 * 12, dtype=torch.float32).reshape(2, 3, 8, 12)
@@ -358,6 +377,38 @@ def test_winograd_transform_choice_and_sizes():
     assert lib.tmdiff_conv3d_wino_packed_bytes(48, 32, 1, 6) == 0                          # Cout / groups not a multiple of 32
     assert lib.tmdiff_conv3d_wino_packed_bytes(64, 32, 1, 5) == 0                          # planes is 4 or 6
     assert lib.tmdiff_conv3d_ll_packed_bytes(64, 32) == 32 * 48 * 64 * 4
+
+
+def test_routing_table_of_the_baseline_configs():
+    """every 3x3x3 convolution of BASELINE configs[0..4] (B in {1, 8, 32}, 4 / 8 bands, 64^2 / 256^2 planes, both
+    widths, fp32 and bf16) walked through tmdiff_amd.routing -- the table committed as profiles/r04_routing_table.txt
+    (tools/routing_table.py).  Every family of the product path is reached by a BASELINE case, except the general-shape direct
+    kernel ("fused"), which the reference's default widths reach; the transform-pass Winograd families (tmdiff_amd.fallback) are
+    reached by none."""
+    import collections
+    from tmdiff_amd import ops, routing
+    assert ops.config.as_dict() == ops.KernelConfig(env={}).as_dict(), "this table is that of the default switches"
+    reached = collections.Counter()
+    for label, ch, b, n, size, math in routing.BASELINE_CASES:
+        rows = routing.unet_table(ch, b, n, size, size, math)
+        assert len(rows) == 51, label                              # the 51 3x3x3 convolutions of one forward
+        assert all(f in routing.PRODUCT_FAMILIES for _, f in rows), (label, [f for _, f in rows if f not in routing.PRODUCT_FAMILIES])
+        reached.update(f for _, f in rows)
+    assert set(reached) == set(routing.PRODUCT_FAMILIES) - {"fused"}, dict(reached)
+    other = collections.Counter(f for _, ch, b, n, size, math in routing.OTHER_CASES for _, f in routing.unet_table(ch, b, n, size, size, math))
+    assert "fused" in other and not (set(other) & set(routing.FALLBACK_FAMILIES)), dict(other)
+    # the benchmark workload: nothing but conv3d_wf (pair mode at the 8x8 level) and its composed-LL mode
+    bench = collections.Counter(f for _, f in routing.unet_table(routing.FULL, 32, 8, 64, 64))
+    assert bench == {"wf": 40, "wf_pair": 8, "wfll": 3}, dict(bench)
+    # what DOES reach the fallback module: even band counts other than 4 / 8 on grids that fill the chip
+    assert routing.conv3_family(32, 64, 64, 12, 64, 64) == "wino4" and routing.conv3_family(32, 64, 64, 6, 64, 64) == "wino2"
+    assert routing.conv3_family(1, 64, 64, 12, 16, 16) in ("staged", "fused")          # ... small grids stay direct
+    # the committed table is this code's table
+    import subprocess, sys
+    path = os.path.join(ROOT, "profiles", "r04_routing_table.txt")
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "routing_table.py")], capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0, out.stderr[-1000:]
+    assert out.stdout == open(path).read(), "profiles/r04_routing_table.txt is stale: python tools/routing_table.py > " + path
 
 
 def test_kernel_routing_rules_and_support_queries():

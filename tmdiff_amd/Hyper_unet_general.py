@@ -22,7 +22,6 @@ dict prompt -> [1,768] tensor, or a path to a torch-saved dict) injects the pool
 defaulting to fixed seeded vectors (``synthetic_text_embeddings``).
 """
 import math
-import os
 
 import torch
 import torch.nn as nn
@@ -30,13 +29,7 @@ import torch.nn as nn
 from . import ops
 
 PROMPTS = ("QB", "WV3", "GF2", "WV2", "WV4")
-_EPILOGUE_FUSE = os.environ.get("TMDIFF_EPILOGUE_FUSE", "1") != "0"   # experiments: "0" = consumers apply their own prologue
-_CONV2_AFTER_LL = os.environ.get("TMDIFF_CONV2_AFTER_LL", "1") != "0"   # experiments: "0" = Conv_2 of a down block at full resolution, as the reference orders it
-_WINOGRAD = os.environ.get("TMDIFF_WINOGRAD", "1") != "0"     # experiments: "0" = every 3x3x3 convolution on the direct kernels
-_LL_COMPOSE = os.environ.get("TMDIFF_LL_COMPOSE", "1") != "0"   # experiments: "0" = Conv_0 at full resolution + LL-only DWT where the high bands are dropped
-_WINO_MULTIPACK = os.environ.get("TMDIFF_WINO_MULTIPACK", "1") != "0"   # experiments: "0" = the Winograd weights of a finetune step packed one launch per (weight, form)
-_PRODUCER_FUSE = os.environ.get("TMDIFF_PRODUCER_FUSE", "1") != "0"   # experiments: "0" = only the conv20 -> conv21 exchange
-
+# (behaviour switches: ops.config)
 
 def synthetic_text_embeddings(seed=1234):
     """prompt -> randn(1,768) from a CPU generator seeded ``seed + index``."""
@@ -178,12 +171,12 @@ class WaveletUPorDown(nn.Module):
     def run(self, x, shift, scale, skipH=None, want_high=True):
         from . import autograd as A
         # down, high bands dropped: Conv_0 + halved LL band as one strided convolution (autograd._ConvLL)
-        ll = (self.down and not want_high and _LL_COMPOSE and
+        ll = (self.down and not want_high and ops.config.ll_compose and
               ops.ll_conv_supported(self.Conv_0.out_channels, self.Conv_0.in_channels, 3, 1) and
               x.shape[3] % 2 == 0 and x.shape[4] % 2 == 0)
         hh = None if ll else A.conv3d([x], self.Conv_0.weight, self.Conv_0.bias, act=True)
         # down: Conv_2 commutes with the halved LL band (see WavBEST._down), so it runs after it, on a quarter of the positions
-        xx = None if self.down and _CONV2_AFTER_LL else A.conv3d([x], self.Conv_2.weight, self.Conv_2.bias)
+        xx = None if self.down and ops.config.conv2_after_ll else A.conv3d([x], self.Conv_2.weight, self.Conv_2.bias)
         hH = None
         if self.up:
             ch = self.convH_0[0]
@@ -339,7 +332,7 @@ class WavBEST(nn.Module):
     # ---- weight-dependent preparation (redone when any parameter changes) --------------------------
     def _prepare(self):
         params = list(self.parameters())
-        key = (tuple(p._version for p in params), tuple(p.data_ptr() for p in params), self.compute_dtype)
+        key = (tuple(p._version for p in params), tuple(p.data_ptr() for p in params), self.compute_dtype, ops.config.key())
         if self._prep is not None and self._prep["key"] == key:
             return self._prep
         dev = params[0].device
@@ -359,18 +352,18 @@ class WavBEST(nn.Module):
                     prep["w"][name] = ops.pack_conv_weight(w, groups=m.groups)
                     # exact-fp32 mode: the 3x3x3 convolutions also in the Winograd F(2,3)-along-n form (csrc/conv3d_wino.hip:
                     # 1.5x fewer multiply-adds; taken when the band count is even and the grid fills the chip)
-                    if _WINOGRAD and ops.wino_conv_supported(m.out_channels, m.in_channels, m.kernel_size[0], m.groups):
+                    if ops.config.winograd and ops.wino_conv_supported(m.out_channels, m.in_channels, m.kernel_size[0], m.groups):
                         prep["w_wino"][name] = {}      # packed on first use, per plane count of the transform (the band count decides)
         # Conv_0 of the main branch's down blocks is followed by an LL-only DWT (its high bands are dropped): the pair runs
         # as one strided convolution on composed weights (csrc/conv3d_ll.hip), exact-fp32 mode only
-        if self.compute_dtype == "fp32" and _LL_COMPOSE:
+        if self.compute_dtype == "fp32" and ops.config.ll_compose:
             for blk in ("down1", "down2", "down3"):
                 m = self.get_submodule(blk + ".down.Conv_0")
                 if ops.ll_conv_supported(m.out_channels, m.in_channels, m.kernel_size[0], m.groups):
                     prep["w_ll"][blk + ".down.Conv_0"] = ops.pack_conv_weight_ll(m.weight.detach().float().contiguous(), 0.5)
                     # ... and with Winograd along the bands on top (conv3d_wf's composed-LL mode), for the launches whose producer
                     # can hand over its second output in space-to-depth form (_ll_s2d)
-                    if _WINOGRAD and ops._WFLL and m.out_channels % 32 == 0:
+                    if ops.config.winograd and ops.config.wfll and m.out_channels % 32 == 0:
                         prep["w_wfll"][blk + ".down.Conv_0"] = ops.pack_conv_weight_wfll(m.weight.detach().float().contiguous(), 0.5)
         shift, scale = [], []
         for name, m in self.named_modules():
@@ -392,27 +385,27 @@ class WavBEST(nn.Module):
 
     # ---- fused building blocks -------------------------------------------------------------------
     def _conv(self, P, name, segs, use_bias=True, bias_scale=1.0, **kw):
+        """One convolution of the fused inference graph on the kernel family tmdiff_amd.routing picks for its extents."""
         m = self.get_submodule(name)
         bias = m.bias.detach() if (use_bias and m.bias is not None) else None
-        direct = lambda: ops.conv3d(segs, P["w"][name], m.out_channels, m.kernel_size[0], groups=m.groups,
-                                    math="bf16" if name in P["bf16"] else "fp32", bias=bias, bias_scale=bias_scale, **kw)
-        ww = P["w_wino"].get(name)
-        if ww is None or kw.get("x_bf16_shape") is not None:
-            return direct()
-        def packed(planes):
+        math = "bf16" if name in P["bf16"] else "fp32"
+        if m.kernel_size[0] != 3:
+            return ops.conv3d(segs, P["w"][name], m.out_channels, m.kernel_size[0], groups=m.groups, math=math, bias=bias,
+                              bias_scale=bias_scale, **kw)
+        ww = P["w_wino"].get(name)        # the Winograd forms of this weight, packed on first use (None: shape not taken)
+
+        def packed(planes):               # transform-pass kernels (tmdiff_amd.fallback): per plane count of the transform
             if planes not in ww:
                 ww[planes] = ops.pack_conv_weight_wino(m.weight.detach().float().contiguous(), groups=m.groups, planes=planes)
             return ww[planes]
-        def packed_wf():          # the F(4,3) weights in natural column order (conv3d_wf's 32-channel tiles)
+
+        def packed_wf():                  # conv3d_wf: F(4,3), natural column order (32-channel tiles)
             if "wf" not in ww:
                 ww["wf"] = ops.pack_conv_weight_wino(m.weight.detach().float().contiguous(), groups=m.groups, mode=2, planes=6)
             return ww["wf"]
-        wino = lambda: ops.conv3d_wino(segs, None, m.out_channels, bias=bias, bias_scale=bias_scale, fallback=direct,
-                                       groups=m.groups, w_packed_fn=packed, **kw)
-        # 8- / 4-band tensors: the Winograd kernel that transforms its input in LDS (no transform pass); other even band
-        # counts: transform pass + kernel; small grids and odd band counts: the direct kernels
-        return ops.conv3d_wf(segs, None, m.out_channels, bias=bias, bias_scale=bias_scale, fallback=wino, groups=m.groups,
-                             w_packed_fn=packed_wf, **kw)
+
+        weights = ops.ConvWeights(lambda: P["w"][name], packed_wf if ww is not None else None, packed if ww is not None else None)
+        return ops.conv3d_auto(segs, weights, m.out_channels, groups=m.groups, math=math, bias=bias, bias_scale=bias_scale, **kw)
 
     @staticmethod
     def _shift(P, S, name):
@@ -452,7 +445,7 @@ class WavBEST(nn.Module):
         # (no prologue / pack pass in between; same bits either way)
         both16 = name + ".conv20" in P["bf16"] and name + ".conv21" in P["bf16"]
         kw = {} if emit is None else {"emit": emit}
-        if _EPILOGUE_FUSE and (both16 or (name + ".conv20" not in P["bf16"] and name + ".conv21" not in P["bf16"])):
+        if ops.config.epilogue_fuse and (both16 or (name + ".conv20" not in P["bf16"] and name + ".conv21" not in P["bf16"])):
             mid = dict(act=True, scale=sc["in_scale"], scale_stride=sc["scale_stride"])
             if pre is not None:     # (bf16 mode: `pre` is the packed bf16 form a bf16 producer wrote)
                 t1p = self._conv(P, name + ".conv20", [pre], keep_y=False, emit=mid,
@@ -471,7 +464,7 @@ class WavBEST(nn.Module):
         """True when the main branch's down block `blk` runs Conv_0 + LL as conv3d_wf_ll: its weights exist, the ResBlock in
         front ends in a conv3d_wf launch that does not split its input channels (only that epilogue writes the space-to-depth
         form), and the composed convolution's own grid is taken by the kernel.  h: the ResBlock's input."""
-        if not _EPILOGUE_FUSE or P["w_wfll"].get(blk + ".down.Conv_0") is None:
+        if not ops.config.epilogue_fuse or P["w_wfll"].get(blk + ".down.Conv_0") is None:
             return False
         c21, c0 = blk + ".conv20.conv21", self.get_submodule(blk + ".down.Conv_0")
         if P["w_wino"].get(c21) is None or c21 in P["bf16"] or (blk + ".conv20.conv20") in P["bf16"]:
@@ -499,7 +492,7 @@ class WavBEST(nn.Module):
         # Both are linear and act on different axes (channels / the 2x2 pixel block), and the halved LL band of a
         # constant is that constant, so LL(Conv_2(x)) / 2 == Conv_2(LL(x) / 2): the convolution runs on a quarter of
         # the positions and the full-resolution intermediate is never written (same value up to fp32 summation order).
-        if _CONV2_AFTER_LL:
+        if ops.config.conv2_after_ll:
             xll = self._conv(P, name + ".Conv_2", [ops.haar_dwt2d(x, want_high=False, ll_scale=0.5)[0]])
         else:
             xll = ops.haar_dwt2d(self._conv(P, name + ".Conv_2", [x]), want_high=False, ll_scale=0.5)[0]
@@ -553,7 +546,7 @@ class WavBEST(nn.Module):
         """(conv -> conv edges, wavelet / stem producers): the first in both compute modes (in the bf16 mode the second
         output is the packed bf16 form, and only if every MFMA convolution of the network runs on the bf16 kernels), the
         second likewise (fp32 tensors, or the packed bf16 units from the *_pack_bf16 variants of the DWT / IDWT / stem)."""
-        if not (_PRODUCER_FUSE and _EPILOGUE_FUSE):
+        if not (ops.config.producer_fuse and ops.config.epilogue_fuse):
             return False, False
         if self.compute_dtype == "fp32":
             return True, True
@@ -638,6 +631,17 @@ class WavBEST(nn.Module):
         self.__dict__.pop("_train_pack", None)       # the training path's packed weights (ops.PackedWeights)
         self.__dict__.pop("_train_pack_wino", None)
 
+    _DERIVED = ("_train_pack", "_train_pack_wino", "_emb_dev", "_freqs_dev")
+
+    def __getstate__(self):
+        """copy.deepcopy / pickle: everything derived from the parameters' ADDRESSES stays behind (packed weights and their
+        device tables of raw pointers, projection banks, the condition cache, device copies of constants) -- the copy
+        rebuilds them from its own tensors on first use.  ADVICE r3: a deep copy of a network that had already trained kept
+        a table pointing at the source network's weights."""
+        state = {k: v for k, v in self.__dict__.items() if k not in self._DERIVED}
+        state["_prep"] = state["_cond"] = None
+        return state
+
     # ---- forward ------------------------------------------------------------------------------------
     def forward(self, x_t, t_input, PAN=None, MS=None, prompt=None):
         """Reference ``WavBEST.forward`` (:600-636).  Under ``torch.no_grad()`` (sampling) this is the fused
@@ -715,9 +719,9 @@ class WavBEST(nn.Module):
         ops.PACKED = pk.refresh()
         # ... and the Winograd (conv3d_wf) forms of the 3x3x3 weights, forward and data gradient, in one more
         wk = self.__dict__.get("_train_pack_wino")
-        if wk is None:
-            wk = self.__dict__["_train_pack_wino"] = ops.WinoPackedWeights()
-        ops.WINO_PACKED = wk.refresh() if _WINO_MULTIPACK else None
+        if wk is None:     # (owner = this network's weights: a foreign weight is packed on the spot, never registered)
+            wk = self.__dict__["_train_pack_wino"] = ops.WinoPackedWeights(owner=[w for w, _ in pk.convs])
+        ops.WINO_PACKED = wk.refresh() if ops.config.wino_multipack else None
         lin = lambda seq, i, x, act: A.linear(x, seq[i].weight, seq[i].bias, act=act)
         pe = self._prompt_rows(prompt, b, dev)
         pemb = lin(self.embed2, 4, lin(self.embed2, 2, lin(self.embed2, 0, pe, True), True), True)

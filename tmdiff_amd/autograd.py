@@ -13,14 +13,9 @@ from . import ops
 from ._lib import check, lib
 
 
-import os as _os
-# "1": the bias gradient is accumulated inside the weight-gradient kernel (tmdiff_conv3d_wgrad_bias) instead of a
-# tmdiff_channel_sum pass over g.  Measured on one box, same process pair: 43.4 vs 43.2 ms per finetune step -- the saved
-# pass (0.6 ms of launches) is paid back inside the MFMA stream -- so the separate pass stays the default.
-_WINOGRAD = _os.environ.get("TMDIFF_WINOGRAD", "1") != "0"     # experiments: "0" = direct kernels for every convolution
-_WGRAD_BIAS = _os.environ.get("TMDIFF_WGRAD_BIAS", "0") == "1"
-_LL_WINO = _os.environ.get("TMDIFF_TRAIN_LL_WINO", "1") != "0"   # experiments: "0" = the finetune forward's Conv_0 + LL stays on conv3d_ll
-_WGRAD_WINO_BIAS = _os.environ.get("TMDIFF_WGRAD_WINO_BIAS", "1") != "0"   # experiments: "0" = a channel-sum kernel beside the Winograd weight gradient
+# (switches: ops.config -- winograd, wgrad_bias (43.4 vs 43.2 ms per finetune step with the bias gradient inside the direct
+#  weight-gradient kernel: the saved pass is paid back inside the MFMA stream, so the separate pass stays the default),
+#  train_ll_wino, wgrad_wino_bias)
 
 
 class DropSpec(tuple):
@@ -63,22 +58,18 @@ class _FusedConv3d(torch.autograd.Function):
             cin = sum(s.shape[1] for s in segs)
             if cin % groups == 0 and (cin // groups) % 4 == 0 and (cout // groups) % 32 == 0:   # shapes the staged kernel takes
                 xp = torch.empty(b, cin, n, h, wd, device=segs[0].device, dtype=torch.float32)
-        direct = lambda: ops.conv3d(segs, wp, cout, ksize, groups=groups, bias=bias, bias_scale=bias_scale, in_shift=shift,
-                                    in_scale=scale, in_act=act, in_mask=mask, drop=drop, residual=residual,
-                                    out_scale=out_scale, xp_out=xp)
+        kw = dict(bias=bias, bias_scale=bias_scale, in_shift=shift, in_scale=scale, in_act=act, in_mask=mask, drop=drop,
+                  residual=residual, out_scale=out_scale, xp_out=xp)
         cin = sum(s.shape[1] for s in segs)
-        # 3x3x3 convolutions (in-kernel dropout included): Winograd F(2,3) along the band axis (1.5x fewer multiply-adds), where its grid
-        # fills the chip -- otherwise, and for everything else, the direct kernels
-        if _WINOGRAD and mask is None and ops.wino_conv_supported(cout, cin, ksize, groups):
-            kw = dict(bias=bias, bias_scale=bias_scale, in_shift=shift, in_scale=scale, in_act=act, drop=drop, residual=residual,
-                      out_scale=out_scale, groups=groups, xp_out=xp)
-            wino = lambda: ops.conv3d_wino(segs, None, cout, fallback=direct,
-                                           w_packed_fn=lambda planes: ops.pack_conv_weight_wino(w, groups, planes=planes), **kw)
-            # 8- / 4-band tensors: the kernel that transforms its input in LDS (its prologue pass writes x' where the weight
-            # gradient will read it); other even band counts: transform pass + kernel
-            y = ops.conv3d_wf(segs, None, cout, fallback=wino, w_packed_fn=lambda: _wf_weights(w, groups, 2), **kw)
+        # 3x3x3 convolutions (in-kernel dropout included): the family tmdiff_amd.routing picks -- Winograd along the bands where
+        # its grid fills the chip (conv3d_wf's prologue pass writes x' where the weight gradient will read it), else direct
+        if ksize == 3:
+            wino_ok = ops.config.winograd and ops.wino_conv_supported(cout, cin, ksize, groups)
+            weights = ops.ConvWeights(lambda: wp, (lambda: _wf_weights(w, groups, 2)) if wino_ok else None,
+                                      (lambda planes: ops.pack_conv_weight_wino(w, groups, planes=planes)) if wino_ok else None)
+            y = ops.conv3d_auto(segs, weights, cout, groups=groups, **kw)
         else:
-            y = direct()
+            y = ops.conv3d(segs, wp, cout, ksize, groups=groups, **kw)
         ctx.meta = meta
         ctx.nseg = len(segs)
         ctx.drop = drop
@@ -113,7 +104,7 @@ class _FusedConv3d(torch.autograd.Function):
                                   in_act=act, in_mask=mask, drop=ctx.drop)
         if need[1]:   # x' kept by the forward: a plain single-tensor input, no prologue pass inside the weight gradient
             desc_w = ops.make_conv_desc([xp], 0, cout, ksize, dummy, groups=groups) if xp is not None else desc
-            if has_bias and need[2] and (_WGRAD_BIAS or (_WGRAD_WINO_BIAS and ops.wgrad_wino_takes(desc_w))):   # the bias gradient rides along in the weight-gradient kernel
+            if has_bias and need[2] and (ops.config.wgrad_bias or (ops.config.wgrad_wino_bias and ops.wgrad_wino_takes(desc_w))):   # the bias gradient rides along in the weight-gradient kernel
                 desc_w.bias_scale = bias_scale
                 d_w, d_bias = ops.conv3d_wgrad(desc_w, g, tuple(w.shape), want_bias=True)
             else:
@@ -127,14 +118,13 @@ class _FusedConv3d(torch.autograd.Function):
         d_segs = [None] * len(segs)
         if need_x:
             wp_t = ctx.wp_dgrad if ctx.wp_dgrad is not None else ops.pack_conv_weight(w, groups=groups, mode=1)
-            direct = lambda: ops.conv3d([g], wp_t, cin, ksize, groups=groups)
-            if _WINOGRAD and ops.wino_conv_supported(cin, cout, ksize, groups):   # the data gradient is a 3x3x3 convolution too
-                wino = lambda: ops.conv3d_wino([g], None, cin, groups=groups, fallback=direct,
-                                               w_packed_fn=lambda planes: ops.pack_conv_weight_wino(w, groups, mode=1, planes=planes))
-                gp = ops.conv3d_wf([g], None, cin, groups=groups, fallback=wino,      # (a plain input: no pass at all)
-                                   w_packed_fn=lambda: _wf_weights(w, groups, 3))
+            if ksize == 3:     # the data gradient is a 3x3x3 convolution too (a plain input: no pass at all)
+                wino_ok = ops.config.winograd and ops.wino_conv_supported(cin, cout, ksize, groups)
+                weights = ops.ConvWeights(lambda: wp_t, (lambda: _wf_weights(w, groups, 3)) if wino_ok else None,
+                                          (lambda planes: ops.pack_conv_weight_wino(w, groups, mode=1, planes=planes)) if wino_ok else None)
+                gp = ops.conv3d_auto([g], weights, cin, groups=groups)                # dL/dx'
             else:
-                gp = direct()                                                    # dL/dx'
+                gp = ops.conv3d([g], wp_t, cin, ksize, groups=groups)
             outs = [torch.empty_like(s) if need[7 + i] else None for i, s in enumerate(segs)]
             d_shift, d_scale = ops.conv3d_prologue_bwd(desc, gp, outs, [False] * len(segs),
                                                        has_shift and need[3], has_scale and need[4])
@@ -167,7 +157,7 @@ class _ConvLL(torch.autograd.Function):
         d.B, d.N, d.H, d.W, d.Cin, d.Cout, d.groups, d.ksize, d.nseg = b, n, h, wd, cin, cout, 1, 3, 1
         d.seg_c[0], d.seg_x[0], d.in_act = cin, x.data_ptr(), 1
         xp = ops.conv3d_prologue(d, tuple(x.shape))
-        if _LL_WINO and ops.wfll_route(b, cin, cout, n, h, wd):
+        if ops.config.train_ll_wino and ops.wfll_route(b, cin, cout, n, h, wd):
             # with Winograd along the bands on top (conv3d_wf's composed-LL mode): x' once more in space-to-depth form (a copy:
             # the weight gradient keeps reading the plain x'; 28.37 -> 28.19 ms per finetune step)
             xs = xp.view(b, cin, n, h // 2, 2, wd // 2, 2).permute(0, 1, 4, 6, 2, 3, 5).reshape(b, 4 * cin, n, h // 2, wd // 2)
@@ -194,9 +184,8 @@ class _ConvLL(torch.autograd.Function):
             wp_t = pre[1] if pre is not None else ops.pack_conv_weight(w, mode=1)
             # dL/dx': a 3x3x3 convolution of the up-sampled gradient -- Winograd along the bands (13.5 multiply-adds per
             # element; the transposed form of the composed strided convolution would take 12)
-            gp = ops.conv3d_wf([g], None, cin, fallback=lambda: ops.conv3d([g], wp_t, cin, 3),
-                               w_packed_fn=lambda: _wf_weights(w, 1, 3)) if _WINOGRAD else \
-                ops.conv3d([g], wp_t, cin, 3)
+            gp = ops.conv3d_auto([g], ops.ConvWeights(lambda: wp_t, (lambda: _wf_weights(w, 1, 3)) if ops.config.winograd else None),
+                                 cin)
             d_x = torch.empty_like(x)
             ops.conv3d_prologue_bwd(ops.make_conv_desc([x], 0, cout, 3, g, in_act=True), gp, [d_x], [False], False, False)
         return None, d_w, d_b, d_x

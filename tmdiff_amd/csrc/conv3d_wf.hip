@@ -497,11 +497,16 @@ __global__ void __launch_bounds__(256, 2) conv3d_wf_kernel(const WfArgs a) {
   };
 
   // (LLM: chunk (c, ph) has index 2 c + ph and every range of chunks starts at an even one: stage 0 <-> ph = 0)
+  // (the LDS-DMA hand-over between waves -- the weight pieces of the next stage are read by every wave -- needs this wave's
+  //  pieces to have LANDED before the barrier; the compiler places s_waitcnt vmcnt(0) there today, the explicit one makes the
+  //  source say so: ADVICE r3)
   for (int c = 0; c < nchunks; c += 2) {
     mfma_chunk(std::integral_constant<int, 0>{}, st0, c + 1 < nchunks ? c + 1 : 0, c + 2 < nchunks ? c + 2 : 0, st1);
+    __builtin_amdgcn_s_waitcnt(0x0F70);       // vmcnt(0)
     __syncthreads();
     if (c + 1 < nchunks) {
       mfma_chunk(std::integral_constant<int, 1>{}, st1, c + 2 < nchunks ? c + 2 : 0, c + 3 < nchunks ? c + 3 : 0, st0);
+      __builtin_amdgcn_s_waitcnt(0x0F70);
       __syncthreads();
     }
   }
@@ -722,9 +727,11 @@ int wf_forward(const tmdiff_conv3d_desc* d, void* workspace, tmdiff_stream_t str
   if (!TMDIFF_WF_STAMPS) {
     const int ks = wf_ksplit(d, llm);
     const size_t need = (size_t)ks * d->B * d->Cout * d->N * d->H * d->W * sizeof(float);
-    if (ks > 1 && a.y2_s2d)
-      return fail(TMDIFF_E_UNSUPPORTED, "conv3d_wf_fwd: a grid that splits its input channels cannot write the space-to-depth second output");
     if (ks > 1 && d->splitk_ws && (size_t)d->splitk_ws_bytes >= need && aligned16(d->splitk_ws)) {
+      // (only a launch that really splits is refused: without a lent workspace the grid runs unsplit and its own epilogue
+      //  writes the second output -- ADVICE r3: TMDIFF_WF_SPLITK=0 used to raise here for shapes the host had routed)
+      if (a.y2_s2d)
+        return fail(TMDIFF_E_UNSUPPORTED, "conv3d_wf_fwd: a grid that splits its input channels cannot write the space-to-depth second output");
       a.ksplit = ks; a.split_chunks = a.cin_g / 2 / ks; a.part = static_cast<float*>(d->splitk_ws);
     }
   }

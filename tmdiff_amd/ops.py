@@ -9,8 +9,97 @@ import os
 
 import torch
 
-from . import _lib
+from . import _lib, routing
 from ._lib import Conv3dDesc, check, lib
+
+
+
+class KernelConfig:
+    """Every behaviour switch of the Python side, in one place.  Each field is read ONCE from its environment variable when
+    the package is imported and is a plain attribute afterwards: code reads ``ops.config.<field>`` at call time, tests and
+    experiments change it with ``with ops.config.override(field=value): ...`` (no re-import, no environment juggling).
+    Defaults are the production path; every other value exists for A/B measurements and for the parity tests of the
+    alternative paths (tests/test_gpu_configs.py runs the finetune step with each result-changing default switched off).
+
+    field              env var                  default  meaning
+    -----------------  -----------------------  -------  ---------------------------------------------------------------------
+    winograd           TMDIFF_WINOGRAD          True     3x3x3 convolutions on the Winograd-along-the-bands kernels (conv3d_wf,
+                                                         fallback.conv3d_wino); False = direct kernels everywhere
+    wf                 TMDIFF_WF                True     ... with the input transform inside the kernel (conv3d_wf) where it applies
+    wf_pair            TMDIFF_WF_PAIR           True     8 bands x 8 columns: two images per 8x16 tile (pair mode); False = fallback
+    wf_splitk          TMDIFF_WF_SPLITK         True     small conv3d_wf grids split their input channels (+ reduction kernel)
+    wf_min_fill        TMDIFF_WF_MIN_FILL       0.7      planes that fill less of conv3d_wf's tiles go to the fallback
+    wino_min_blocks    TMDIFF_WINO_MIN_BLOCKS   256      Winograd grids below this many workgroups go to the direct kernels
+                                                         (1 = force the production family onto small test batches)
+    ll_compose         TMDIFF_LL_COMPOSE        True     main-branch Conv_0 + halved LL band as one composed convolution
+    wfll               TMDIFF_WFLL              True     ... with Winograd on top (conv3d_wf's composed-LL mode) in inference
+    train_ll_wino      TMDIFF_TRAIN_LL_WINO     True     ... and in the finetune forward; False = conv3d_ll there
+    conv2_after_ll     TMDIFF_CONV2_AFTER_LL    True     down blocks: the 1x1x1 Conv_2 after the LL band it commutes with
+    epilogue_fuse      TMDIFF_EPILOGUE_FUSE     True     conv20 -> conv21: the producer's epilogue writes the consumer's prologue
+    producer_fuse      TMDIFF_PRODUCER_FUSE     True     ... likewise for DWT / IDWT / stem producers
+    fp32_staged        TMDIFF_FP32_STAGED       "auto"   direct fp32 kernels: "0" fused only, "1" staged wherever supported
+    bf16_pack          TMDIFF_BF16_PACK         "auto"   bf16 mode: "0" fused kernel, "1"/"auto" packed input + DMA kernel
+    wgrad_wino         TMDIFF_WGRAD_WINO        True     3x3x3 weight gradients in the Winograd domain (F(3,4)); False = direct
+    wgrad_wino_bias    TMDIFF_WGRAD_WINO_BIAS   True     ... whose g pass sums the bias gradient on the side
+    wgrad_bias         TMDIFF_WGRAD_BIAS        False    direct weight gradient accumulates the bias gradient in-kernel
+    wino_multipack     TMDIFF_WINO_MULTIPACK    True     finetune step: all Winograd weight forms re-packed by one launch
+    train_graph        TMDIFF_TRAIN_GRAPH       False    (model.DDPM) capture the finetune step into a HIP graph
+
+    Library-side experiment variables (read by libtmdiff_hip.so itself, C getenv): TMDIFF_SPLITK, TMDIFF_SPLITK_LONG,
+    TMDIFF_WF_STAGGER, TMDIFF_WINO_STAGGER, TMDIFF_WINO_F4, TMDIFF_EPILOGUE_VEC, TMDIFF_SMALLGRID, TMDIFF_WW_PHASES,
+    TMDIFF_ATTN_SIMPLE, TMDIFF_CONV1_VEC, TMDIFF_CONV1_DWORD -- timing experiments only; TMDIFF_HIP_LIB selects a diagnostic
+    build of the library (_lib.py)."""
+
+    _FLAG = lambda default: (lambda v: (v != "0") if default else (v == "1"))
+    _FIELDS = {
+        "winograd": ("TMDIFF_WINOGRAD", _FLAG(True), True), "wf": ("TMDIFF_WF", _FLAG(True), True),
+        "wf_pair": ("TMDIFF_WF_PAIR", _FLAG(True), True), "wf_splitk": ("TMDIFF_WF_SPLITK", _FLAG(True), True),
+        "wf_min_fill": ("TMDIFF_WF_MIN_FILL", float, 0.7), "wino_min_blocks": ("TMDIFF_WINO_MIN_BLOCKS", int, 256),
+        "ll_compose": ("TMDIFF_LL_COMPOSE", _FLAG(True), True), "wfll": ("TMDIFF_WFLL", _FLAG(True), True),
+        "train_ll_wino": ("TMDIFF_TRAIN_LL_WINO", _FLAG(True), True),
+        "conv2_after_ll": ("TMDIFF_CONV2_AFTER_LL", _FLAG(True), True),
+        "epilogue_fuse": ("TMDIFF_EPILOGUE_FUSE", _FLAG(True), True), "producer_fuse": ("TMDIFF_PRODUCER_FUSE", _FLAG(True), True),
+        "fp32_staged": ("TMDIFF_FP32_STAGED", str, "auto"), "bf16_pack": ("TMDIFF_BF16_PACK", str, "auto"),
+        "wgrad_wino": ("TMDIFF_WGRAD_WINO", _FLAG(True), True), "wgrad_wino_bias": ("TMDIFF_WGRAD_WINO_BIAS", _FLAG(True), True),
+        "wgrad_bias": ("TMDIFF_WGRAD_BIAS", _FLAG(False), False), "wino_multipack": ("TMDIFF_WINO_MULTIPACK", _FLAG(True), True),
+        "train_graph": ("TMDIFF_TRAIN_GRAPH", _FLAG(False), False),
+    }
+
+    def __init__(self, env=None):
+        env = os.environ if env is None else env
+        for name, (var, parse, default) in self._FIELDS.items():
+            object.__setattr__(self, name, parse(env[var]) if var in env else default)
+
+    def __setattr__(self, name, value):
+        if name not in self._FIELDS:
+            raise AttributeError(f"ops.config has no switch {name!r}")
+        object.__setattr__(self, name, value)
+
+    def key(self):
+        """The current values as a tuple (cache keys of routing decisions)."""
+        return tuple(getattr(self, n) for n in self._FIELDS)
+
+    def as_dict(self):
+        return {n: getattr(self, n) for n in self._FIELDS}
+
+    def override(self, **values):
+        """Context manager: the given switches take the given values inside the block."""
+        import contextlib
+
+        @contextlib.contextmanager
+        def ctx():
+            old = {k: getattr(self, k) for k in values}
+            try:
+                for k, v in values.items():
+                    setattr(self, k, v)
+                yield self
+            finally:
+                for k, v in old.items():
+                    setattr(self, k, v)
+        return ctx()
+
+
+config = KernelConfig()
 
 
 _raw_stream = getattr(torch._C, "_cuda_getCurrentRawStream", None)
@@ -103,12 +192,23 @@ class WinoPackedWeights:
     (tmdiff_conv3d_wino_pack_weights_multi).  Which (weight, form) pairs those are depends on the tensor sizes (the 8x8 level
     and small grids take other kernels, and the deep levels hold most of the parameters), so the set is learnt: ``get``
     packs a pair it does not hold by itself and registers it; ``refresh`` (once per step, before the forward) re-packs the
-    registered pairs whose weight changed."""
+    registered pairs whose weight changed.
 
-    def __init__(self):
-        self.items = {}               # (data_ptr, mode) -> [weight, groups, packed tensor, packed version]
-        self._dirty = False
+    ``owner`` = the weights of the network this pack belongs to (WavBEST.forward_train passes its convolution weights): a weight
+    that is not among them -- another module's, a test's -- is packed on the spot by ``get`` and NOT registered, so a foreign
+    call can neither keep tensors alive here nor dirty the table.  The device table holds raw addresses; it is
+    rebuilt whenever the (weight address, packed address) pairs it was built from are not the live ones any more -- a
+    ``copy.deepcopy`` of a network that had already trained used to launch the multi-pack on the SOURCE network's memory."""
+
+    def __init__(self, owner=None):
+        self.items = {}               # (weight address, mode) -> [weight, groups, packed tensor, packed version]
+        self.owner = None if owner is None else list(owner)
+        self._owner_ptrs = None
+        self._table_key = None
         self.n_chunks = 0
+
+    def _live_key(self):
+        return tuple((it[0].data_ptr(), it[2].data_ptr(), mode) for (_, mode), it in self.items.items())
 
     def _build_tables(self):
         import struct
@@ -124,13 +224,21 @@ class WinoPackedWeights:
         self.chunk_tensor = torch.tensor(ct, dtype=torch.int32).to(dev)
         self.chunk_index = torch.tensor(ci, dtype=torch.int32).to(dev)
         self.n_chunks = len(ct)
-        self._dirty = False
+        self._table_key = self._live_key()
 
     def refresh(self):
+        if self.owner is not None:
+            self._owner_ptrs = {w.data_ptr() for w in self.owner}
+        # a registered weight whose storage moved (module.to(), parameters re-created) is forgotten and re-learnt
+        self.items = {k: it for k, it in self.items.items()
+                      if it[0].data_ptr() == k[0] and it[0].device == it[2].device}
         if not self.items:
+            self._table_key = None
             return self
-        if self._dirty:
+        if self._table_key != self._live_key():      # new pairs since the table was built
             self._build_tables()
+            for it in self.items.values():
+                it[3] = None
         if any(it[3] != it[0]._version for it in self.items.values()):
             check(lib.tmdiff_conv3d_wino_pack_weights_multi(self.entries.data_ptr(), self.chunk_tensor.data_ptr(),
                                                             self.chunk_index.data_ptr(), self.n_chunks, stream_ptr()),
@@ -139,22 +247,33 @@ class WinoPackedWeights:
                 it[3] = it[0]._version
         return self
 
+    def __deepcopy__(self, memo):
+        """A copy starts empty and is re-learnt by the copy's first step: the packed tensors and the device table belong to
+        the tensors of the network they were built from (WavBEST.__getstate__ drops the pack from copies anyway)."""
+        return WinoPackedWeights()
+
     def get(self, w, groups, mode):
-        it = self.items.get((w.data_ptr(), mode))
-        if it is not None and it[0] is w and it[3] == w._version:
+        key = (w.data_ptr(), mode)
+        it = self.items.get(key)
+        if it is not None and it[0].shape != w.shape:
+            it = None
+        if it is not None and it[3] == w._version:
             return it[2]
-        if it is not None and it[0] is w:       # registered, but the weight changed since the last refresh
+        if self.owner is not None and self._owner_ptrs is None:
+            self._owner_ptrs = {t.data_ptr() for t in self.owner}
+        foreign = self._owner_ptrs is not None and w.data_ptr() not in self._owner_ptrs
+        if it is not None:              # registered, but the weight changed since the last refresh
             out = it[2]
         else:
             _chk(w.detach(), "weight")
             out = torch.empty(w.numel() * 2, device=w.device, dtype=torch.float32)   # six planes for three taps
-            self._dirty = True
         cout, cin = w.shape[0], w.shape[1] * groups
         if mode & 1:
             cout, cin = cin, cout
         check(lib.tmdiff_conv3d_wino_pack_weights(w.detach().data_ptr(), out.data_ptr(), cout, cin, groups, mode, 6, stream_ptr()),
               "conv3d_wino_pack_weights")
-        self.items[(w.data_ptr(), mode)] = [w, groups, out, w._version]
+        if not foreign:
+            self.items[key] = [w, groups, out, w._version]
         return out
 
 
@@ -310,8 +429,6 @@ def _count(what, flops=0.0):
 
 _WS = {}     # (device index, stream) -> grow-only scratch tensor (prologue outputs / bf16-packed conv inputs); launches
              # on one stream are ordered, so consecutive convolutions can reuse it; other streams get their own
-_FP32_STAGED = os.environ.get("TMDIFF_FP32_STAGED", "auto")   # experiments: "0" = fused kernel only, "1" = staged wherever supported
-_BF16_PACK = os.environ.get("TMDIFF_BF16_PACK", "auto")       # experiments: "0" = fused kernel, "1"/"auto" = packed input
 
 
 def _workspace(device, nbytes, tag="x"):
@@ -355,7 +472,7 @@ def conv3d(segs, w_packed, cout, ksize, out=None, math="fp32", pack_input=None, 
         if w_packed.dtype != torch.int16:
             raise TypeError("conv3d(math='bf16') needs weights from pack_conv_weight_bf16")
         if pack_input is None:
-            pack_input = {"0": False, "1": True}.get(_BF16_PACK, True)   # measured: the two-kernel variant wins on every production layer
+            pack_input = {"0": False, "1": True}.get(config.bf16_pack, True)   # measured: the two-kernel variant wins on every production layer
         ws = (_workspace(dev, lib.tmdiff_conv3d_bf16_workspace_bytes(C.byref(d))).data_ptr()
               if pack_input and ksize == 3 and x_bf16_shape is None else None)
         fwd, what = (lambda dd, st: lib.tmdiff_conv3d_fwd_bf16(dd, ws, st)), "conv3d_fwd_bf16"
@@ -366,18 +483,12 @@ def conv3d(segs, w_packed, cout, ksize, out=None, math="fp32", pack_input=None, 
             nsk = lib.tmdiff_conv3d_fwd_splitk_workspace_bytes(C.byref(d))
             if nsk:
                 d.splitk_ws, d.splitk_ws_bytes = _workspace(dev, nsk, "splitk").data_ptr(), nsk
-        if staged is None:
-            # measured (tools/bench_conv.py, B=32): the staged kernel itself is 3-6 % faster than the fused one, but its
-            # prologue pass costs 8 B per input element -- a net win when the input needs no pass (one plain tensor:
-            # every data-gradient convolution), is shared by >= 2 channel tiles of a 3x3x3 convolution, is wide, or carries a
-            # dropout mask (the fused kernel reads the mask inside its MFMA stream).  1x1x1 layers have their own
-            # bandwidth kernel behind tmdiff_conv3d_fwd.
+        if staged is None:       # (the rule and its measurements: routing.direct_family)
             plain = len(segs) == 1 and not (kw.get("in_act") or kw.get("in_shift") is not None or
                                             kw.get("in_scale") is not None or kw.get("in_mask") is not None)
             plain = plain and kw.get("drop") is None
-            staged = {"0": False, "1": True}.get(_FP32_STAGED, ksize == 3 and (
-                plain or cout // d.groups >= 128 or d.Cin // d.groups >= 384 or kw.get("in_mask") is not None
-                or kw.get("drop") is not None))
+            staged = ksize == 3 and routing.direct_family(d.Cin, cout, d.groups, plain, kw.get("in_mask") is not None,
+                                                          kw.get("drop") is not None) == "staged"
         if xp_out is not None:
             staged = True
         if staged and lib.tmdiff_conv3d_fwd_staged_supported(C.byref(d)):
@@ -412,11 +523,6 @@ def conv3d_prologue(desc, shape):
     return xp
 
 
-def wino_planes(n_bands):
-    """Planes of the Winograd transform the library uses for a tensor of n_bands bands: 6 (F(4,3)), 4 (F(2,3)), 0 (odd)."""
-    return lib.tmdiff_conv3d_wino_planes(int(n_bands))
-
-
 def pack_conv_weight_wino(w, groups=1, mode=0, planes=6):
     """[Cout, Cin/groups, 3, 3, 3] -> the transformed, packed weights of the Winograd-along-n convolution (conv3d_wino);
     planes = wino_planes(N) of the tensors it will run on.  mode bit 0: the weights of the DATA-GRADIENT convolution
@@ -434,131 +540,66 @@ def pack_conv_weight_wino(w, groups=1, mode=0, planes=6):
     return out
 
 
-_WINO_MIN_BLOCKS = int(os.environ.get("TMDIFF_WINO_MIN_BLOCKS", "256"))   # below: the direct kernels (split-K fills the chip)
 
 
-def wino_conv_supported(cout, cin, ksize=3, groups=1):
-    """Weight shapes tmdiff_conv3d_wino_fwd takes."""
-    return (ksize == 3 and groups in (1, 3) and cin % groups == 0 and cout % groups == 0 and (cin // groups) % 2 == 0 and
-            (cout // groups) % 32 == 0)
+# routing lives in tmdiff_amd/routing.py; these names stay importable from ops (tests, tools)
+wino_conv_supported = routing.wino_weight_ok
+wf_route = routing.wf_route
+wfll_route = routing.wfll_route
 
 
-def conv3d_wino(segs, w_packed, cout, emit=None, keep_y=True, fallback=None, groups=1, w_packed_fn=None, xp_out=None, **kw):
-    """conv3d(segs, ...) (fp32, 3x3x3, groups 1) through the Winograd F(2,3)-along-n kernels (csrc/conv3d_wino.hip): an
-    input-transform pass (prologue and concatenation applied there) + a convolution with 1.5x fewer multiply-adds.
-    Same keyword arguments and return convention as conv3d; fallback = a callable that runs the direct convolution
-    instead when the shape is not taken or its grid would be too small (the kernel has no split-K).  drop = (seed, p):
-    in-kernel dropout of the prologue output; xp_out: a [B, Cin, N, H, W] tensor that receives that output (finetune path)."""
+class ConvWeights:
+    """The packed forms of one 3x3x3 convolution weight, each produced on first use: direct() (pack_conv_weight), wf()
+    (pack_conv_weight_wino mode | 2, planes 6), wino(planes) (fallback kernels).  Any callable may be None: that family is
+    then not offered for this weight (conv3d_auto falls through to the next rule)."""
+
+    def __init__(self, direct, wf=None, wino=None):
+        self.direct, self.wf, self.wino = direct, wf, wino
+
+
+def conv3d_auto(segs, weights, cout, groups=1, math="fp32", emit=None, keep_y=True, xp_out=None, x_bf16_shape=None, **kw):
+    """A 3x3x3 convolution on the kernel family routing.conv3_family picks for its extents (same keyword arguments and
+    return convention as conv3d): conv3d_wf, the direct kernels (staged / fused), the bf16 kernel, or -- band counts other
+    than 4 / 8 -- tmdiff_amd.fallback.conv3d_wino."""
+    if math == "bf16" or x_bf16_shape is not None:
+        return conv3d(segs, weights.direct(), cout, 3, groups=groups, math=math, emit=emit, keep_y=keep_y,
+                      x_bf16_shape=x_bf16_shape, **kw)
     b, _, n, h, w = segs[0].shape
-    dev = segs[0].device
-    planes = wino_planes(n)
-    cg = cout // groups
-    per_tile = b * groups * ((h + 7) // 8) * (((w + 7) // 8) * (cg // 64) if cg % 64 == 0 else ((w + 15) // 16) * (cg // 32))
-    blocks = lambda p: per_tile * ((n // (p - 2) + 1) // 2) if p else 0          # (= tmdiff_conv3d_wino_blocks)
-    if planes == 6 and blocks(6) < _WINO_MIN_BLOCKS <= blocks(4):
-        planes = 4                   # F(2,3) has twice the tiles along the bands: it still fills the chip here
-    if fallback is not None and (not planes or w % 4 or blocks(planes) < _WINO_MIN_BLOCKS):
-        return fallback()            # unsupported extents, or a grid too small for a kernel without split-K
-    if w_packed is None:             # (packed only once it is known that the kernel will run, and with how many planes)
-        w_packed = w_packed_fn(planes)
-    y = torch.empty(b, cout, n, h, w, device=dev, dtype=torch.float32) if keep_y else None
-    y2 = None
-    if emit is not None:
-        y2 = torch.empty(b, cout, n, h, w, device=dev, dtype=torch.float32)
-        kw = dict(kw, y2_act=emit.get("act", False), y2_shift=emit.get("shift"), y2_scale=emit.get("scale"),
-                  y2_shift_stride=emit.get("shift_stride", 0), y2_scale_stride=emit.get("scale_stride", 0))
-    elif y is None:
-        raise ValueError("conv3d_wino: keep_y=False needs emit=")
-    d = make_conv_desc(segs, w_packed, cout, 3, y, y2=y2, groups=groups, **kw)
-    if not lib.tmdiff_conv3d_wino_supported(C.byref(d)):
-        raise ValueError("conv3d_wino: shape not supported")
-    ws = _workspace(dev, lib.tmdiff_conv3d_wino_workspace_bytes(C.byref(d)), "wino").data_ptr()
-    ret = y if y2 is None else ((y, y2) if y is not None else y2)
-    if xp_out is not None and not (xp_out.is_cuda and xp_out.is_contiguous() and xp_out.numel() == b * d.Cin * n * h * w):
-        raise ValueError("conv3d_wino: xp_out must be a contiguous fp32 [B, Cin, N, H, W] tensor")
-    _count(f"conv3d_wino{planes - 2}_fwd", 2.0 * b * cout * (d.Cin // groups) * (9.0 * planes / (planes - 2)) * n * h * w)
-    if TIMER is None or xp_out is not None:
-        check(lib.tmdiff_conv3d_wino_fwd_planes(C.byref(d), ws, 0, xp_out.data_ptr() if xp_out is not None else None, planes,
-                                                stream_ptr()), "conv3d_wino_fwd")
-        return ret
-    # timed: the input-transform pass (an HBM pass, recorded under ksize 0 with its bytes) and the convolution kernel apart
-    ev = [torch.cuda.Event(enable_timing=True) for _ in range(3)]
-    ev[0].record()
-    check(lib.tmdiff_conv3d_wino_fwd_planes(C.byref(d), ws, 1, None, planes, stream_ptr()), "conv3d_wino_fwd (input transform)")
-    ev[1].record()
-    check(lib.tmdiff_conv3d_wino_fwd_planes(C.byref(d), ws, 2, None, planes, stream_ptr()), "conv3d_wino_fwd")
-    ev[2].record()
-    mo = planes - 2                  # bands per tile; bytes: 4 B read + 4 * planes / mo B written per input element
-    TIMER.records.append((ev[0], ev[1], (4.0 + 4.0 * planes / mo) * b * d.Cin * n * h * w, 0, "wino_input", _tag(d)))
-    # EXECUTED flops: 9 * planes multiply-adds per (ci, co) and tile of mo output bands (the direct kernel: 27 per band)
-    TIMER.records.append((ev[1], ev[2], 2.0 * b * cout * (d.Cin // groups) * (9.0 * planes / mo) * n * h * w, 3, f"conv3d_wino{mo}_fwd", _tag(d)))
-    return ret
+    cin = sum(s_.shape[1] for s_ in segs)
+    masked, dropout = kw.get("in_mask") is not None, kw.get("drop") is not None
+    plain = len(segs) == 1 and not (kw.get("in_act") or kw.get("in_shift") is not None or kw.get("in_scale") is not None or
+                                    masked or dropout)
+    fam = routing.conv3_family(b, cin, cout, n, h, w, groups, plain=plain, masked=masked, dropout=dropout,
+                               keep_xp=xp_out is not None)
+    if fam in ("wf", "wf_pair") and weights.wf is not None:
+        return conv3d_wf(segs, weights.wf(), cout, emit=emit, keep_y=keep_y, groups=groups, xp_out=xp_out, **kw)
+    if fam in ("wino4", "wino2") and weights.wino is not None:
+        from . import fallback
+        planes = 6 if fam == "wino4" else 4
+        return fallback.conv3d_wino(segs, weights.wino(planes), cout, planes, emit=emit, keep_y=keep_y, groups=groups,
+                                    xp_out=xp_out, **kw)
+    if emit is not None and emit.get("s2d"):
+        raise ValueError("conv3d_auto: only conv3d_wf writes a space-to-depth second output (ask routing.wf_route first)")
+    staged = fam == "staged" or (fam not in ("staged", "fused") and
+                                 routing.direct_family(cin, cout, groups, plain, masked, dropout, xp_out is not None) == "staged")
+    return conv3d(segs, weights.direct(), cout, 3, groups=groups, staged=staged, emit=emit, keep_y=keep_y, xp_out=xp_out, **kw)
 
 
-_WF = os.environ.get("TMDIFF_WF", "1") != "0"    # experiments: "0" = never the in-kernel-transform Winograd kernel (conv3d_wf)
-_WF_MIN_FILL = float(os.environ.get("TMDIFF_WF_MIN_FILL", "0.7"))
-_WF_PAIR = os.environ.get("TMDIFF_WF_PAIR", "1") != "0"          # experiments: "0" = 8-column planes go to the fallback kernels
-_WF_SPLITK = os.environ.get("TMDIFF_WF_SPLITK", "1") != "0"      # experiments: "0" = small grids go to the fallback kernels
-
-
-def wf_route(b, cin, cout, n, h, w, groups=1, masked=False, llm=False):
-    """(taken, split): whether conv3d_wf runs a convolution of these extents itself (else its fallback does) and into how many
-    ranges it splits the input channels (1 = no split-K).  The kernel's own plan (tmdiff_conv3d_wf_plan) plus the host's rules:
-    grids below _WINO_MIN_BLOCKS workgroups and planes that leave much of every 8 x 16 tile empty go to the fallback.
-    llm: the composed Conv_0 + LL mode (cin, h, w those of the space-to-depth tensor)."""
-    key = (b, cin, cout, n, h, w, groups, masked, llm, _WF, _WF_SPLITK, _WF_PAIR, _WINO_MIN_BLOCKS, _WF_MIN_FILL)
-    r = _WF_ROUTES.get(key)
-    if r is None:
-        if len(_WF_ROUTES) > 4096:
-            _WF_ROUTES.clear()
-        r = _WF_ROUTES[key] = _wf_route(b, cin, cout, n, h, w, groups, masked, llm)
-    return r
-
-
-_WF_ROUTES = {}      # (the plan is a pure function of the extents: one library call per distinct shape, not per launch)
-
-
-def _wf_route(b, cin, cout, n, h, w, groups=1, masked=False, llm=False):
-    """wf_route without the cache."""
-    if cin % groups or cout % groups or masked or not _WF:
-        return False, 1
-    tiles = C.c_int64(0)
-    split = lib.tmdiff_conv3d_wf_plan(b, cin, cout, n, h, w, groups, 1 if llm else 0, C.byref(tiles))
-    if split == 0:
-        return False, 1
-    if not _WF_SPLITK:
-        split = 1
-    th = 8 if n == 8 else 16
-    # (8 bands x 8 columns: two images side by side in one 8 x 16 tile -- the kernel's pair mode)
-    pair = n == 8 and w == 8
-    if pair and not _WF_PAIR:
-        return False, 1
-    # (tiles of th x 16 positions: a plane that leaves much of every tile empty goes to the fallback)
-    fill = (h * w) / float(((h + th - 1) // th) * th * (8 if pair else ((w + 15) // 16) * 16))
-    if pair:
-        fill *= b / (2.0 * ((b + 1) // 2))        # (an odd batch leaves the last pair's second half empty: B = 1 is half a tile)
-    return bool(tiles.value * split >= _WINO_MIN_BLOCKS and fill >= _WF_MIN_FILL), split
-
-
-def conv3d_wf(segs, w_packed, cout, emit=None, keep_y=True, fallback=None, groups=1, w_packed_fn=None, xp_out=None, **kw):
+def conv3d_wf(segs, w_packed, cout, emit=None, keep_y=True, groups=1, xp_out=None, **kw):
     """conv3d(segs, ...) (fp32, 3x3x3) through the Winograd F(4,3)-along-the-bands kernel that transforms its input INSIDE the
     kernel (csrc/conv3d_wf.hip; 8- or 4-band tensors, the whole band axis in one workgroup): no transformed copy of the input,
     no transform pass -- an input that is one plain tensor is read as it stands, any other (prologue, segments, dropout) goes
     through one elementwise prologue pass first (its output lands in xp_out when given: the finetune path keeps it for the
-    weight gradient).  Same keyword arguments and return convention as conv3d_wino; w_packed / w_packed_fn() = the weights
-    from pack_conv_weight_wino(w, groups, mode | 2, planes=6).  fallback() runs instead when the shape is not taken or the
-    grid is too small for a kernel without split-K."""
+    weight gradient).  Same keyword arguments and return convention as conv3d; w_packed = the weights from
+    pack_conv_weight_wino(w, groups, mode | 2, planes=6).  Runs whatever the grid size (routing.conv3_family is where small
+    grids are sent elsewhere); raises for shapes the kernel does not take."""
     b, _, n, h, w = segs[0].shape
     dev = segs[0].device
-    cin = sum(s_.shape[1] for s_ in segs)
     s2d = bool(emit is not None and emit.get("s2d"))
-    takes, split = wf_route(b, cin, cout, n, h, w, groups, kw.get("in_mask") is not None)
-    if s2d and ((fallback is not None and not takes) or split > 1 or h % 2 or w % 4):
-        raise ValueError("conv3d_wf: this launch cannot write a space-to-depth second output (ask wf_route first)")
-    if fallback is not None and not takes:
-        return fallback()            # unsupported extents, or a grid too small even with its input channels split
-    if w_packed is None:
-        w_packed = w_packed_fn()
+    if s2d:
+        cin = sum(s_.shape[1] for s_ in segs)
+        if routing.wf_route(b, cin, cout, n, h, w, groups)[1] > 1 or h % 2 or w % 4:
+            raise ValueError("conv3d_wf: this launch cannot write a space-to-depth second output (ask routing.wf_route first)")
     y = torch.empty(b, cout, n, h, w, device=dev, dtype=torch.float32) if keep_y else None
     y2 = None
     if emit is not None:
@@ -570,7 +611,7 @@ def conv3d_wf(segs, w_packed, cout, emit=None, keep_y=True, fallback=None, group
     d = make_conv_desc(segs, w_packed, cout, 3, y, y2=y2, groups=groups, **kw)
     if not lib.tmdiff_conv3d_wf_supported(C.byref(d)):
         raise ValueError("conv3d_wf: shape not supported")
-    nsk = lib.tmdiff_conv3d_wf_splitk_workspace_bytes(C.byref(d)) if _WF_SPLITK else 0
+    nsk = lib.tmdiff_conv3d_wf_splitk_workspace_bytes(C.byref(d)) if config.wf_splitk else 0
     if nsk:
         d.splitk_ws, d.splitk_ws_bytes = _workspace(dev, nsk, "splitk").data_ptr(), nsk
     nws = lib.tmdiff_conv3d_wf_workspace_bytes(C.byref(d))
@@ -650,7 +691,6 @@ def conv3d_ll(x, w_packed, cout, ll_scale=0.5, emit=None, keep_y=True, **kw):
     return ret
 
 
-_WFLL = os.environ.get("TMDIFF_WFLL", "1") != "0"    # experiments: "0" = the composed Conv_0 + LL convolution stays on conv3d_ll
 
 
 def pack_conv_weight_wfll(w, ll_scale=0.5):
@@ -661,14 +701,6 @@ def pack_conv_weight_wfll(w, ll_scale=0.5):
     check(lib.tmdiff_conv3d_wfll_pack_weights(_chk(w.detach(), "w"), out.data_ptr(), cout, cin, float(ll_scale), stream_ptr()),
           "conv3d_wfll_pack_weights")
     return out
-
-
-def wfll_route(b, cin, cout, n, h, w):
-    """True when conv3d_wf_ll takes the composed Conv_0 + LL convolution of a [b, cin, n, h, w] input (h, w: full resolution)."""
-    if not (_WFLL and n in (4, 8) and h % 2 == 0 and w % 8 == 0 and cout % 32 == 0):
-        return False
-    takes, _ = wf_route(b, 4 * cin, cout, n, h // 2, w // 2, llm=True)
-    return takes
 
 
 def conv3d_wf_ll(x_s2d, w_packed, cout, ll_scale=0.5, emit=None, keep_y=True, **kw):
@@ -689,7 +721,7 @@ def conv3d_wf_ll(x_s2d, w_packed, cout, ll_scale=0.5, emit=None, keep_y=True, **
     d = make_conv_desc([x_s2d], w_packed, cout, 3, y, y2=y2, out_div=2, x_s2d=True, **kw)
     if not lib.tmdiff_conv3d_wfll_supported(C.byref(d)):
         raise ValueError("conv3d_wf_ll: shape not supported")
-    nsk = lib.tmdiff_conv3d_wfll_splitk_workspace_bytes(C.byref(d)) if _WF_SPLITK else 0
+    nsk = lib.tmdiff_conv3d_wfll_splitk_workspace_bytes(C.byref(d)) if config.wf_splitk else 0
     if nsk:
         d.splitk_ws, d.splitk_ws_bytes = _workspace(dev, nsk, "splitk").data_ptr(), nsk
     ret = y if y2 is None else ((y, y2) if y is not None else y2)
@@ -911,20 +943,19 @@ def q_sample(x0, noise, a, out=None):
 
 
 # ---- backward-side wrappers (finetune path) -----------------------------------------------------------
-_WGRAD_WINO = os.environ.get("TMDIFF_WGRAD_WINO", "1") != "0"   # experiments: "0" = every weight gradient on the direct kernel
 
 
 def wgrad_wino_takes(desc):
     """True when conv3d_wgrad runs this weight gradient in the Winograd domain (its g pass then sums the bias gradient on
     the side for free)."""
-    return bool(_WGRAD_WINO and desc.ksize == 3 and lib.tmdiff_conv3d_wgrad_wino_supported(C.byref(desc)))
+    return bool(config.wgrad_wino and desc.ksize == 3 and lib.tmdiff_conv3d_wgrad_wino_supported(C.byref(desc)))
 
 
 def conv3d_wgrad(desc, g, weight_shape, want_bias=False):
     """dL/dw [Cout, Cin/g, k,k,k] for the convolution described by `desc` (a filled Conv3dDesc) given g = dL/dy; with
     want_bias also dL/dbias = desc.bias_scale * sum_{b,pos} g, accumulated inside the same kernel: returns (dw, dbias)."""
     dw = torch.empty(weight_shape, device=g.device, dtype=torch.float32)
-    if _WGRAD_WINO and desc.ksize == 3 and lib.tmdiff_conv3d_wgrad_wino_supported(C.byref(desc)):
+    if config.wgrad_wino and desc.ksize == 3 and lib.tmdiff_conv3d_wgrad_wino_supported(C.byref(desc)):
         # Winograd F(3,4) along the bands (csrc/wgrad_wino.hip): 13.5 executed multiply-adds per element instead of 27
         _count("conv3d_wgrad_wino", 2.0 * desc.B * desc.Cout * (desc.Cin // desc.groups) * 13.5 * desc.N * desc.H * desc.W)
         nbytes = lib.tmdiff_conv3d_wgrad_wino_workspace_bytes(C.byref(desc))

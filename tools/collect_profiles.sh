@@ -1,7 +1,7 @@
 #!/bin/bash
 # collect_profiles.sh [TAG]: everything profiles/ holds for a round, in one GPU call (~4 min).  Outputs land in
 # gpurun_out/${TAG}_final/ (scratch); copy the summaries into profiles/ afterwards (tools/README.md).
-R=$PWD; TAG=${1:-r03}; O=$R/gpurun_out/${TAG}_final; mkdir -p $O
+R=$PWD; TAG=${1:-r04}; O=$R/gpurun_out/${TAG}_final; mkdir -p $O
 # (the PMC traffic first: bench.py reads profiles/${TAG}_bench_traffic.json back into roofline.traffic and marks it stale when it
 #  was collected from other sources)
 bash tools/bench_traffic.sh $TAG > $O/traffic.log 2>&1; echo "traffic rc=$?"
@@ -19,7 +19,8 @@ python3 tools/bench_conv_ll.py 32 5 2>&1 | grep -v amdgpu > $O/conv_ll.txt
 python3 tools/bench_conv_wino.py 32 5 2>&1 | grep -v amdgpu > $O/conv_wino.txt
 python3 tools/bench_conv_wino.py 32 5 epi 2>&1 | grep -v amdgpu > $O/conv_wino_epilogue.txt
 python3 tools/bench_layers.py 5 2>&1 | grep -v amdgpu > $O/bench_layers.txt
-./tools/micro/cu_probe > $O/cu_probe.txt 2>&1
+# (built here from its source: no binary is kept in the tree)
+hipcc -O2 --offload-arch=gfx950 -o tools/micro/cu_probe tools/micro/cu_probe.hip && ./tools/micro/cu_probe > $O/cu_probe.txt 2>&1
 # (diagnostic builds with s_memrealtime stamps / ablation switches, before the call:
 #  tools/build_variant.sh wstamps "-DTMDIFF_WINO_STAMPS=1" conv3d_wino; tools/build_variant.sh wfstamps "-DTMDIFF_WF_STAMPS=1" conv3d_wf;
 #  for v in 1 2 3: tools/build_variant.sh wfab$v "-DTMDIFF_WF_ABLATE=$v" conv3d_wf)
