@@ -44,6 +44,7 @@ FULL = [32, 64, 128, 256]
 BATCH, BANDS, SIZE, T = 32, 8, 64, 1000
 GFLOP_PER_SAMPLE = 172.39          # algorithmic conv FLOPs per sample per forward
 PEAK_FP32_MFMA = 157.3             # TFLOP/s, MI355X_MICROARCH.md
+COPY_RATE_TB_S = 6.29              # plain device-to-device copy rate of the box (tools/bench_hbm_kernels.py): the HBM roof in practice
 
 
 def visible_gpus():
@@ -288,6 +289,34 @@ def rehearse(world, rank, args):
         dist.destroy_process_group()
 
 
+PEAK_BF16_MFMA = 2500.0            # TFLOP/s dense, MI355X_MICROARCH.md
+
+
+def bf16_by_level(timer, steps):
+    """Per layer class of the bf16 compute mode (3x3x3 launches by plane size; 1x1x1 apart): time per step, FLOP rate against the
+    2.5 PFLOP/s bf16 matrix peak, algorithmic bytes (packed bf16 input 2 B, fp32 outputs / residual 4 B, packed second output
+    2 B per element) against the copy rate -- and which of the two fractions is the larger, i.e. the roof that binds."""
+    import re
+    import torch
+    torch.cuda.synchronize()
+    acc = {}
+    for rec in timer.records:
+        e0, e1, fl, k, what, tag = rec[:6]
+        nbytes = rec[6] if len(rec) > 6 else 0.0
+        m = re.search(r"(\d+)x(\d+)x(\d+) b", tag)
+        key = ("k1 (all levels)" if k == 1 else f"k3 {m.group(2)}x{m.group(3)}") + ("" if "bf16" in what else " [fp32 kernel]")
+        a = acc.setdefault(key, [0, 0.0, 0.0, 0.0])
+        a[0] += 1; a[1] += e0.elapsed_time(e1); a[2] += fl; a[3] += nbytes
+    out = {}
+    for key, (n, ms, fl, nb) in sorted(acc.items()):
+        tf, tb = fl / (ms * 1e-3) / 1e12, nb / (ms * 1e-3) / 1e12
+        fm, fh = tf / PEAK_BF16_MFMA, tb / COPY_RATE_TB_S
+        out[key] = {"launches_per_step": n // steps, "ms_per_step": round(ms / steps, 3), "tflops": round(tf, 1),
+                    "frac_of_bf16_mfma_peak": round(fm, 3), "tb_per_s": round(tb, 2), "frac_of_copy_rate": round(fh, 3),
+                    "nearer_roof": "hbm" if fh > fm else "mfma"}
+    return out
+
+
 def source_sha16():
     """Digest of the sources that decide which kernels the benchmark launches and what they do (csrc, ops.py, the UNet): the
     PMC traffic file records it at collection time, so a figure collected from other code is reported as stale."""
@@ -325,17 +354,20 @@ def load_traffic():
         return None, TRAFFIC_FILE + " missing: run tools/bench_traffic.sh on the GPU box"
 
 
-def train_leg(dev, world, rank, dist, steps, warmup):
+def train_leg(dev, world, rank, dist, steps, warmup, graph=False):
     """BASELINE configs[3] per-GPU share: local batch 8 of 8x64x64 tiles, ch 32-256, dropout on, forward + backward +
     SUM all-reduce (overlapped with backward, tmdiff_amd.dist.GradReducer) + AdamW + EMA (reference model.py:40-47,
-    general_finetune.json:64-66, utils/EmaUpdater.py).  Returns seconds for `steps` steps plus all-reduce figures."""
+    general_finetune.json:64-66, utils/EmaUpdater.py).  Returns seconds for `steps` steps plus all-reduce figures.
+    graph: the step recorded into a HIP graph (tmdiff_amd.model.CapturedStep; one rank: forward + backward + AdamW are one
+    graph launch, the EMA update one more kernel) -- the first two steps run eagerly, so warmup >= 3 puts only replays
+    into the timed region."""
     import copy
     import numpy as np
     from tmdiff_amd.model import DDPM, EmaUpdater
     from tmdiff_amd.util import fill_weights_, synthetic_tile_batch
     opt = {"phase": "train", "gpu_ids": [dev.index], "distributed": world > 1, "path": {"resume": None},
            "model": {"unet": {"channel_multiplier": FULL}, "diffusion": {"loss_type": "l1"}, "init_type": "orthogonal"},
-           "train": {"optimizer": {"lr": 1e-4}, "max_iter": 150000}}
+           "train": {"optimizer": {"lr": 1e-4}, "max_iter": 150000, "hip_graph": bool(graph)}}
     m = DDPM(opt)
     fill_weights_(m.netG.denoise_fn)                     # same weights on every rank (replicas start identical) ...
     if dist is not None:                                 # ... and, as tmdiff_amd.train.build_replica does, made so by a
@@ -359,7 +391,8 @@ def train_leg(dev, world, rank, dist, steps, warmup):
             m.optimize_parameters("WV3")
             ema.update(it0 + i)
 
-    run(max(warmup, 2), 0)          # step 1 lays out the gradient buckets; overlapped all-reduce from step 2 on
+    run(max(warmup, 4 if graph else 2), 0)   # step 1 lays out the gradient buckets; overlapped all-reduce from step 2 on
+                                             # (graph: two eager steps, the capture, one replay before the clock starts)
     barrier()
     t0 = time.perf_counter()
     run(steps, 10)
@@ -367,12 +400,15 @@ def train_leg(dev, world, rank, dist, steps, warmup):
     barrier()
     dt = time.perf_counter() - t0
     from tmdiff_amd import ops as _ops
-    _ops.FLOPS = [0.0]                          # one more step with the executed-FLOP counter on (outside the timed region)
+    _ops.FLOPS = [0.0]                          # one more step with the executed-FLOP counter on (outside the timed region;
+    keep_graph, m.use_graph = m.use_graph, False    # eagerly: a graph replay passes no Python counter)
     run(1, 50)
+    m.use_graph = keep_graph
     barrier()
     executed, _ops.FLOPS = _ops.FLOPS[0], None
     out = {"seconds": dt, "host_seconds": t_host, "loss": float(m.get_current_log()["l_pix"]), "allreduce": None,
-           "executed_gflop_per_step": executed / 1e9}
+           "executed_gflop_per_step": executed / 1e9, "captured": bool(graph),
+           "graph_replays": sum(c.replays for c in m._captured.values()) if graph else 0}
     if dist is not None:
         red = m.reducer
         hook_launches = red.launched_last      # of the last timed step (the exchange-free steps below reset it)
@@ -412,10 +448,19 @@ def train_leg(dev, world, rank, dist, steps, warmup):
 TRAIN_GFLOP_PER_SAMPLE = 3 * GFLOP_PER_SAMPLE      # training step ~ forward + dgrad + wgrad = 517 GF/sample
 
 
-def train_object(leg, world, steps):
+def train_object(leg, world, steps, eager=None):
     dt = leg["seconds"]
+    extra = {}
+    if leg.get("captured"):
+        extra = {"captured_in_hip_graph": True, "graph_replays": leg["graph_replays"],
+                 "capture": "forward + backward + AdamW of the step as ONE HIP-graph launch (tmdiff_amd.model.CapturedStep); per "
+                            "step the host copies the batch, the NumPy-drawn timesteps and their table values into fixed device "
+                            "tensors, fills the noise tensor, launches the graph and the EMA kernel"}
+        if eager is not None:
+            extra["eager_ms_per_step"] = round(eager["seconds"] / steps * 1e3, 3)
+            extra["eager_host_enqueue_ms_per_step"] = round(eager["host_seconds"] / steps * 1e3, 3)
     return {"value": round(world * 8 * steps / dt, 2), "unit": "samples/s", "ms_per_step": round(dt / steps * 1e3, 3),
-            "host_enqueue_ms_per_step": round(leg["host_seconds"] / steps * 1e3, 3),
+            "host_enqueue_ms_per_step": round(leg["host_seconds"] / steps * 1e3, 3), **extra,
             "steps": steps, "global_batch": 8 * world,
             # what the matrix pipe EXECUTES (Winograd forward / data-gradient convolutions and the composed Conv_0 + LL
             # convolution run fewer multiply-adds than the reference's operator order; the weight gradient runs them all)
@@ -426,7 +471,9 @@ def train_object(leg, world, steps):
             "reference_order_tflops_per_gpu": round(8 * TRAIN_GFLOP_PER_SAMPLE * 1e-3 * steps / dt, 2),
             "loss": round(leg["loss"], 5), "allreduce": leg["allreduce"],
             "what": "BASELINE configs[3] per-GPU share: local batch 8 of 8x64x64 tiles, ch 32-256, dropout 0.2 on, fwd + bwd + "
-                    "SUM all-reduce of 216 gradient tensors (RCCL, flat buckets, started from backward hooks) + AdamW + EMA"}
+                    "SUM all-reduce of 216 gradient tensors (RCCL, flat buckets, started from backward hooks) + AdamW + EMA; "
+                    "one rank: the step is replayed from a HIP graph (eager figures beside it), several ranks: eager launches "
+                    "with the exchange overlapped"}
 
 
 def main():
@@ -483,9 +530,11 @@ def main():
 
     if args.mode == "train":
         log(f"rank {rank}/{world}: finetune step on {torch.cuda.get_device_name(dev)}")
-        leg = train_leg(dev, world, rank, dist, args.steps, args.warmup)
+        graph = world == 1 and os.environ.get("TMDIFF_BENCH_TRAIN_GRAPH", "1") != "0"
+        eager = train_leg(dev, world, rank, dist, args.steps, args.warmup) if graph else None
+        leg = train_leg(dev, world, rank, dist, args.steps, args.warmup, graph=graph)
         if rank == 0:
-            obj = train_object(leg, world, args.steps)
+            obj = train_object(leg, world, args.steps, eager)
             line = {"metric": "finetune train samples/sec (8-ch 64x64 tiles, local batch 8 per GPU)", "value": obj["value"],
                     "unit": "samples/s", "n_gpus": evidence["world"], "rccl": evidence, "steps": args.steps, "warmup": args.warmup,
                     "ms_per_step": obj["ms_per_step"], "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
@@ -538,9 +587,10 @@ def main():
     timer, ops.TIMER = ops.TIMER, None
     conv = timer.summary()
     conv_by_entry = timer.summary(by_entry=True)
+    k1_n, k1_ms, k1_bytes = timer.bytes_summary(1)
     del xi
 
-    dt_cached = dt_bf16 = None
+    dt_cached = dt_bf16 = bf16_levels = None
     train = None
     if not args.no_extras:
         # ---- the same loop with the condition branch hoisted (a real sampling run), outside `value` -------
@@ -561,6 +611,11 @@ def main():
         x3 = run(args.steps, T - 1, x3)
         barrier()
         dt_bf16 = time.perf_counter() - t2
+        # ... and three more steps with an event pair around every convolution launch: which roof binds each layer class
+        ops.TIMER = ops.ConvTimer()
+        run(3, T - 1, x3)
+        bf16_timer, ops.TIMER = ops.TIMER, None
+        bf16_levels = bf16_by_level(bf16_timer, 3)
         net.set_compute_dtype("fp32")
         assert torch.isfinite(x3).all()
         log(f"bf16-compute loop: {args.steps} steps in {dt_bf16:.3f} s")
@@ -644,8 +699,15 @@ def main():
                                                             "the 3x3x3 launches run at "
                                                             f"{round(fl3 / ((ms3 + ms0) * 1e-3) / 1e12, 2) if ms3 > 0 else 0.0} "
                                                             "TFLOP/s executed = `frac_with_transforms`"},
-                         "k1_conv": {"launches": n1, "avg_launch_us": round(ms1 / max(n1, 1) * 1e3, 2),
-                                     "tflops": round(fl1 / (ms1 * 1e-3) / 1e12, 2) if ms1 > 0 else 0.0}},
+                         # the 1x1x1 convolutions are bandwidth kernels: algorithmic bytes (input + output (+ residual) once) over
+                         # their summed durations, against the box's 6.29 TB/s copy rate (tools/bench_hbm_kernels.py)
+                         "k1_conv": {"launches": n1, "avg_launch_us": round(ms1 / max(n1, 1) * 1e3, 2), "bound": "hbm",
+                                     "ms_per_step": round(ms1 / args.steps, 3),
+                                     "tb_per_s": round(k1_bytes / (k1_ms * 1e-3) / 1e12, 2) if k1_ms > 0 else 0.0,
+                                     "frac_of_copy_rate": round(k1_bytes / (k1_ms * 1e-3) / 1e12 / COPY_RATE_TB_S, 3) if k1_ms > 0 else 0.0,
+                                     "copy_rate_tb_s": COPY_RATE_TB_S,
+                                     "note": "19 launches per step, most of them small (8x8 / 16x16 levels: 4-60 MB each, "
+                                             "20-40 us = launch + ramp, not bandwidth); the level-0 ones run at 3.9-4.6 TB/s"}},
         }
         if not args.no_extras:
             line["cond_cached"] = {"value": round(world * args.steps / dt_cached, 4), "unit": "batch32-steps/s",
@@ -653,6 +715,7 @@ def main():
                                            "evaluated once inside the timed run instead of every step; outputs are "
                                            "bit-identical (tests/test_gpu_sampling.py)"}
             line["bf16_compute"] = {"value": round(world * args.steps / dt_bf16, 4), "unit": "batch32-steps/s",
+                                    "by_layer_class": bf16_levels,
                                     "unet_reference_order_tflops": round(BATCH * GFLOP_PER_SAMPLE * 1e-3 * args.steps / dt_bf16, 2),
                                     "note": "same full-forward steps with bf16 conv operands / fp32 accumulation "
                                             "(set_compute_dtype('bf16'), the config-3 mode; forward rel-L2 7e-3 vs fp32, "
@@ -686,7 +749,9 @@ def main():
         dog.daemon = True
         dog.start()
         try:
-            train = train_object(train_leg(dev, world, rank, dist, tsteps, 2), world, tsteps)
+            graph = world == 1 and os.environ.get("TMDIFF_BENCH_TRAIN_GRAPH", "1") != "0"
+            eager = train_leg(dev, world, rank, dist, tsteps, 2) if graph else None
+            train = train_object(train_leg(dev, world, rank, dist, tsteps, 2, graph=graph), world, tsteps, eager)
             log(f"train leg: {train['ms_per_step']} ms/step")
         except Exception as e:       # the headline line must survive a failure of this side measurement
             train = {"error": f"{type(e).__name__}: {e}"}

@@ -23,7 +23,7 @@
 extern "C" {
 #endif
 
-#define TMDIFF_ABI_VERSION 5
+#define TMDIFF_ABI_VERSION 6
 
 #define TMDIFF_OK 0
 #define TMDIFF_E_INVALID (-1)     /* bad argument / shape */
@@ -101,6 +101,11 @@ typedef struct tmdiff_conv3d_desc {
    * mask tensor exists.  in_mask (a caller-supplied mask tensor, parity runs) must then be NULL.  fp32 entry points only. */
   uint64_t drop_seed;
   float drop_p;
+  /* Optional DEVICE word added to drop_seed when the kernel starts (NULL: none).  A launch recorded into a HIP graph is
+   * replayed with the arguments it was captured with; with the per-step part of the seed in device memory (one 8-byte word
+   * the step bumps before the graph runs) every replay still draws a fresh mask -- and forward, weight gradient and
+   * prologue backward of one step still agree, since all three read the same word.  (ABI v6) */
+  const uint64_t* drop_seed_dev;
   /* != 0 (tmdiff_conv3d_wf_fwd only, even H, W % 4 == 0, a grid that does not split its input channels): y2 is written in
    * "space to depth" form [B, 4 Cout, N, H/2, W/2], channel 4 co + 2 ph + pw holding y2[co][n][2i + ph][2j + pw] -- the input
    * form of tmdiff_conv3d_wfll_fwd (the down blocks' Conv_0 + LL band, Hyper_unet_general.py:371-372, :389, :396). */

@@ -385,6 +385,11 @@ def main():
     arrs["cross_masked"] = m(randn(163, 2, 256, 128), context=randn(164, 2, 77, 768), mask=mask)
     m = fill_weights_(RA.CrossAttention(128, heads=4, dim_head=32), seed=3).eval()
     arrs["self"] = m(randn(165, 2, 64, 128))
+    # the CLIP-context shape of the reference's defaults (CrossAttention(query_dim, context_dim=768, heads=8, dim_head=64),
+    # core/Attention.py:165-170) at a small query count: 77 keys x d_head 64 -- the small-context kernel's shape
+    m = fill_weights_(RA.CrossAttention(128, context_dim=768, heads=2, dim_head=64), seed=3).eval()
+    arrs["cross_d64"] = m(randn(171, 2, 200, 128), context=randn(164, 2, 77, 768))
+    arrs["cross_d64_masked"] = m(randn(171, 2, 200, 128), context=randn(164, 2, 77, 768), mask=mask)
     m = fill_weights_(RA.BasicTransformerBlock(128, 8, 16, context_dim=768, checkpoint=False), seed=3).eval()
     arrs["block"] = m(randn(166, 2, 64, 128), context=randn(167, 2, 77, 768))
     m = RA.SpatialTransformer(128, 8, 16, depth=1, context_dim=768, use_checkpoint=False)

@@ -38,8 +38,11 @@ def test_primitives():
     assert_close(ops.geglu(cu(u)).cpu(), a * F.gelu(gate), 1e-6, 1e-6, "geglu")
     assert_close(ops.geglu(cu(u), gelu_only=True).cpu(), F.gelu(u), 1e-6, 1e-6, "gelu")
     # (head dims 64 / 128 take the pipelined LDS-DMA kernel, the others the simple one: ragged Nq / Nk for both)
+    # (... and d_head 64 with at most 96 keys -- the CLIP context -- the small-context kernel: K / V resident in LDS, single-pass
+    #  softmax; 77 / 80 keys (80 key rows in LDS), 96 and 81 (96 rows), one key tile, several query blocks per wave, ragged Nq)
     for b, h, nq, nk, d in ((2, 8, 256, 77, 16), (1, 4, 64, 64, 32), (2, 1, 200, 200, 64), (1, 2, 33, 5, 128), (2, 4, 300, 77, 64),
-                            (1, 1, 1024, 1024, 128), (3, 2, 129, 97, 64)):
+                            (1, 1, 1024, 1024, 128), (3, 2, 129, 97, 64), (1, 2, 1200, 80, 64), (2, 2, 130, 96, 64),
+                            (1, 1, 64, 13, 64), (1, 8, 4096, 77, 64), (1, 3, 1000, 81, 64), (2, 1, 31, 33, 64)):
         q, k, v = randn(12, b, nq, h * d), randn(13, b, nk, h * d), randn(14, b, nk, h * d)
         split = lambda t: t.reshape(t.shape[0], t.shape[1], h, d).permute(0, 2, 1, 3)
         want = F.scaled_dot_product_attention(split(q), split(k), split(v), scale=d ** -0.5)
@@ -69,6 +72,11 @@ def test_modules_vs_reference_fixture(golden):
     assert_close(hip(cu(x), context=cu(ctx), mask=mask).cpu(), g["cross_masked"], 2e-5, 2e-5, "masked cross attention")
     ref, hip = pair(R.CrossAttention, A.CrossAttention, 128, heads=4, dim_head=32)
     assert_close(hip(cu(randn(165, 2, 64, 128))).cpu(), g["self"], 2e-5, 2e-5, "self attention")
+    # the reference's default cross-attention shape: 77 context tokens, d_head 64 (the small-context kernel)
+    ref, hip = pair(R.CrossAttention, A.CrossAttention, 128, context_dim=768, heads=2, dim_head=64)
+    x64 = randn(171, 2, 200, 128)
+    assert_close(hip(cu(x64), context=cu(ctx)).cpu(), g["cross_d64"], 2e-5, 2e-5, "cross attention, 77 keys x d_head 64")
+    assert_close(hip(cu(x64), context=cu(ctx), mask=mask).cpu(), g["cross_d64_masked"], 2e-5, 2e-5, "... masked")
     ref, hip = pair(R.BasicTransformerBlock, A.BasicTransformerBlock, 128, 8, 16, context_dim=768)
     assert_close(hip(cu(randn(166, 2, 64, 128)), context=cu(randn(167, 2, 77, 768))).cpu(), g["block"], 3e-5, 3e-5)
     ref, hip = pair(R.SpatialTransformer, A.SpatialTransformer, 128, 8, 16, depth=1, context_dim=768)

@@ -305,6 +305,97 @@ def test_ragged_tile_sizes_vs_oracle(channels, b, c, h, w):
 _C4_ORACLE = {}
 
 
+def _c4_inputs():
+    B = 8
+    return case_inputs(3420, B, 8, 64), randn(3421, B, 8, 64, 64), np.random.RandomState(7).randint(1, 1001, size=B)
+
+
+def _c4_oracle(d, noise):
+    """The oracle's side of the full-size finetune step, once for all tests that use it (CPU autograd of a batch of 8 at
+    full width; np.random.randint must already be patched to the shared timesteps)."""
+    if _C4_ORACLE:
+        return _C4_ORACLE
+    ref_net = U.fill_weights_(U.WavBESTRef(channels=FULL)).eval()
+    for loss_type in ("l1", "l2"):
+        ora = GeneralDiffusionRef(ref_net, loss_type, noise_fn=lambda like: noise)
+        ora.set_loss("cpu")
+        ora.set_new_noise_schedule({"schedule": "cosine", "n_timestep": 1000}, "cpu")
+        ref_net.zero_grad()
+        lo = ora(d, "WV3")
+        if loss_type == "l2":
+            lo.backward()
+        _C4_ORACLE[loss_type] = float(lo)
+    _C4_ORACLE["grads"] = {k: (None if p.grad is None else p.grad.clone()) for k, p in ref_net.named_parameters()}
+    return _C4_ORACLE
+
+
+def test_config4_finetune_step_captured_in_a_hip_graph_vs_oracle_autograd():
+    """the finetune forward + backward RECORDED INTO A HIP GRAPH and replayed (tmdiff_amd.model.CapturedStep
+    records exactly this call; reference model.py:40-47, diffusion_general.py:349-370): local batch 8 of 8x64x64 tiles at
+    full width, timesteps / noise in fixed device tensors, the L2 loss and all 216 gradients of the REPLAY against the
+    oracle's CPU autograd -- and a second replay on new inputs in the same tensors against an eager evaluation."""
+    from tmdiff_amd import ops
+    from tmdiff_amd.diffusion_general import GeneralDiffusion
+    d, noise, times = _c4_inputs()
+    orig = np.random.randint
+    np.random.randint = lambda lo, hi, size: times
+    try:
+        want = _c4_oracle(d, noise)
+    finally:
+        np.random.randint = orig
+    net = _hip_net(FULL)
+    diff = GeneralDiffusion(net, "l2").cuda()
+    diff.set_loss("cuda")
+    diff.set_new_noise_schedule({"schedule": "cosine", "n_timestep": 1000}, "cuda")
+    static = {k: cu(v) for k, v in d.items() if k in ("Res", "PAN", "MS")}
+    t_dev = torch.from_numpy(times).view(8, 1).cuda()
+    a_dev = torch.tensor(diff.sqrt_alphas_cumprod_prev[times], dtype=torch.float32).cuda()
+    nz = cu(noise)
+    for _ in range(2):                                     # eager warm-up: packed-weight sets, workspaces, allocator
+        net.zero_grad(set_to_none=True)
+        diff.p_losses_with(static, "WV3", t_dev, a_dev, nz).backward()
+    net.zero_grad(set_to_none=True)
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(g):
+        loss = diff.p_losses_with(static, "WV3", t_dev, a_dev, nz)
+        loss.backward()
+    for p in net.parameters():                             # recording ran nothing: poison what the replay must produce
+        if p.grad is not None:
+            p.grad.fill_(float("nan"))
+    g.replay()
+    assert abs(float(loss) - want["l2"]) <= 1e-5 * abs(want["l2"]), (float(loss), want["l2"])
+    n = 0
+    for k, p in net.named_parameters():
+        if p.grad is None:
+            assert want["grads"][k] is None, k
+            continue
+        n += 1
+        m, l2 = rel_err(p.grad, want["grads"][k])
+        assert l2 <= 1e-4, (k, m, l2)
+    assert n == 272 - 56
+    # new inputs through the same static tensors: the replay equals an eager call (same launches, same arithmetic)
+    d2 = case_inputs(3440, 8, 8, 64)
+    for k in static:
+        static[k].copy_(cu(d2[k]))
+    t_dev.copy_(torch.from_numpy(times[::-1].copy()).view(8, 1))
+    a_dev.copy_(torch.tensor(diff.sqrt_alphas_cumprod_prev[times[::-1]], dtype=torch.float32))
+    nz.copy_(cu(randn(3441, 8, 8, 64, 64)))
+    g.replay()
+    got_loss, got = float(loss), {k: p.grad.clone() for k, p in net.named_parameters() if p.grad is not None}
+    net.zero_grad(set_to_none=True)
+    eager = diff.p_losses_with(static, "WV3", t_dev, a_dev, nz)
+    eager.backward()
+    assert got_loss == float(eager)
+    off = []
+    for k, p in net.named_parameters():
+        if p.grad is not None and not torch.equal(got[k], p.grad):
+            off.append((float((got[k] - p.grad).abs().max() / p.grad.abs().max().clamp_min(1e-30)), k))
+    print("replay vs eager, tensors that are not bit-identical (max-rel difference, name):", sorted(off, reverse=True)[:10])
+    # (same launches, same arithmetic: bit-identical except where a reduction's order depends on the launch stream's
+    #  workspace -- nothing may differ beyond fp32 rounding of a sum)
+    assert all(m <= 2e-6 for m, _ in off), sorted(off, reverse=True)[:5]
+
+
 @pytest.mark.parametrize("switches", [{}, {"wgrad_wino": False}, {"train_ll_wino": False}, {"wf_pair": False}],
                          ids=["defaults", "wgrad_direct", "train_ll_direct", "no_pair_mode"])
 def test_config4_finetune_step_vs_oracle_autograd(switches):
@@ -319,10 +410,7 @@ def test_config4_finetune_step_vs_oracle_autograd(switches):
     import collections
     from tmdiff_amd import ops
     from tmdiff_amd.diffusion_general import GeneralDiffusion
-    B = 8
-    d = case_inputs(3420, B, 8, 64)
-    noise = randn(3421, B, 8, 64, 64)
-    times = np.random.RandomState(7).randint(1, 1001, size=B)
+    d, noise, times = _c4_inputs()
     names = ["up1.up1.convH_0.0.weight", "down1.down.Conv_0.weight", "final.conv24.weight", "conv2.conv21.weight",
              "down2_1.conv20.conv21.weight", "down3.down.Conv_1.weight", "middle1.conv20.weight", "up2.conv20.conv20.weight",
              "up3.up1.Conv_2.weight", "final.conv21.conv20.bias", "down1.conv20.dense1.dense.weight", "embed.2.weight",
@@ -330,19 +418,7 @@ def test_config4_finetune_step_vs_oracle_autograd(switches):
     orig = np.random.randint
     np.random.randint = lambda lo, hi, size: times
     try:
-        # the oracle's side once for all parametrisations (CPU autograd of a batch of 8 at full width)
-        if not _C4_ORACLE:
-            ref_net = U.fill_weights_(U.WavBESTRef(channels=FULL)).eval()
-            for loss_type in ("l1", "l2"):
-                ora = GeneralDiffusionRef(ref_net, loss_type, noise_fn=lambda like: noise)
-                ora.set_loss("cpu")
-                ora.set_new_noise_schedule({"schedule": "cosine", "n_timestep": 1000}, "cpu")
-                ref_net.zero_grad()
-                lo = ora(d, "WV3")
-                if loss_type == "l2":
-                    lo.backward()
-                _C4_ORACLE[loss_type] = float(lo)
-            _C4_ORACLE["grads"] = {k: (None if p.grad is None else p.grad.clone()) for k, p in ref_net.named_parameters()}
+        _c4_oracle(d, noise)
         net = _hip_net(FULL)
         net.eval()
         res = {}

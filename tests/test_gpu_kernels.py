@@ -737,7 +737,10 @@ def test_conv3d_winograd_along_bands(ops, case):
     assert routing.conv3_family(B, cin, cout, N, H, W, groups) in ("staged", "fused", "wf", "wf_pair")     # (small test grids)
     with ops.config.override(wino_min_blocks=1):
         fam = routing.conv3_family(B, cin, cout, N, H, W, groups)
-        assert fam == ("wino4" if fallback.wino_planes(N) == 6 else "wino2") if N not in (4, 8) or W < 16 else fam in ("wf", "wf_pair", "wino4", "wino2")
+        if N not in (4, 8):
+            assert fam == ("wino4" if fallback.wino_planes(N) == 6 else "wino2"), fam
+        else:         # (4 / 8 bands: conv3d_wf wherever its tiles are filled, this module only for the narrow planes it leaves)
+            assert fam in ("wf", "wf_pair", "wino4", "wino2"), fam
         if N not in (4, 8):        # ... and ops.conv3d_auto dispatches here, with the same bits
             weights = ops.ConvWeights(lambda: ops.pack_conv_weight(cu(w), groups=groups), None,
                                       lambda planes: ops.pack_conv_weight_wino(cu(w), groups=groups, planes=planes))
@@ -849,6 +852,60 @@ def test_conv3d_winograd_data_gradient_weights(ops, case):
     assert_close(dx, want, 2e-5, 2e-6, "winograd data gradient vs CPU autograd")
     direct = ops.conv3d([cu(g)], ops.pack_conv_weight(cu(w), groups=groups, mode=1), cin, 3, groups=groups)
     assert_close(dx, direct.cpu(), 1e-5, 2e-6, "winograd data gradient vs the direct kernel")   # (F(4,3): 1e-6 vs fp64 by itself)
+
+
+def test_dropout_seed_word_in_device_memory(ops):
+    """tmdiff_conv3d_desc.drop_seed_dev (ABI v6): the in-kernel dropout seed is drop_seed + *drop_seed_dev, read when the
+    kernel starts -- a launch recorded into a HIP graph draws a fresh mask on every replay once the word is bumped.  The
+    prologue pass (conv3d_wf / staged), the fused direct kernel, the weight gradient's own prologue and the prologue
+    backward all honour it: with word w and seed s they reproduce seed s + w without a word, bit for bit."""
+    from tmdiff_amd import autograd as A
+    torch.manual_seed(3)
+    x = torch.randn(2, 32, 8, 16, 16, device="cuda")
+    w = torch.randn(32, 32, 3, 3, 3, device="cuda") / 30
+    sh = torch.randn(2, 32, device="cuda") * 0.3
+    wd, wf = ops.pack_conv_weight(w), ops.pack_conv_weight_wino(w, mode=2, planes=6)
+
+    def run(seed, word):
+        ops.DROP_WORD = None if word is None else torch.tensor([word], dtype=torch.int64, device="cuda")
+        try:
+            xp = torch.empty_like(x)
+            y_wf = ops.conv3d_wf([x], wf, 32, in_shift=sh, in_act=True, drop=(seed, 0.2), xp_out=xp)
+            y_fused = ops.conv3d([x], wd, 32, 3, in_shift=sh, in_act=True, drop=(seed, 0.2), staged=False)
+            g = torch.ones_like(y_wf)
+            d = ops.make_conv_desc([x], 0, 32, 3, g, in_shift=sh, in_act=True, drop=(seed, 0.2))
+            dw = ops.conv3d_wgrad(d, g, tuple(w.shape))
+            dx = torch.empty_like(x)
+            dsh, _ = ops.conv3d_prologue_bwd(d, g, [dx], [False], True, False)
+            return xp, y_wf, y_fused, dw, dx, dsh
+        finally:
+            ops.DROP_WORD = None
+
+    base = run(1000, None)
+    assert 0.1 < float((base[0] == 0).float().mean()) < 0.3
+    moved = run(1000, 7)
+    assert not torch.equal(base[0], moved[0])                       # another word, another mask
+    for a, b in zip(run(1007, None), moved):                        # ... namely the mask of seed + word
+        assert torch.equal(a, b)
+    for a, b in zip(run(1000, 0), base):
+        assert torch.equal(a, b)
+    # inside a graph: the word is bumped by a recorded kernel, every replay draws the next mask
+    word = torch.tensor([50], dtype=torch.int64, device="cuda")
+    ops.DROP_WORD = word
+    try:
+        xp = torch.empty_like(x)
+        ops.conv3d_wf([x], wf, 32, in_shift=sh, in_act=True, drop=(1000, 0.2), xp_out=xp)     # warm-up (workspaces)
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g):
+            word.add_(1)
+            ops.conv3d_wf([x], wf, 32, in_shift=sh, in_act=True, drop=(1000, 0.2), xp_out=xp)
+        g.replay()
+        first = xp.clone()
+        g.replay()
+        assert int(word) == 52 and not torch.equal(first, xp)
+    finally:
+        ops.DROP_WORD = None
+    assert torch.equal(first, run(1051, None)[0]) and torch.equal(xp, run(1052, None)[0])
 
 
 def test_conv3d_large_plane_config3_shape(ops):

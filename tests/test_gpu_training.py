@@ -234,6 +234,69 @@ def test_packed_weights_follow_a_deep_copy_and_ignore_foreign_weights():
     assert got2[0] == want[0] and torch.equal(got2[1], want[1])
 
 
+def test_captured_finetune_step_follows_the_eager_trainer():
+    """tmdiff_amd.model.DDPM with train.hip_graph: after two eager warm-up steps per (prompt, batch shape) the step -- forward,
+    backward, AdamW -- is ONE HIP-graph launch (reference model.py:40-47).  (1) dropout off, same timesteps and noise: the
+    parameters after six steps follow the eager trainer's (capturable AdamW computes its bias corrections on the device, so
+    agreement is to rounding, not to the bit); (2) dropout on: replays of the recorded launches draw fresh masks (the
+    per-step seed word lives in device memory), the loss stays finite and decreases over a few steps of a fixed batch."""
+    import copy
+    from tmdiff_amd import ops
+    from tmdiff_amd.model import DDPM
+    from tmdiff_amd.util import fill_weights_, synthetic_tile_batch
+    base = {"phase": "train", "gpu_ids": [0], "distributed": False, "path": {"resume": None},
+            "model": {"unet": {"channel_multiplier": [32, 64, 128, 256]}, "diffusion": {"loss_type": "l1"}, "init_type": "orthogonal"},
+            "train": {"optimizer": {"lr": 1e-4}, "max_iter": 1000}}
+    d = synthetic_tile_batch(4100, 4, 8, 32, device=torch.device("cuda"))
+    d["LR"] = d["MS"]
+    gen = torch.Generator().manual_seed(9)
+    noises = [torch.randn(4, 8, 32, 32, generator=gen) for _ in range(6)]
+
+    def run(graph, dropout):
+        opt = copy.deepcopy(base)
+        opt["train"]["hip_graph"] = graph
+        m = DDPM(opt)
+        fill_weights_(m.netG.denoise_fn)
+        m.netG.denoise_fn.invalidate_prepared()
+        m.set_new_noise_schedule({"schedule": "cosine", "n_timestep": 1000}, "train")
+        if not dropout:
+            for mod in m.netG.modules():
+                if isinstance(mod, torch.nn.Dropout):
+                    mod.p = 0.0
+        it = iter(noises)
+        m.netG.noise_fn = lambda like: next(it)
+        np.random.seed(77)
+        torch.manual_seed(5)
+        losses = []
+        for _ in range(6):
+            m.feed_data(dict(d))
+            m.optimize_parameters("WV3")
+            losses.append(float(m.get_current_log()["l_pix"]))
+        return m, losses
+
+    eager, le = run(False, False)
+    graph, lg = run(True, False)
+    step = next(iter(graph._captured.values()))
+    assert graph.use_graph and len(graph._captured) == 1 and step.replays == 4          # 2 eager warm-up steps + 4 replays
+    assert np.allclose(le, lg, rtol=2e-5), (le, lg)
+    worst = 0.0
+    for (k, p), (_, q) in zip(eager.netG.named_parameters(), graph.netG.named_parameters()):
+        worst = max(worst, float((p - q).abs().max() / p.abs().max().clamp_min(1e-12)))
+    assert worst <= 2e-4, worst                      # six AdamW steps of lr <= 6e-6 (warm-up schedule): tiny updates, tiny differences
+    print(f"captured vs eager trainer after 6 steps: losses {lg}, worst relative parameter difference {worst:.2e}")
+    del eager, graph
+    torch.cuda.empty_cache()
+    # (2) dropout on: fresh masks per replay
+    m, losses = run(True, True)
+    step = next(iter(m._captured.values()))
+    assert all(np.isfinite(losses))
+    word0 = int(ops.DROP_WORD)
+    step.replay()
+    step.replay()
+    assert int(ops.DROP_WORD) == word0 + 2 and np.isfinite(float(step.loss))     # the graph itself bumps the seed word
+    # (that the kernels add the word to their seeds: tests/test_gpu_kernels.py::test_dropout_seed_word_in_device_memory)
+
+
 def test_trainer_wrapper_roundtrip(tmp_path):
     """DDPM wrapper (reference model.py API): train steps, EMA, save -> load into a fresh wrapper, test()."""
     import copy

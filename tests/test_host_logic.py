@@ -25,7 +25,7 @@ def test_library_exports_every_declared_symbol():
     for name in sorted(declared):
         assert hasattr(lib, name), f"{name} is declared in include/tmdiff_hip.h but not exported"
     assert declared == set(_lib.SIGNATURES), (declared ^ set(_lib.SIGNATURES))
-    assert _lib.ABI_VERSION == 5
+    assert _lib.ABI_VERSION == 6
     assert ctypes.sizeof(_lib.Conv3dDesc) % 8 == 0
 
 

@@ -254,6 +254,138 @@ __global__ void __launch_bounds__(256, 2) attn_fwd_dma_kernel(const AttnArgs a) 
 }
 
 // ---------------------------------------------------------------------------------------------------------
+// Small-context variant (CrossAttention on the CLIP context: 77 keys, d_head 64 -- core/Attention.py:165-214 with
+// context [B, 77, 768]): Nk <= NKR keys, D == 64.  The K and V of one (batch, head) are 2 x 20 KB: they are loaded into LDS
+// ONCE per workgroup and stay there while its four waves walk over QPW queries, 32 at a time -- no K/V tile loop, no block
+// barrier after the prologue, and the softmax is SINGLE-PASS (all scores of a query are in registers: one max, one sum, no
+// running rescale of the output accumulator).  A wave stages its 32 query rows through a wave-private LDS tile (coalesced
+// rows in, this lane's row out), computes S^T = K Q^T for the ceil(Nk / 32) key tiles, and skips the P V MFMAs of 8-key
+// groups that lie entirely beyond Nk (77 keys: 80 of 96 key slots are multiplied); the next block's query rows are already
+// in flight while the MFMAs of the current one run.  LDS: K 20.8 KB (odd row stride) + V 20.5 KB + 4 x 8.3 KB staging = 74.5
+// KB at NKR = 80: two workgroups per CU.
+// ---------------------------------------------------------------------------------------------------------
+template <int NKR>   // key rows held in LDS: 80 (Nk <= 80) or 96
+__global__ void __launch_bounds__(256, 2) attn_ctx_kernel(const AttnArgs a, const int qpw) {
+  constexpr int D = 64, KS = D + 1, NT = (NKR + 31) / 32;
+  __shared__ float ks[NKR * KS];
+  __shared__ __attribute__((aligned(16))) float vs[NKR * D];
+  __shared__ float kbias[NT * 32];          // 0 for a kept key, -FLT_MAX for a masked one / a slot beyond Nk
+  __shared__ float stage[4 * 32 * KS];
+  const int tid = threadIdx.x, lane = tid & 63, l31 = lane & 31, h = lane >> 5;
+  const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int bh = blockIdx.y, b = bh / a.H, hd = bh % a.H;
+  const float* qb = a.q + b * a.q_bs + hd * a.q_hs;
+  const float* kb = a.k + b * a.k_bs + hd * a.k_hs;
+  const float* vb = a.v + b * a.v_bs + hd * a.v_hs;
+  float* ob = a.o + b * a.o_bs + hd * a.o_hs;
+  for (int e = tid; e < NKR * D; e += 256) {
+    const int r = e >> 6, c = e & 63;
+    const bool ok = r < a.Nk;
+    ks[r * KS + c] = ok ? kb[(long)r * a.k_rs + c] : 0.f;
+    vs[r * D + c] = ok ? vb[(long)r * a.v_rs + c] : 0.f;
+  }
+  for (int e = tid; e < NT * 32; e += 256)
+    kbias[e] = (e < a.Nk && (!a.mask || a.mask[(long)b * a.Nk + e] != 0)) ? 0.f : -3.4028234e38f;   // masked_fill(-finfo.max), ref :203-204
+  __syncthreads();
+  const int nt = (a.Nk + 31) >> 5;          // key tiles in use (uniform)
+  float* st = stage + wv * 32 * KS;         // this wave's staging tile [32 rows][KS]
+  const int qbeg = blockIdx.x * qpw + wv * 32, qend = min(a.Nq, (blockIdx.x + 1) * qpw);
+  // coalesced rows: float4 i of this lane is row (i * 64 + lane) / 16, columns 4 * ((i * 64 + lane) % 16) ..
+  const int lrow = lane >> 4, lc4 = (lane & 15) * 4;
+  float4 qn[8];
+  auto load_q = [&](int q0) __attribute__((always_inline)) {
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      const int row = q0 + 4 * i + lrow;
+      qn[i] = row < a.Nq ? *reinterpret_cast<const float4*>(qb + (long)row * a.q_rs + lc4) : make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+  };
+  if (qbeg < qend) load_q(qbeg);
+  for (int q0 = qbeg; q0 < qend; q0 += 128) {
+    // ---- this block's queries: staged rows -> this lane's row (query l31), elements 2j + h, pre-scaled ----------------
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      float* dst = st + (4 * i + lrow) * KS + lc4;
+      dst[0] = qn[i].x, dst[1] = qn[i].y, dst[2] = qn[i].z, dst[3] = qn[i].w;
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    float qreg[D / 2];
+#pragma unroll
+    for (int j = 0; j < D / 2; ++j) qreg[j] = st[l31 * KS + 2 * j + h] * a.scale;
+    if (q0 + 128 < qend) load_q(q0 + 128);          // the next block's rows fly under this block's MFMAs
+    // ---- S^T[key, query] for every key tile ---------------------------------------------------------------------------
+    f32x16 s[NT];
+#pragma unroll
+    for (int t = 0; t < NT; ++t) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) s[t][r] = 0.f;
+      if (t < nt) {
+        const int row = min(32 * t + l31, NKR - 1);          // (slots beyond NKR repeat the last row: masked below)
+        const float* krow = ks + row * KS + h;
+#pragma unroll
+        for (int j = 0; j < D / 2; ++j) s[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(krow[2 * j], qreg[j], s[t], 0, 0, 0);
+      }
+    }
+    // ---- single-pass softmax over this lane's query: register r of tile t, half h is key 32 t + (r&3) + 8 (r>>2) + 4 h ----
+    float mx = -3.4028234e38f;
+#pragma unroll
+    for (int t = 0; t < NT; ++t)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const float kbv = kbias[32 * t + (r & 3) + 8 * (r >> 2) + 4 * h];
+        s[t][r] = (t < nt && kbv == 0.f) ? s[t][r] : -3.4028234e38f;
+        mx = fmaxf(mx, s[t][r]);
+      }
+    mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+    float psum = 0.f;
+#pragma unroll
+    for (int t = 0; t < NT; ++t)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const bool slot = 32 * t + (r & 3) + 8 * (r >> 2) + 4 * h < a.Nk;       // (a slot beyond Nk is no key at all)
+        s[t][r] = slot ? __expf(s[t][r] - mx) : 0.f;
+        psum += s[t][r];
+      }
+    psum += __shfl_xor(psum, 32, 64);
+    // ---- O^T[d, query] = sum_key V[key, d] P^T[key, query] ------------------------------------------------------------
+    f32x16 oacc[2];
+#pragma unroll
+    for (int tt = 0; tt < 2; ++tt) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) oacc[tt][r] = 0.f;
+#pragma unroll
+      for (int t = 0; t < NT; ++t)
+#pragma unroll
+        for (int g = 0; g < 4; ++g)
+          if (32 * t + 8 * g < a.Nk) {                        // uniform: whole 8-key groups beyond Nk are skipped
+#pragma unroll
+            for (int r4 = 0; r4 < 4; ++r4) {
+              const int r = 4 * g + r4, key = min(32 * t + r4 + 8 * g + 4 * h, NKR - 1);
+              oacc[tt] = __builtin_amdgcn_mfma_f32_32x32x2f32(vs[key * D + tt * 32 + l31], s[t][r], oacc[tt], 0, 0, 0);
+            }
+          }
+    }
+    // ---- out[query, d] = O^T[d, query] / l: transpose through the staging tile, coalesced float4 rows out -----------------
+    const float inv = 1.f / psum;
+    __builtin_amdgcn_wave_barrier();
+#pragma unroll
+    for (int tt = 0; tt < 2; ++tt)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) st[l31 * KS + tt * 32 + (r & 3) + 8 * (r >> 2) + 4 * h] = oacc[tt][r] * inv;
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      const int row = q0 + 4 * i + lrow;
+      const float* src = st + (4 * i + lrow) * KS + lc4;
+      if (row < a.Nq) *reinterpret_cast<float4*>(ob + (long)row * a.o_rs + lc4) = make_float4(src[0], src[1], src[2], src[3]);
+    }
+    __builtin_amdgcn_wave_barrier();
+  }
+}
+
+// ---------------------------------------------------------------------------------------------------------
 // C[M,N] = A[M,K] W[N,K]^T (+ bias[N]) (+ residual[M,N]); 64x64 tile per workgroup, each wave a 32x32 block.
 // MFMA rows = 32 rows of A (lane holds A[row][k]), cols = 32 output features (lane holds W[feature][k]).
 // ---------------------------------------------------------------------------------------------------------
@@ -385,6 +517,19 @@ extern "C" int tmdiff_attn_fwd(const float* q, const float* k, const float* v, f
   dim3 grid((Nq + 127) / 128, B * H);
   hipStream_t st = as_stream(stream);
   static const bool no_dma = getenv("TMDIFF_ATTN_SIMPLE") != nullptr;   // experiments: the un-pipelined kernel everywhere
+  static const bool no_ctx = getenv("TMDIFF_ATTN_NO_CTX") != nullptr;   // experiments: never the small-context kernel
+  // a short context (the 77 CLIP tokens) with d_head 64: K / V resident in LDS, single-pass softmax.  Needs 16-byte aligned
+  // query / output rows (float4 row pieces).
+  if (!no_dma && !no_ctx && D == 64 && Nk <= 96 && a.q_rs % 4 == 0 && a.o_rs % 4 == 0 && a.q_bs % 4 == 0 && a.q_hs % 4 == 0 &&
+      a.o_bs % 4 == 0 && a.o_hs % 4 == 0 && aligned16(q) && aligned16(out)) {
+    // queries per workgroup: blocks of 128 (4 waves x 32); enough workgroups to fill the chip twice over, at most 1024 queries each
+    int qpw = 128;
+    while (qpw < 1024 && (long)((Nq + 2 * qpw - 1) / (2 * qpw)) * B * H >= 1024) qpw *= 2;
+    dim3 g((Nq + qpw - 1) / qpw, B * H);
+    if (Nk <= 80) attn_ctx_kernel<80><<<g, 256, 0, st>>>(a, qpw);
+    else attn_ctx_kernel<96><<<g, 256, 0, st>>>(a, qpw);
+    return check_launch("attn_fwd");
+  }
   if (!no_dma && (D == 64 || D == 128)) {
     if (D == 64) attn_fwd_dma_kernel<2><<<grid, 256, 0, st>>>(a);
     else attn_fwd_dma_kernel<4><<<grid, 256, 0, st>>>(a);

@@ -93,6 +93,7 @@ struct ApplyArgs {
   float* xp;
   long plane;
   uint64_t drop_seed;      // in-kernel dropout (drop_inv > 0): keep mask from (seed, element index)
+  const uint64_t* drop_seed_dev;   // ... plus this device word (HIP-graph replays: tmdiff_conv3d_desc.drop_seed_dev)
   uint32_t drop_thresh;
   float drop_inv;
 };
@@ -110,6 +111,7 @@ __global__ void __launch_bounds__(256) prologue_apply_kernel(const ApplyArgs a) 
   const float sc = a.in_scale ? a.in_scale[(long)b * a.scale_stride + c] : 1.f;
   float* dst = a.xp + (long)bc * a.plane;
   const bool drop = a.drop_inv > 0.f;
+  const uint64_t dseed = a.drop_seed + (drop && a.drop_seed_dev ? *a.drop_seed_dev : 0ull);
   const uint64_t ebase = (uint64_t)bc * (uint64_t)a.plane;
   if ((a.plane & 3) == 0 && tmdiff_aligned16_dev(xs) && tmdiff_aligned16_dev(dst) && (!msk || tmdiff_aligned16_dev(msk))) {
     for (long i = (blockIdx.x * 256L + threadIdx.x) * 4; i < a.plane; i += 1024L * gridDim.x) {
@@ -126,7 +128,7 @@ __global__ void __launch_bounds__(256) prologue_apply_kernel(const ApplyArgs a) 
         if (a.in_act) t = tmdiff::silu_f(t);
         t *= sc;
         if (msk) t *= m[k];
-        if (drop) t *= tmdiff::drop_keep(a.drop_seed, ebase + (uint64_t)(i + k), a.drop_thresh, a.drop_inv);
+        if (drop) t *= tmdiff::drop_keep(dseed, ebase + (uint64_t)(i + k), a.drop_thresh, a.drop_inv);
         v[k] = t;
       }
       *reinterpret_cast<float4*>(dst + i) = make_float4(v[0], v[1], v[2], v[3]);
@@ -138,7 +140,7 @@ __global__ void __launch_bounds__(256) prologue_apply_kernel(const ApplyArgs a) 
     if (a.in_act) v = tmdiff::silu_f(v);
     v *= sc;
     if (msk) v *= msk[i];
-    if (drop) v *= tmdiff::drop_keep(a.drop_seed, ebase + (uint64_t)i, a.drop_thresh, a.drop_inv);
+    if (drop) v *= tmdiff::drop_keep(dseed, ebase + (uint64_t)i, a.drop_thresh, a.drop_inv);
     dst[i] = v;
   }
 }
@@ -461,6 +463,7 @@ struct PrologueBwdArgs {
   float* d_scale;
   long plane;
   uint64_t drop_seed;      // in-kernel dropout, as in ApplyArgs
+  const uint64_t* drop_seed_dev;
   uint32_t drop_thresh;
   float drop_inv;
   int slices;              // workgroups per (b, c) plane; > 1: d_shift / d_scale hold [B, Cin, slices] partial sums
@@ -484,6 +487,7 @@ __global__ void __launch_bounds__(256) prologue_bwd_kernel(const PrologueBwdArgs
   const float* gp = a.gp + ((long)b * a.Cin + c) * a.plane;
   const float* msk = a.in_mask ? a.in_mask + ((long)b * a.Cin + c) * a.plane : nullptr;
   const bool drop = a.drop_inv > 0.f;
+  const uint64_t dseed = a.drop_seed + (drop && a.drop_seed_dev ? *a.drop_seed_dev : 0ull);
   const uint64_t ebase = ((uint64_t)b * a.Cin + c) * (uint64_t)a.plane;
   // this slice's element range (multiples of 4 when vectorised)
   const bool vec = (a.plane & 3) == 0 && tmdiff_aligned16_dev(xs) && tmdiff_aligned16_dev(gp) &&
@@ -498,7 +502,7 @@ __global__ void __launch_bounds__(256) prologue_bwd_kernel(const PrologueBwdArgs
     const float act = a.in_act ? tmdiff::silu_f(t) : t;
     const float dact = a.in_act ? silu_grad(t) : 1.f;
     float gm = msk ? g * m : g;
-    if (drop) gm *= tmdiff::drop_keep(a.drop_seed, ebase + (uint64_t)i, a.drop_thresh, a.drop_inv);
+    if (drop) gm *= tmdiff::drop_keep(dseed, ebase + (uint64_t)i, a.drop_thresh, a.drop_inv);
     s_sc += gm * act;
     const float dt = gm * sc * dact;
     s_sh += dt;
@@ -726,7 +730,7 @@ int tmdiff::launch_prologue_apply(const tmdiff_conv3d_desc* d, float* xp, hipStr
   q.B = d->B; q.Cin = d->Cin; q.nseg = d->nseg;
   for (int i = 0; i < 3; ++i) { q.seg_c[i] = i < d->nseg ? d->seg_c[i] : 0; q.seg_x[i] = i < d->nseg ? d->seg_x[i] : nullptr; }
   q.in_shift = d->in_shift; q.in_scale = d->in_scale; q.in_mask = d->in_mask; q.in_act = d->in_act;
-  q.drop_seed = d->drop_seed; q.drop_thresh = drop_threshold(d->drop_p);
+  q.drop_seed = d->drop_seed; q.drop_seed_dev = d->drop_seed_dev; q.drop_thresh = drop_threshold(d->drop_p);
   q.drop_inv = d->drop_p > 0.f ? 1.0f / (1.0f - d->drop_p) : 0.f;
   q.shift_stride = d->in_shift_stride > 0 ? d->in_shift_stride : (d->in_shift_stride < 0 ? 0 : d->Cin);
   q.scale_stride = d->in_scale_stride > 0 ? d->in_scale_stride : (d->in_scale_stride < 0 ? 0 : d->Cin);
@@ -869,7 +873,7 @@ extern "C" int tmdiff_conv3d_prologue_bwd_ws(const tmdiff_conv3d_desc* d, const 
   a.in_shift = d->in_shift; a.in_scale = d->in_scale; a.in_mask = d->in_mask; a.in_act = d->in_act;
   a.shift_stride = d->in_shift_stride > 0 ? d->in_shift_stride : (d->in_shift_stride < 0 ? 0 : d->Cin);
   a.scale_stride = d->in_scale_stride > 0 ? d->in_scale_stride : (d->in_scale_stride < 0 ? 0 : d->Cin);
-  a.drop_seed = d->drop_seed; a.drop_thresh = drop_threshold(d->drop_p);
+  a.drop_seed = d->drop_seed; a.drop_seed_dev = d->drop_seed_dev; a.drop_thresh = drop_threshold(d->drop_p);
   a.drop_inv = d->drop_p > 0.f ? 1.0f / (1.0f - d->drop_p) : 0.f;
   a.gp = gp; a.d_shift = d_shift; a.d_scale = d_scale;
   a.plane = (long)d->N * d->H * d->W;

@@ -69,6 +69,7 @@ struct ConvArgs {
   int w_vec4;                               // cout_g % 4 == 0 -> 16-byte weight loads
   unsigned total_blocks;
   uint64_t drop_seed;                       // in-kernel dropout (drop_inv > 0; MASK instantiations): common.h drop_keep
+  const uint64_t* drop_seed_dev;            // ... plus this device word (tmdiff_conv3d_desc.drop_seed_dev), or NULL
   uint32_t drop_thresh;
   float drop_inv;
   int ksplit, split_ch;                     // split-K: ksplit ranges of split_ch input channels (1, cin_g = no split)
@@ -118,6 +119,10 @@ __global__ void __launch_bounds__(256, 2) conv3d_mfma_kernel(const ConvArgs a) {
   constexpr int CO = G::CO;
   __shared__ __attribute__((aligned(16))) float lds[2 * G::STAGE];
 
+  uint64_t dseed = a.drop_seed;
+  if constexpr (MASK) {
+    if (a.drop_seed_dev) dseed += *a.drop_seed_dev;      // (per-step part of the dropout seed: HIP-graph replays)
+  }
   const int tid = threadIdx.x;
   const int lane = tid & 63, wv = tid >> 6;
   const int l31 = lane & 31, khalf = lane >> 5;
@@ -283,7 +288,7 @@ __global__ void __launch_bounds__(256, 2) conv3d_mfma_kernel(const ConvArgs a) {
         if constexpr (MASK)  // dropout (training only): a mask tensor read here (not prefetched), or the counter-based hash
           if (cval[ci]) {
             const long ei = ((long)b * a.Cin + g * a.cin_g + cn + ci) * plane + goff[i];
-            t *= a.in_mask ? a.in_mask[ei] : tmdiff::drop_keep(a.drop_seed, (uint64_t)ei, a.drop_thresh, a.drop_inv);
+            t *= a.in_mask ? a.in_mask[ei] : tmdiff::drop_keep(dseed, (uint64_t)ei, a.drop_thresh, a.drop_inv);
           }
         xr[ci][i] = t;
       } else {
@@ -772,7 +777,7 @@ extern "C" int tmdiff_conv3d_fwd(const tmdiff_conv3d_desc* d, tmdiff_stream_t st
   a.in_shift = d->in_shift; a.in_scale = d->in_scale; a.in_mask = d->in_mask; a.in_act = d->in_act;
   TMDIFF_REQUIRE(!(d->in_mask && d->drop_p > 0.f), "conv3d_fwd: give either a mask tensor or drop_p, not both");
   TMDIFF_REQUIRE(d->drop_p >= 0.f && d->drop_p < 1.f, "conv3d_fwd: drop_p=%g", (double)d->drop_p);
-  a.drop_seed = d->drop_seed; a.drop_thresh = drop_threshold(d->drop_p);
+  a.drop_seed = d->drop_seed; a.drop_seed_dev = d->drop_seed_dev; a.drop_thresh = drop_threshold(d->drop_p);
   a.drop_inv = d->drop_p > 0.f ? 1.0f / (1.0f - d->drop_p) : 0.f;
   a.shift_stride = d->in_shift_stride > 0 ? d->in_shift_stride : (d->in_shift_stride < 0 ? 0 : d->Cin);
   a.scale_stride = d->in_scale_stride > 0 ? d->in_scale_stride : (d->in_scale_stride < 0 ? 0 : d->Cin);

@@ -92,6 +92,7 @@ struct WinoInArgs {
   float* v;
   float* xp;                 // optional: the prologue output x' itself [B, Cin, N, H, W] (kept for the weight gradient)
   uint64_t drop_seed;        // in-kernel dropout of x' (drop_inv > 0): common.h drop_keep, element index as in prologue_apply
+  const uint64_t* drop_seed_dev;   // ... plus this device word (tmdiff_conv3d_desc.drop_seed_dev), or NULL
   uint32_t drop_thresh;
   float drop_inv;
 };
@@ -115,6 +116,7 @@ __global__ void __launch_bounds__(256) wino_input_kernel(const WinoInArgs a) {
   const float sh = a.in_shift ? a.in_shift[(long)b * a.shift_stride + c] : 0.f;
   const float sc = a.in_scale ? a.in_scale[(long)b * a.scale_stride + c] : 1.f;
   const bool drop = a.drop_inv > 0.f;
+  const uint64_t dseed = a.drop_seed + (drop && a.drop_seed_dev ? *a.drop_seed_dev : 0ull);
   const bool plain = !a.in_shift && !a.in_scale && !a.in_act && !drop;
   const uint64_t ebase = (uint64_t)bc * (uint64_t)(a.N * hw);
   float* xpp = a.xp ? a.xp + (long)bc * a.N * hw : nullptr;
@@ -131,7 +133,7 @@ __global__ void __launch_bounds__(256) wino_input_kernel(const WinoInArgs a) {
       float u = x + sh;
       const float ua = tmdiff::silu_f(u);
       u = (a.in_act ? ua : u) * sc;
-      if (drop) u *= tmdiff::drop_keep(a.drop_seed, ebase + (uint64_t)idx, a.drop_thresh, a.drop_inv);
+      if (drop) u *= tmdiff::drop_keep(dseed, ebase + (uint64_t)idx, a.drop_thresh, a.drop_inv);
       return u;
     };
 #pragma unroll
@@ -667,7 +669,7 @@ extern "C" int tmdiff_conv3d_wino_fwd_planes(const tmdiff_conv3d_desc* d, void* 
   q.scale_stride = d->in_scale_stride > 0 ? d->in_scale_stride : (d->in_scale_stride < 0 ? 0 : d->Cin);
   q.v = static_cast<float*>(workspace);
   q.xp = xp_out;
-  q.drop_seed = d->drop_seed; q.drop_thresh = drop_threshold(d->drop_p);
+  q.drop_seed = d->drop_seed; q.drop_seed_dev = d->drop_seed_dev; q.drop_thresh = drop_threshold(d->drop_p);
   q.drop_inv = d->drop_p > 0.f ? 1.0f / (1.0f - d->drop_p) : 0.f;
   TMDIFF_REQUIRE(!xp_out || aligned16(xp_out), "conv3d_wino_fwd: xp_out must be 16-byte aligned");
   TMDIFF_REQUIRE(stage >= 0 && stage <= 2, "conv3d_wino_fwd: stage=%d", stage);

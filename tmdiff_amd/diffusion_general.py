@@ -266,15 +266,32 @@ class GeneralDiffusion(nn.Module):
             a = a.expand(x_start.shape[0]).contiguous()
         return ops.q_sample(x_start.contiguous(), noise.contiguous(), a)
 
+    def draw_training_inputs(self, b):
+        """The per-step random inputs of p_losses_dynamic that come from the HOST generator, as the reference draws them
+        (:353-360): integer timesteps 1..T from NumPy's global RNG and their sqrt(alpha_bar) values.  Returns host tensors
+        (int64 [b, 1], float32 [b]); the captured finetune step (tmdiff_amd.model) copies them into fixed device tensors."""
+        time_in = np.random.randint(1, self.num_timesteps + 1, size=b)           # host RNG, as the reference (:353)
+        a = torch.tensor(np.atleast_1d(self.sqrt_alphas_cumprod_prev[time_in]), dtype=torch.float32)
+        return torch.from_numpy(time_in).view(b, -1), a
+
     def p_losses_dynamic(self, x_in, prompt=None):
         x_start = x_in["Res"].float().contiguous()
         b = x_start.shape[0]
-        time_in = np.random.randint(1, self.num_timesteps + 1, size=b)           # host RNG, as the reference (:353)
-        a = torch.tensor(np.atleast_1d(self.sqrt_alphas_cumprod_prev[time_in]), dtype=torch.float32)
+        t_host, a_host = self.draw_training_inputs(b)
         noise = self._noise(x_start)
-        x_noisy = self.q_sample(x_start, a, noise)
-        t_dev = self._to_device(torch.from_numpy(time_in), x_start.device).view(b, -1)
-        x_recon = self.denoise_fn.forward_train(x_noisy, t_dev, x_in["PAN"].float().contiguous(),
+        return self.p_losses_with(x_in, prompt, self._to_device(t_host, x_start.device),
+                                  self._to_device(a_host, x_start.device), noise)
+
+    def p_losses_with(self, x_in, prompt, t_dev, a_dev, noise):
+        """p_losses_dynamic (ref :349-370) on given timesteps t_dev [b, 1], sqrt(alpha_bar) values a_dev [b] and noise, all
+        on the device: q_sample, the differentiable UNet forward, the loss.  Launches kernels only (no host sync, no host ->
+        device copy), so the whole call can be recorded into a HIP graph."""
+        x_start = x_in["Res"].float().contiguous()
+        a = a_dev.reshape(-1).float()
+        if a.numel() == 1 and x_start.shape[0] > 1:
+            a = a.expand(x_start.shape[0])
+        x_noisy = ops.q_sample(x_start, noise.contiguous(), a.contiguous())
+        x_recon = self.denoise_fn.forward_train(x_noisy, t_dev.view(x_start.shape[0], -1), x_in["PAN"].float().contiguous(),
                                                 x_in["MS"].float().contiguous(), prompt)
         return self.loss_func(x_start, x_recon)
 

@@ -16,7 +16,7 @@ from collections import OrderedDict
 import torch
 
 from . import dist as tdist
-from . import networks
+from . import networks, ops
 
 logger = logging.getLogger("base")
 
@@ -52,20 +52,101 @@ class BaseModel:
         return str(network), sum(p.numel() for p in network.parameters())
 
 
+class CapturedStep:
+    """The finetune step of reference model.py:40-47 -- p_losses_dynamic (diffusion_general.py:349-370) forward, backward,
+    AdamW -- for ONE (prompt, batch shape) recorded into a HIP graph: ~700 kernel launches become one graph launch.
+
+    Everything the recorded launches read lives at fixed device addresses: the batch (`Res`, `PAN`, `MS`), the timesteps
+    `t` and their sqrt(alpha_bar) values `a`, the noise, the parameters, the gradients (allocated inside the capture, from
+    the graph's private pool), the AdamW state (capturable=True: its step counter and the learning rate are device tensors)
+    and the per-step dropout word (ops.DROP_WORD, bumped by the graph itself).  Per step the host only (1) copies the new
+    batch into the static tensors, (2) draws the timesteps from NumPy's RNG exactly as the reference does and copies them
+    and their table values in (two small pinned, non-blocking copies), (3) fills the noise tensor, (4) launches the graph.
+    The recorded step is the eager one launch for launch (same kernels, same order, same arithmetic)."""
+
+    def __init__(self, trainer, data, prompt):
+        self.trainer, self.prompt = trainer, prompt
+        dev = trainer.device
+        self.static = {k: torch.empty_like(data[k], dtype=torch.float32, memory_format=torch.contiguous_format)
+                       for k in ("Res", "PAN", "MS")}
+        b = data["Res"].shape[0]
+        self.t = torch.ones(b, 1, dtype=torch.int64, device=dev)
+        self.a = torch.ones(b, dtype=torch.float32, device=dev)
+        self.noise = torch.empty_like(self.static["Res"])
+        self.graph = torch.cuda.CUDAGraph()
+        self.loss = None
+        self.replays = 0
+
+    def load(self, data):
+        """Host side of a step: the batch, the host-drawn timesteps and the noise into the static tensors."""
+        diff = self.trainer.netG
+        for k, dst in self.static.items():
+            dst.copy_(data[k], non_blocking=True)
+        t_host, a_host = diff.draw_training_inputs(self.t.shape[0])
+        self.t.copy_(t_host.pin_memory(), non_blocking=True)
+        self.a.copy_(a_host.pin_memory(), non_blocking=True)
+        if diff.noise_fn is not None:
+            self.noise.copy_(diff.noise_fn(self.noise).to(self.noise.device))
+        else:
+            self.noise.normal_()
+
+    def _step(self):
+        tr = self.trainer
+        ops.DROP_WORD.add_(1)                  # a fresh dropout mask per replay: the kernels add this word to their seeds
+        loss = tr.netG.p_losses_with(self.static, self.prompt, self.t, self.a, self.noise).sum()
+        loss.backward()
+        return loss
+
+    def capture(self):
+        tr = self.trainer
+        tr.netG.zero_grad(set_to_none=True)          # gradients are (re)allocated inside the capture: static from here on
+        with torch.cuda.graph(self.graph):
+            loss = self._step()
+            if not tr.split_graph:
+                tr.optG.step()
+        self.loss = loss.detach()
+        self.opt_graph = None
+        if tr.split_graph:       # > 1 rank: the gradient exchange runs between two graphs (see DDPM.optimize_parameters)
+            self.opt_graph = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(self.opt_graph):
+                tr.optG.step()
+        return self
+
+    def replay(self):
+        self.graph.replay()
+        if self.opt_graph is not None:
+            tdist.allreduce_gradients(self.trainer.netG, op=self.trainer.grad_reduce)
+            self.opt_graph.replay()
+        self.replays += 1
+
+
 class DDPM(BaseModel):
+    GRAPH_WARMUP = 2       # eager steps per (prompt, batch shape) before its step is captured (optimizer state, packed-weight
+                           # sets and workspaces exist by then)
+
     def __init__(self, opt):
         super().__init__(opt)
         self.optG = None
         self.scheduler = None
         self.netG = self.set_device(networks.define_General(opt))
         self.schedule_phase = None
-        self.grad_reduce = (opt.get("train") or {}).get("grad_reduce", "sum") if isinstance(opt, dict) else "sum"
+        train_opt = (opt.get("train") or {}) if isinstance(opt, dict) else {}
+        self.grad_reduce = train_opt.get("grad_reduce", "sum")
+        # train.hip_graph (default: ops.config.train_graph / TMDIFF_TRAIN_GRAPH): record the finetune step into a HIP graph
+        self.use_graph = bool(train_opt.get("hip_graph", ops.config.train_graph)) and self.device.type == "cuda"
+        self.split_graph = False
+        self._captured, self._eager_steps, self._drop_word = {}, {}, None
         self.reducer = None
         self.set_loss()
         if self.opt["phase"] == "train":
             self.netG.train()
             optim_params = [p for n, p in self.netG.named_parameters() if "clip_text" not in n]
-            self.optG = torch.optim.AdamW(optim_params, lr=opt["train"]["optimizer"]["lr"], weight_decay=1e-4)
+            lr = opt["train"]["optimizer"]["lr"]
+            if self.use_graph:       # capturable: step counter and learning rate on the device, no host reads inside step()
+                self.optG = torch.optim.AdamW(optim_params, lr=torch.tensor(float(lr), device=self.device), weight_decay=1e-4,
+                                              capturable=True)
+            else:
+                self.optG = torch.optim.AdamW(optim_params, lr=lr, weight_decay=1e-4)
             self.scheduler = linear_warmup_decay(self.optG, 100, opt["train"]["max_iter"])
             self.log_dict = OrderedDict()
         self.load_network()
@@ -74,9 +155,16 @@ class DDPM(BaseModel):
     def feed_data(self, data):
         self.data = self.set_device(data)
 
+    def _lr(self):
+        lr = self.optG.param_groups[0]["lr"]
+        return lr            # (a device tensor in graph mode: formatting it is the only host read, done by whoever logs)
+
     def optimize_parameters(self, prompt=None):
         if self.reducer is None:       # created here: the process group exists by the first step
             self.reducer = tdist.GradReducer(self.netG, op=self.grad_reduce)
+            self.split_graph = self.use_graph and self.reducer.active
+        if self.use_graph:
+            return self._optimize_captured(prompt)
         l_pix = self.netG(self.data, prompt).sum()
         l_pix.backward()                # bucket all-reduces start from hooks while backward is still running
         self.reducer.finish()           # no-op in a single process
@@ -84,7 +172,48 @@ class DDPM(BaseModel):
         self.scheduler.step()
         self.reducer.zero_grad()
         self.log_dict["l_pix"] = l_pix.detach()
-        self.log_dict["lr"] = self.optG.state_dict()["param_groups"][0]["lr"]
+        self.log_dict["lr"] = self._lr()
+
+    def _optimize_captured(self, prompt):
+        """The same step from a HIP graph (CapturedStep).  The first GRAPH_WARMUP steps of every (prompt, batch shape) run
+        eagerly -- without the reducer's hooks: with more than one rank the exchange of a graph step is a flat all-reduce
+        between the backward graph and the optimizer graph, and the warm-up steps do the same."""
+        key = (prompt if not isinstance(prompt, (list, tuple)) else tuple(prompt),
+               tuple((k, tuple(self.data[k].shape)) for k in ("Res", "PAN", "MS")))
+        if self._drop_word is None:      # ONE word per trainer, alive as long as its graphs (they hold its address)
+            self._drop_word = torch.randint(0, 2 ** 40, (1,), dtype=torch.int64).to(self.device)
+        ops.DROP_WORD = self._drop_word
+        step = self._captured.get(key)
+        if step is None:
+            done = self._eager_steps.get(key, 0)
+            if done < self.GRAPH_WARMUP:
+                self._eager_steps[key] = done + 1
+                keep, self.reducer.active = self.reducer.active, False
+                try:
+                    self.netG.zero_grad(set_to_none=True)
+                    l_pix = self.netG(self.data, prompt).sum()
+                    l_pix.backward()
+                finally:
+                    self.reducer.active = keep
+                if self.split_graph:
+                    tdist.allreduce_gradients(self.netG, op=self.grad_reduce)
+                self.optG.step()
+                self.scheduler.step()
+                self.log_dict["l_pix"], self.log_dict["lr"] = l_pix.detach(), self._lr()
+                return
+            step = CapturedStep(self, self.data, prompt)
+            step.load(self.data)
+            keep, self.reducer.active = self.reducer.active, False
+            try:
+                step.capture()            # (recording runs nothing: the replay below is this step)
+            finally:
+                self.reducer.active = keep
+            self._captured[key] = step
+        else:
+            step.load(self.data)
+        step.replay()
+        self.scheduler.step()             # (fills the device learning-rate tensor for the next step)
+        self.log_dict["l_pix"], self.log_dict["lr"] = step.loss, self._lr()
 
     def test(self, continous=False, prompt="QB", guidance=3.0):
         self.netG.eval()

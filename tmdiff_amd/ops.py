@@ -320,6 +320,8 @@ def make_conv_desc(segs, w_packed, cout, ksize, y, groups=1, bias=None, bias_sca
         if in_mask is not None:
             raise ValueError("conv3d: give either in_mask (a mask tensor) or drop=(seed, p)")
         d.drop_seed, d.drop_p = int(drop[0]) & 0xFFFFFFFFFFFFFFFF, float(drop[1])
+        if DROP_WORD is not None:         # the per-step part of the seed lives in device memory (HIP-graph replays)
+            d.drop_seed_dev = DROP_WORD.data_ptr()
     if x_bf16_shape is not None:
         xp = segs[0]
         if len(segs) != 1 or xp.dtype != torch.int16 or xp.dim() != 4 or xp.shape[3] != 8 or not xp.is_contiguous():
@@ -396,11 +398,21 @@ class ConvTimer:
         """{ksize: (launches, ms, flops)}; with by_entry the key is (ksize, C entry point that served the launch)."""
         torch.cuda.synchronize()
         out = {}
-        for e0, e1, fl, k, what, tag in self.records:
+        for e0, e1, fl, k, what, tag, *_ in self.records:
             key = (k, what, tag) if by_entry == "layer" else ((k, what) if by_entry else k)
             n, ms, f = out.get(key, (0, 0.0, 0.0))
             out[key] = (n + 1, ms + e0.elapsed_time(e1), f + fl)
         return out
+
+    def bytes_summary(self, ksize=1):
+        """(launches, ms, algorithmic HBM bytes) of the launches of one kernel size that recorded their bytes (the 1x1x1
+        convolutions: input + output (+ residual) tensors once -- they are bandwidth kernels, priced against the copy rate)."""
+        torch.cuda.synchronize()
+        n, ms, nbytes = 0, 0.0, 0.0
+        for rec in self.records:
+            if rec[3] == ksize and len(rec) > 6:
+                n, ms, nbytes = n + 1, ms + rec[0].elapsed_time(rec[1]), nbytes + rec[6]
+        return n, ms, nbytes
 
 
 def _tag(d):
@@ -414,6 +426,11 @@ TIMER = None      # set to a ConvTimer() to time every conv launch
 COUNTS = None     # set to a collections.Counter() to count convolution launches per C entry point ("conv3d_fwd",
                   # "conv3d_fwd_staged", "conv3d_fwd_bf16", "conv3d_wino4_fwd", "conv3d_wino2_fwd", "conv3d_ll_fwd"): the
                   # tests and bench.py's parity leg assert from it WHICH kernel family produced a result
+
+
+DROP_WORD = None  # an int64 [1] device tensor: its value is added to every in-kernel dropout seed when the kernel starts
+                  # (tmdiff_conv3d_desc.drop_seed_dev).  The captured finetune step (tmdiff_amd.model) sets it and bumps it
+                  # inside the graph, so that replays of the same recorded launches draw fresh masks.
 
 
 FLOPS = None      # set to [0.0] to add up the multiply-add FLOPs the convolution launches EXECUTE on the matrix pipe (Winograd
@@ -512,7 +529,11 @@ def conv3d(segs, w_packed, cout, ksize, out=None, math="fp32", pack_input=None, 
     e0.record()
     check(fwd(C.byref(d), stream_ptr()), what)
     e1.record()
-    TIMER.records.append((e0, e1, 2.0 * b * cout * (d.Cin // d.groups) * ksize ** 3 * n * h * w, ksize, what, _tag(d)))
+    # algorithmic HBM bytes of the launch: input once (2 B per element for packed bf16 units, else 4), outputs once
+    in_b = 2.0 if d.x_bf16 else 4.0
+    y2_b = 0.0 if y2 is None else (2.0 if d.y2_bf16 else 4.0)
+    nbytes = b * n * h * w * (in_b * d.Cin + cout * (4.0 * ((1 if y is not None else 0) + (1 if kw.get("residual") is not None else 0)) + y2_b))
+    TIMER.records.append((e0, e1, 2.0 * b * cout * (d.Cin // d.groups) * ksize ** 3 * n * h * w, ksize, what, _tag(d), nbytes))
     return ret
 
 
