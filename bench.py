@@ -531,7 +531,8 @@ def main():
     if args.mode == "train":
         log(f"rank {rank}/{world}: finetune step on {torch.cuda.get_device_name(dev)}")
         graph = world == 1 and os.environ.get("TMDIFF_BENCH_TRAIN_GRAPH", "1") != "0"
-        eager = train_leg(dev, world, rank, dist, args.steps, args.warmup) if graph else None
+        eager = train_leg(dev, world, rank, dist, args.steps, args.warmup) if (
+            graph and os.environ.get("TMDIFF_BENCH_TRAIN_EAGER", "1") != "0") else None      # (profiling runs: only the graph leg)
         leg = train_leg(dev, world, rank, dist, args.steps, args.warmup, graph=graph)
         if rank == 0:
             obj = train_object(leg, world, args.steps, eager)

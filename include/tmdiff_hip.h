@@ -466,6 +466,20 @@ typedef struct tmdiff_mt_entry {
 int32_t tmdiff_multi_axpby_chunk(void);
 int tmdiff_multi_axpby(const tmdiff_mt_entry* tensors_dev, const int32_t* chunk_tensor_dev, const int32_t* chunk_index_dev,
                        int32_t n_chunks, float ca, float cb, tmdiff_stream_t stream);
+/* AdamW step (torch.optim.AdamW semantics, amsgrad off; reference GeneralModel/model.py:30-31, :43) of a whole list of parameter
+ * tensors in ONE launch, chunked like tmdiff_multi_axpby (same chunk size, same two device tables).  lr_dev / step_dev are DEVICE
+ * scalars (the learning rate; the step count t of THIS update, already incremented, as a float), so a recorded launch can be
+ * replayed from a HIP graph.  In place: p, m (exp_avg), v (exp_avg_sq). */
+typedef struct tmdiff_adamw_entry {
+  float* p;
+  const float* g;
+  float* m;
+  float* v;
+  int64_t n;
+} tmdiff_adamw_entry;
+int tmdiff_multi_adamw(const tmdiff_adamw_entry* tensors_dev, const int32_t* chunk_tensor_dev, const int32_t* chunk_index_dev,
+                       int32_t n_chunks, const float* lr_dev, const float* step_dev, float beta1, float beta2, float eps,
+                       float weight_decay, tmdiff_stream_t stream);
 int tmdiff_x0_from_model(const float* x, const float* model_out, float* x0, int64_t n, float alpha, float sigma,
                          int32_t model_is_x_start, tmdiff_stream_t stream);
 size_t tmdiff_abs_quantile_workspace_bytes(int32_t B, int64_t n_per_sample);

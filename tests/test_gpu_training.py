@@ -234,6 +234,53 @@ def test_packed_weights_follow_a_deep_copy_and_ignore_foreign_weights():
     assert got2[0] == want[0] and torch.equal(got2[1], want[1])
 
 
+def test_fused_adamw_is_torch_adamw():
+    """tmdiff_amd.optim.FusedAdamW (one multi-tensor HIP launch, learning rate and step count read from device scalars) against
+    torch.optim.AdamW (reference model.py:30-31) on the same parameters and gradients: ragged tensor sizes, a parameter
+    without a gradient, a learning-rate schedule, eight steps -- and the state_dict of either continues in the other."""
+    from tmdiff_amd.optim import FusedAdamW
+    g = torch.Generator().manual_seed(4)
+    shapes = [(64, 32, 3, 3, 3), (7,), (33, 5), (1,), (128, 128), (16385,), (3, 3)]
+    base = [torch.randn(s, generator=g) for s in shapes]
+    mk = lambda: [torch.nn.Parameter(t.clone().cuda()) for t in base]
+    pa, pb = mk(), mk()
+    oa = torch.optim.AdamW(pa, lr=1e-3, weight_decay=1e-2)
+    ob = FusedAdamW(pb, lr=torch.tensor(1e-3, device="cuda"), weight_decay=1e-2)
+    sa = torch.optim.lr_scheduler.LambdaLR(oa, lambda k: 1.0 / (1 + k))
+    sb = torch.optim.lr_scheduler.LambdaLR(ob, lambda k: 1.0 / (1 + k))
+
+    def steps(opt_a, opt_b, sch_a, sch_b, params_a, params_b, n, seed):
+        gg = torch.Generator().manual_seed(seed)
+        for it in range(n):
+            for k, (x, y) in enumerate(zip(params_a, params_b)):
+                if k == 6:                      # this one never gets a gradient (56 WavBEST tensors never do)
+                    continue
+                gr = torch.randn(x.shape, generator=gg).cuda() * (10.0 if it == 2 else 1.0)
+                x.grad, y.grad = gr.clone(), gr.clone()
+            opt_a.step(); opt_b.step(); sch_a.step(); sch_b.step()
+        return max(float((x - y).abs().max() / x.abs().max()) for x, y in zip(params_a, params_b))
+
+    worst = steps(oa, ob, sa, sb, pa, pb, 8, 1)
+    assert worst <= 2e-6, worst
+    assert torch.equal(pa[6], pb[6]) and pb[6] not in ob.state or "exp_avg" not in ob.state[pb[6]]
+    assert float(ob.state[pb[0]]["step"]) == 8.0 and ob.state[pb[0]]["step"] is ob.state[pb[3]]["step"]
+    # checkpoints interchange: each optimizer continues from the other's state
+    pc, pd = [torch.nn.Parameter(x.detach().clone()) for x in pa], [torch.nn.Parameter(y.detach().clone()) for y in pb]
+    oc = FusedAdamW(pc, lr=torch.tensor(1e-3, device="cuda"), weight_decay=1e-2)
+    od = torch.optim.AdamW(pd, lr=1e-3, weight_decay=1e-2)
+    sd_a, sd_b = oa.state_dict(), ob.state_dict()
+    sd_b["param_groups"][0]["lr"] = float(sd_b["param_groups"][0]["lr"])
+    sd_b["param_groups"][0]["initial_lr"] = float(sd_b["param_groups"][0]["initial_lr"])
+    sd_a["param_groups"][0]["lr"] = torch.tensor(sd_a["param_groups"][0]["lr"], device="cuda")
+    oc.load_state_dict(sd_a)
+    od.load_state_dict(sd_b)
+    sc = torch.optim.lr_scheduler.LambdaLR(oc, lambda k: 1.0 / (1 + k), last_epoch=7)
+    sdd = torch.optim.lr_scheduler.LambdaLR(od, lambda k: 1.0 / (1 + k), last_epoch=7)
+    worst2 = steps(od, oc, sdd, sc, pd, pc, 3, 2)
+    assert worst2 <= 4e-6 and float(oc.state[pc[0]]["step"]) == 11.0, (worst2, oc.state[pc[0]]["step"])
+    print(f"FusedAdamW vs torch.optim.AdamW: {worst:.2e} after 8 steps, {worst2:.2e} after swapping the state_dicts")
+
+
 def test_captured_finetune_step_follows_the_eager_trainer():
     """tmdiff_amd.model.DDPM with train.hip_graph: after two eager warm-up steps per (prompt, batch shape) the step -- forward,
     backward, AdamW -- is ONE HIP-graph launch (reference model.py:40-47).  (1) dropout off, same timesteps and noise: the

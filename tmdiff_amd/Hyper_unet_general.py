@@ -631,7 +631,7 @@ class WavBEST(nn.Module):
         self.__dict__.pop("_train_pack", None)       # the training path's packed weights (ops.PackedWeights)
         self.__dict__.pop("_train_pack_wino", None)
 
-    _DERIVED = ("_train_pack", "_train_pack_wino", "_emb_dev", "_freqs_dev")
+    _DERIVED = ("_train_pack", "_train_pack_wino", "_emb_dev", "_freqs_dev", "_side_stream")
 
     def __getstate__(self):
         """copy.deepcopy / pickle: everything derived from the parameters' ADDRESSES stays behind (packed weights and their
@@ -760,13 +760,26 @@ class WavBEST(nn.Module):
         def down(name, x, want_high):
             return self.get_submodule(name).run(x, sh(name + ".Dense_0"), scales[name + ".dense1"], want_high=want_high)
 
-        cond = {0: self.conv1.run(scales["conv1.dense2"], pan=PAN.contiguous(), ms=MS.contiguous())}
-        skips = {}
-        h = cond[0]
-        for lvl, dn in enumerate(("down1_1", "down2_1", "down3_1"), start=1):
-            h = resblock(dn + ".conv20", [h])
-            h, skips[lvl] = down(dn + ".down", h, True)
-            cond[lvl] = h
+        # The condition branch (conv1, down*_1: a third of the forward) and the main branch's down path are independent until
+        # the up path.  At the finetune batch most of their launches fill half of the CU slots or exactly one round, so set-up,
+        # epilogue and tail of every launch are exposed; on two streams the workgroups of one branch fill what the other leaves
+        # idle (ops.config.train_two_streams; at B = 32 every launch fills the chip and this gains nothing -- DESIGN.md 3).
+        # Autograd runs each backward node on its forward's stream, so the two backward passes overlap as well.
+        cur = torch.cuda.current_stream(dev)
+        side = None
+        if ops.config.train_two_streams:
+            side = self.__dict__.get("_side_stream")
+            if side is None or side.device != dev:
+                side = self.__dict__["_side_stream"] = torch.cuda.Stream(device=dev)
+            side.wait_stream(cur)
+        cond, skips = {}, {}
+        with torch.cuda.stream(side if side is not None else cur):
+            cond[0] = self.conv1.run(scales["conv1.dense2"], pan=PAN.contiguous(), ms=MS.contiguous())
+            h = cond[0]
+            for lvl, dn in enumerate(("down1_1", "down2_1", "down3_1"), start=1):
+                h = resblock(dn + ".conv20", [h])
+                h, skips[lvl] = down(dn + ".down", h, True)
+                cond[lvl] = h
         hs = [self.conv2.run(scales["conv2.dense2"], xin=x_t.contiguous())]
         h = hs[0]
         for dn in ("down1", "down2", "down3"):
@@ -774,6 +787,10 @@ class WavBEST(nn.Module):
             h, _ = down(dn + ".down", h, False)
             hs.append(h)
         h = resblock("middle1", [hs[3]])
+        if side is not None:          # join: the up path reads the condition branch's tensors on the current stream
+            cur.wait_stream(side)
+            for t in list(cond.values()) + [b_ for bands in skips.values() for b_ in bands if b_ is not None]:
+                t.record_stream(cur)
         for lvl, upn in ((3, "up1"), (2, "up2"), (1, "up3")):
             h = resblock(upn + ".conv20", [h, cond[lvl], hs[lvl]])
             h = self.get_submodule(upn + ".up1").run(h, sh(upn + ".up1.Dense_0"), scales[upn + ".up1.dense1"],

@@ -107,6 +107,7 @@ SIGNATURES = {
     "tmdiff_axpby": (C.c_int, [vp * 4, C.c_float * 4, C.c_int32, vp, C.c_int64, vp]),
     "tmdiff_multi_axpby_chunk": (C.c_int32, []),
     "tmdiff_multi_axpby": (C.c_int, [vp, vp, vp, C.c_int32, C.c_float, C.c_float, vp]),
+    "tmdiff_multi_adamw": (C.c_int, [vp, vp, vp, C.c_int32, vp, vp, C.c_float, C.c_float, C.c_float, C.c_float, vp]),
     "tmdiff_x0_from_model": (C.c_int, [vp, vp, vp, C.c_int64, C.c_float, C.c_float, C.c_int32, vp]),
     "tmdiff_abs_quantile_workspace_bytes": (C.c_size_t, [C.c_int32, C.c_int64]),
     "tmdiff_abs_quantile_clamp": (C.c_int, [vp, C.c_int32, C.c_int64, C.c_float, C.c_float, vp, vp]),

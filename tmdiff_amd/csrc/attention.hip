@@ -265,7 +265,7 @@ __global__ void __launch_bounds__(256, 2) attn_fwd_dma_kernel(const AttnArgs a) 
 // KB at NKR = 80: two workgroups per CU.
 // ---------------------------------------------------------------------------------------------------------
 template <int NKR>   // key rows held in LDS: 80 (Nk <= 80) or 96
-__global__ void __launch_bounds__(256, 2) attn_ctx_kernel(const AttnArgs a, const int qpw) {
+__global__ void __launch_bounds__(256, NKR <= 80 ? 2 : 1) attn_ctx_kernel(const AttnArgs a, const int qpw) {
   constexpr int D = 64, KS = D + 1, NT = (NKR + 31) / 32;
   __shared__ float ks[NKR * KS];
   __shared__ __attribute__((aligned(16))) float vs[NKR * D];

@@ -168,10 +168,23 @@ class GradReducer:
             # bucket slot would be reduced stale and the real gradient not at all -- copy it in and re-point p.grad
             view.copy_(p.grad)
             p.grad = view
+        if p.grad.is_cuda:           # (forward_train may run its two branches on two streams: autograd runs each backward
+            s = torch.cuda.current_stream(p.grad.device)      # node -- and this hook -- on its forward's stream)
+            bk["streams"][s.cuda_stream] = s
         bk["pending"] -= 1
         if bk["pending"] == 0:
-            self._handles.append(dist.all_reduce(bk["flat"], op=dist.ReduceOp.SUM, group=self.group, async_op=True))
+            self._launch(bk)
             self.launched += 1
+
+    def _launch(self, bk):
+        """All-reduce of a bucket whose gradients are all enqueued: the collective is ordered after the CURRENT stream only, so
+        that stream first waits for every other stream that produced one of the bucket's gradients."""
+        if bk["streams"]:
+            cur = torch.cuda.current_stream(bk["flat"].device)
+            for sid, s in bk["streams"].items():
+                if sid != cur.cuda_stream:
+                    cur.wait_stream(s)
+        self._handles.append(dist.all_reduce(bk["flat"], op=dist.ReduceOp.SUM, group=self.group, async_op=True))
 
     def _build(self):
         params = [p for p in self._order if p.grad is not None]
@@ -202,7 +215,7 @@ class GradReducer:
                 p.grad = view
                 views[id(p)] = view
                 off += p.numel()
-            bk = {"flat": flat, "params": ps, "pending": len(ps), "views": views}
+            bk = {"flat": flat, "params": ps, "pending": len(ps), "views": views, "streams": {}}
             self.buckets.append(bk)
             for p in ps:
                 self._bucket_of[id(p)] = bk
@@ -220,7 +233,7 @@ class GradReducer:
         # buckets whose hooks did not all fire (a parameter got no gradient this step: its slot is still zero)
         for bk in self.buckets:
             if bk["pending"] > 0:
-                self._handles.append(dist.all_reduce(bk["flat"], op=dist.ReduceOp.SUM, group=self.group, async_op=True))
+                self._launch(bk)
                 bk["pending"] = 0
         for h in self._handles:
             h.wait()
@@ -244,6 +257,7 @@ class GradReducer:
         for bk in self.buckets:
             bk["flat"].zero_()
             bk["pending"] = len(bk["params"])
+            bk["streams"] = {}
         for p in self.module.parameters():           # gradient-free parameters stay None
             if p.grad is not None and id(p) not in self._bucket_of:
                 p.grad = None

@@ -58,7 +58,7 @@ class CapturedStep:
 
     Everything the recorded launches read lives at fixed device addresses: the batch (`Res`, `PAN`, `MS`), the timesteps
     `t` and their sqrt(alpha_bar) values `a`, the noise, the parameters, the gradients (allocated inside the capture, from
-    the graph's private pool), the AdamW state (capturable=True: its step counter and the learning rate are device tensors)
+    the graph's private pool), the AdamW state (tmdiff_amd.optim.FusedAdamW: step counter and learning rate are device scalars)
     and the per-step dropout word (ops.DROP_WORD, bumped by the graph itself).  Per step the host only (1) copies the new
     batch into the static tensors, (2) draws the timesteps from NumPy's RNG exactly as the reference does and copies them
     and their table values in (two small pinned, non-blocking copies), (3) fills the noise tensor, (4) launches the graph.
@@ -100,7 +100,9 @@ class CapturedStep:
     def capture(self):
         tr = self.trainer
         tr.netG.zero_grad(set_to_none=True)          # gradients are (re)allocated inside the capture: static from here on
-        with torch.cuda.graph(self.graph):
+        # (one stream: a graph with the two branches of forward_train as parallel paths replays slower than the single-stream
+        #  one on this runtime -- 27.7 against 27.1 ms, and its launch costs the host 13 ms instead of 1)
+        with ops.config.override(train_two_streams=False), torch.cuda.graph(self.graph):
             loss = self._step()
             if not tr.split_graph:
                 tr.optG.step()
@@ -142,9 +144,11 @@ class DDPM(BaseModel):
             self.netG.train()
             optim_params = [p for n, p in self.netG.named_parameters() if "clip_text" not in n]
             lr = opt["train"]["optimizer"]["lr"]
-            if self.use_graph:       # capturable: step counter and learning rate on the device, no host reads inside step()
-                self.optG = torch.optim.AdamW(optim_params, lr=torch.tensor(float(lr), device=self.device), weight_decay=1e-4,
-                                              capturable=True)
+            if self.device.type == "cuda":
+                # torch.optim.AdamW as ONE multi-tensor HIP launch (tmdiff_amd.optim; same state layout and checkpoint
+                # files); the learning rate is a device scalar the scheduler fills, so the step can live in a HIP graph
+                from .optim import FusedAdamW
+                self.optG = FusedAdamW(optim_params, lr=torch.tensor(float(lr), device=self.device), weight_decay=1e-4)
             else:
                 self.optG = torch.optim.AdamW(optim_params, lr=lr, weight_decay=1e-4)
             self.scheduler = linear_warmup_decay(self.optG, 100, opt["train"]["max_iter"])

@@ -44,6 +44,9 @@ class KernelConfig:
     wgrad_bias         TMDIFF_WGRAD_BIAS        False    direct weight gradient accumulates the bias gradient in-kernel
     wino_multipack     TMDIFF_WINO_MULTIPACK    True     finetune step: all Winograd weight forms re-packed by one launch
     train_graph        TMDIFF_TRAIN_GRAPH       False    (model.DDPM) capture the finetune step into a HIP graph
+    train_two_streams  TMDIFF_TRAIN_STREAMS     True     forward_train runs the condition branch on a second stream beside the
+                                                         main branch's down path (at a local batch of 8 most launches fill half
+                                                         of the CU slots); autograd then runs their backward passes side by side too
 
     Library-side experiment variables (read by libtmdiff_hip.so itself, C getenv): TMDIFF_SPLITK, TMDIFF_SPLITK_LONG,
     TMDIFF_WF_STAGGER, TMDIFF_WINO_STAGGER, TMDIFF_WINO_F4, TMDIFF_EPILOGUE_VEC, TMDIFF_SMALLGRID, TMDIFF_WW_PHASES,
@@ -63,6 +66,7 @@ class KernelConfig:
         "wgrad_wino": ("TMDIFF_WGRAD_WINO", _FLAG(True), True), "wgrad_wino_bias": ("TMDIFF_WGRAD_WINO_BIAS", _FLAG(True), True),
         "wgrad_bias": ("TMDIFF_WGRAD_BIAS", _FLAG(False), False), "wino_multipack": ("TMDIFF_WINO_MULTIPACK", _FLAG(True), True),
         "train_graph": ("TMDIFF_TRAIN_GRAPH", _FLAG(False), False),
+        "train_two_streams": ("TMDIFF_TRAIN_STREAMS", _FLAG(True), True),
     }
 
     def __init__(self, env=None):
