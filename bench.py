@@ -331,7 +331,7 @@ def source_sha16():
     return h.hexdigest()[:16]
 
 
-TRAFFIC_FILE = "profiles/r03_bench_traffic.json"
+TRAFFIC_FILE = "profiles/r04_bench_traffic.json"
 
 
 def load_traffic():

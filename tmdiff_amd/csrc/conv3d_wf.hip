@@ -32,6 +32,9 @@
 #ifndef TMDIFF_WF_ABLATE
 #define TMDIFF_WF_ABLATE 0       // timing experiments (WRONG results): 1 = no input transform in the loop, 2 = ... and no raw DMA,
 #endif                           // 3 = ... and no weight DMA
+#ifndef TMDIFF_WF_NT
+#define TMDIFF_WF_NT 0           // experiments: 1 = non-temporal stores of y / y2 in the epilogue, 2 = ... and non-temporal residual loads
+#endif
 #ifndef TMDIFF_WF_STAMPS
 #define TMDIFF_WF_STAMPS 0       // diagnostic build: per-wave s_memrealtime stamps (tools/wino_stamps.py)
 #endif
@@ -39,6 +42,35 @@
 namespace {
 
 using f32x16 = __attribute__((ext_vector_type(16))) float;
+using f32x4 = __attribute__((ext_vector_type(4))) float;
+using f32x2 = __attribute__((ext_vector_type(2))) float;
+
+// epilogue stores / residual loads (TMDIFF_WF_NT: streamed past the caches -- nothing of a launch's output is read again
+// before the next launch, whose working set is far larger than L2 anyway)
+__device__ __forceinline__ void store4(float* p, float a, float b, float c, float d) {
+#if TMDIFF_WF_NT >= 1
+  f32x4 v = {a, b, c, d};
+  __builtin_nontemporal_store(v, reinterpret_cast<f32x4*>(p));
+#else
+  *reinterpret_cast<float4*>(p) = make_float4(a, b, c, d);
+#endif
+}
+__device__ __forceinline__ void store2(float* p, float a, float b) {
+#if TMDIFF_WF_NT >= 1
+  f32x2 v = {a, b};
+  __builtin_nontemporal_store(v, reinterpret_cast<f32x2*>(p));
+#else
+  *reinterpret_cast<float2*>(p) = make_float2(a, b);
+#endif
+}
+__device__ __forceinline__ float4 load_res4(const float* p) {
+#if TMDIFF_WF_NT >= 2
+  const f32x4 v = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(p));
+  return make_float4(v.x, v.y, v.z, v.w);
+#else
+  return *reinterpret_cast<const float4*>(p);
+#endif
+}
 
 template <int B, int E, class F>
 __device__ __forceinline__ void static_for(F&& f) {
@@ -222,7 +254,7 @@ __device__ __forceinline__ void epilogue_wf(const WfArgs& a, f32x16 (&out)[8], f
     constexpr int i = decltype(ic)::value, s = i / MO, n = i % MO;
 #pragma unroll
     for (int j = 0; j < 4; ++j)     // (outside the image: a valid address, the value is never stored)
-      rs[i % (DEPTH + 1)][j] = *reinterpret_cast<const float4*>(a.residual + cbase + (long)(8 * j) * plane + (long)n * hw + toff[s]);
+      rs[i % (DEPTH + 1)][j] = load_res4(a.residual + cbase + (long)(8 * j) * plane + (long)n * hw + toff[s]);
   };
   if constexpr (RES) static_for<0, DEPTH>([&](auto ic) __attribute__((always_inline)) { load_res(ic); });
   static_for<0, 8>([&](auto ic) __attribute__((always_inline)) {
@@ -244,7 +276,7 @@ __device__ __forceinline__ void epilogue_wf(const WfArgs& a, f32x16 (&out)[8], f
       for (int e = 0; e < 4; ++e) v[e] = (v[e] + bias_t[j] + q[e]) * oscale;   // as the scalar epilogue
       const long o = cbase + (long)(8 * j) * plane + (long)n * hw + toff[s];
       if constexpr (Y) {
-        if (FULL || tok[s]) *reinterpret_cast<float4*>(ydst + o) = make_float4(v[0], v[1], v[2], v[3]);
+        if (FULL || tok[s]) store4(ydst + o, v[0], v[1], v[2], v[3]);
       }
       if constexpr (Y2) {
         float u[4];
@@ -257,11 +289,11 @@ __device__ __forceinline__ void epilogue_wf(const WfArgs& a, f32x16 (&out)[8], f
         if (a.y2_s2d) {
           const long o2 = cbase + (long)(8 * j) * plane + (long)n * (hw >> 2) + s2off[s];
           if (FULL || tok[s]) {
-            *reinterpret_cast<float2*>(a.y2 + o2) = make_float2(u[0], u[2]);
-            *reinterpret_cast<float2*>(a.y2 + o2 + qplane) = make_float2(u[1], u[3]);
+            store2(a.y2 + o2, u[0], u[2]);
+            store2(a.y2 + o2 + qplane, u[1], u[3]);
           }
         } else if (FULL || tok[s]) {
-          *reinterpret_cast<float4*>(a.y2 + o) = make_float4(u[0], u[1], u[2], u[3]);
+          store4(a.y2 + o, u[0], u[1], u[2], u[3]);
         }
       }
     }

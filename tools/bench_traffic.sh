@@ -3,7 +3,7 @@
 # MI355X_MICROARCH.md prescribes: separate `rocprofv3 --pmc` passes (FETCH_SIZE and WRITE_SIZE do not fit one pass),
 # only --kernel-trace beside them, the program itself after `--`.  Writes profiles/${TAG}_bench_traffic.json (read back
 # by bench.py into roofline.traffic) and a kernel-stats pass of the same command (profiles/${TAG}_bench_kernel_stats.csv).
-R=$PWD; TAG=${1:-r03}; OUT=$R/gpurun_out/${TAG}_traffic
+R=$PWD; TAG=${1:-r04}; OUT=$R/gpurun_out/${TAG}_traffic
 CMD="python3 $R/bench.py --steps 3 --warmup 1 --no-extras"
 cd /tmp && export TMPDIR=/tmp
 rocprofv3 --kernel-trace --pmc FETCH_SIZE -d $OUT/fetch -o p --output-format csv -- $CMD > $OUT.fetch.log 2>&1 &&

@@ -39,3 +39,5 @@ cd /tmp && export TMPDIR=/tmp
 timeout -k 10 400 rocprofv3 --kernel-trace --stats -d $O/prof_train -o p --output-format csv -- python3 $R/bench.py --mode train --steps 6 --warmup 2 > /dev/null 2>&1; echo "train prof rc=$?"
 timeout -k 10 400 rocprofv3 --kernel-trace --stats -d $O/prof_bf16 -o p --output-format csv -- python3 $R/tools/prof_bf16_step.py 10 > /dev/null 2>&1; echo "bf16 prof rc=$?"
 TMDIFF_BENCH_BACKEND=gloo timeout -k 10 300 python3 $R/bench.py --gpus 2 --mode train --steps 4 --warmup 2 > $O/train_2rank_gloo.json 2> /dev/null; echo "2-rank rc=$?"
+TMDIFF_BENCH_BACKEND=gloo timeout -k 10 300 python3 $R/bench.py --gpus 2 --steps 5 --warmup 2 --no-extras > $O/bench_2rank_gloo.json 2> /dev/null; echo "2-rank sample rc=$?"
+python3 $R/tools/exp_half_batches.py 10 2>&1 | grep -v amdgpu > $O/half_batches.txt
