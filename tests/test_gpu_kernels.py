@@ -767,6 +767,8 @@ def test_conv3d_winograd_along_bands(ops, case):
     (1, (4,), 32, 8, 8, 8, 1),            # pair mode, a single image
     (3, (8, 8, 8), 192, 8, 8, 8, 3),      # pair mode, groups = 3 on three segments (read in place), split-K
     (5, (64,), 64, 8, 16, 8, 1),          # pair mode, split-K, odd batch
+    (8, (8,), 64, 8, 64, 64, 1),          # a grid of two full rounds (512 tiles x 2 channel tiles), several images
+    (5, (6,), 128, 8, 40, 72, 1),         # ragged in h and w on a large grid, four channel tiles, odd chunk count
 ])
 def test_conv3d_winograd_in_kernel_transform(ops, case):
     """tmdiff_conv3d_wf_fwd: Winograd F(4,3) along the bands with the input transform inside the kernel (no transformed
