@@ -106,6 +106,15 @@ typedef struct tmdiff_conv3d_desc {
    * the step bumps before the graph runs) every replay still draws a fresh mask -- and forward, weight gradient and
    * prologue backward of one step still agree, since all three read the same word.  (ABI v6) */
   const uint64_t* drop_seed_dev;
+  /* Optional folded "residual convolution" (tmdiff_conv3d_wf_fwd only; ABI v6): y = (conv(x') + bias + rc_w^T rc_x) * out_scale,
+   * i.e. the 1x1x1 res_conv of a ResBlock (Hyper_unet_general.py:231, :248) on the block's RAW input rc_x [B, rc_cin, N, H, W],
+   * accumulated on the matrix pipe where its consumer conv21 would have added it -- no launch of its own, its result never
+   * written and read back.  rc_w = the weight [Cout, rc_cin, 1, 1, 1] as PyTorch holds it (contiguous, NOT packed); the
+   * caller adds res_conv's bias into `bias`.  Needs groups 1, rc_cin % 32 == 0, residual NULL, planes wider than 8 columns and
+   * a grid that does not split its input channels (tmdiff_conv3d_wf_plan() == 1); else TMDIFF_E_UNSUPPORTED. */
+  const float* rc_x;
+  const float* rc_w;
+  int32_t rc_cin;
   /* != 0 (tmdiff_conv3d_wf_fwd only, even H, W % 4 == 0, a grid that does not split its input channels): y2 is written in
    * "space to depth" form [B, 4 Cout, N, H/2, W/2], channel 4 co + 2 ph + pw holding y2[co][n][2i + ph][2j + pw] -- the input
    * form of tmdiff_conv3d_wfll_fwd (the down blocks' Conv_0 + LL band, Hyper_unet_general.py:371-372, :389, :396). */

@@ -856,6 +856,43 @@ def test_conv3d_winograd_data_gradient_weights(ops, case):
     assert_close(dx, direct.cpu(), 1e-5, 2e-6, "winograd data gradient vs the direct kernel")   # (F(4,3): 1e-6 vs fp64 by itself)
 
 
+@pytest.mark.parametrize("case", [
+    # B, Cx (res_conv input channels), Cin = Cout of conv21, N, H, W
+    (2, 32, 64, 8, 16, 32),           # the level-0 shape class (32 -> 64): two channel tiles, whole tiles
+    (3, 64, 128, 8, 12, 20),          # ragged in h and w, four channel tiles, two 32-channel groups of x
+    (2, 32, 64, 4, 32, 32),           # 4 bands (GF-2 / QB): the 16 x 16 tile's position mapping
+    (1, 128, 32, 8, 8, 16),           # more input channels than output channels, a single tile
+])
+def test_conv3d_wf_folds_the_residual_convolution(ops, case):
+    """desc.rc_* (ABI v6): a ResBlock's 1x1x1 res_conv (reference Hyper_unet_general.py:231, :248) folded into conv21's epilogue
+    -- W1^T x accumulated by the matrix pipe into the output blocks -- against the CPU convolutions (fp64) and against the
+    two-launch form it replaces (1x1x1 kernel, then conv3d_wf with its result as residual); second output and scale included."""
+    B, cx, c, N, H, W = case
+    torch.manual_seed(500 + cx + c + N)
+    xr, t1 = torch.randn(B, cx, N, H, W), torch.randn(B, c, N, H, W)
+    w21, w1, b1 = torch.randn(c, c, 3, 3, 3) / (c * 27) ** 0.5, torch.randn(c, cx, 1, 1, 1) / cx ** 0.5, torch.randn(c)
+    sh2, sc2 = torch.randn(B, c) * 0.3, torch.rand(B, c) + 0.5
+    want = ((F.conv3d(t1.double(), w21.double(), None, padding=1) + F.conv3d(xr.double(), w1.double(), b1.double())) * 0.7071).float()
+    v = want + sh2[:, :, None, None, None]
+    want2 = v * torch.sigmoid(v) * sc2[:, :, None, None, None]
+    wp, w1p, w1d = ops.pack_conv_weight_wino(cu(w21), mode=2, planes=6), ops.pack_conv_weight(cu(w1)), cu(w1)
+    em = dict(act=True, shift=cu(sh2), scale=cu(sc2))
+    y, y2 = ops.conv3d_wf([cu(t1)], wp, c, bias=cu(b1), res_conv=(cu(xr), w1d, cx), out_scale=0.7071, emit=em)
+    assert_close(y, want, 2e-5, 2e-6, "folded res_conv")
+    assert_close(y2, want2, 2e-5, 2e-6, "folded res_conv, second output")
+    res = ops.conv3d([cu(xr)], w1p, c, 1, bias=cu(b1))
+    y_two, y2_two = ops.conv3d_wf([cu(t1)], wp, c, residual=res, out_scale=0.7071, emit=em)
+    assert_close(y, y_two.cpu(), 5e-6, 2e-6, "folded vs two launches")           # (same products, another summation order)
+    assert_close(y2, y2_two.cpu(), 5e-6, 2e-6, "folded vs two launches, second output")
+    only = ops.conv3d_wf([cu(t1)], wp, c, bias=cu(b1), res_conv=(cu(xr), w1d, cx), out_scale=0.7071, emit=em, keep_y=False)
+    assert torch.equal(only, y2)
+    # what the kernel does not take is refused, not computed wrongly: a residual tensor beside it, the direct kernels
+    with pytest.raises(ValueError):
+        ops.conv3d_wf([cu(t1)], wp, c, residual=res, res_conv=(cu(xr), w1d, cx))
+    with pytest.raises(ValueError):
+        ops.conv3d([cu(t1)], ops.pack_conv_weight(cu(w21)), c, 3, res_conv=(cu(xr), w1d, cx))
+
+
 def test_dropout_seed_word_in_device_memory(ops):
     """tmdiff_conv3d_desc.drop_seed_dev (ABI v6): the in-kernel dropout seed is drop_seed + *drop_seed_dev, read when the
     kernel starts -- a launch recorded into a HIP graph draws a fresh mask on every replay once the word is bumped.  The

@@ -384,10 +384,12 @@ class WavBEST(nn.Module):
         return prep
 
     # ---- fused building blocks -------------------------------------------------------------------
-    def _conv(self, P, name, segs, use_bias=True, bias_scale=1.0, **kw):
-        """One convolution of the fused inference graph on the kernel family tmdiff_amd.routing picks for its extents."""
+    def _conv(self, P, name, segs, use_bias=True, bias_scale=1.0, bias=None, **kw):
+        """One convolution of the fused inference graph on the kernel family tmdiff_amd.routing picks for its extents.
+        bias: another module's bias instead of this one's (a folded res_conv's)."""
         m = self.get_submodule(name)
-        bias = m.bias.detach() if (use_bias and m.bias is not None) else None
+        if bias is None:
+            bias = m.bias.detach() if (use_bias and m.bias is not None) else None
         math = "bf16" if name in P["bf16"] else "fp32"
         if m.kernel_size[0] != 3:
             return ops.conv3d(segs, P["w"][name], m.out_channels, m.kernel_size[0], groups=m.groups, math=math, bias=bias,
@@ -438,7 +440,16 @@ class WavBEST(nn.Module):
         (None without emit)."""
         rb = self.get_submodule(name)
         sh = {} if flag else self._shift(P, S, name + ".dense1")
-        res = self._conv(P, name + ".res_conv", segs) if isinstance(rb.res_conv, nn.Conv3d) else segs[0]
+        # res_conv (1x1x1, where the channel count changes) folded into conv21's epilogue where conv21 runs on conv3d_wf unsplit:
+        # W1^T x is accumulated by the matrix pipe into conv21's output blocks -- no launch of its own, no residual tensor
+        # written and read back (19 -> 13 1x1x1 launches per step at the benchmark batch)
+        rc = None
+        if isinstance(rb.res_conv, nn.Conv3d):
+            rc = self._fold_res_conv(P, name, segs)
+            res = None if rc is not None else self._conv(P, name + ".res_conv", segs)
+        else:
+            res = segs[0]
+        rckw = {} if rc is None else {"res_conv": rc, "bias": rb.res_conv.bias.detach()}
         sc = self._scale(P, S, name + ".dense2")
         # conv20's result feeds conv21 only: its epilogue applies conv21's prologue (SiLU, text modulation) and conv21
         # reads that directly -- a plain fp32 tensor for the staged kernel, or the packed bf16 units in the bf16 mode
@@ -449,16 +460,34 @@ class WavBEST(nn.Module):
             mid = dict(act=True, scale=sc["in_scale"], scale_stride=sc["scale_stride"])
             if pre is not None:     # (bf16 mode: `pre` is the packed bf16 form a bf16 producer wrote)
                 t1p = self._conv(P, name + ".conv20", [pre], keep_y=False, emit=mid,
-                                 x_bf16_shape=tuple(res.shape[2:]) if pre.dtype == torch.int16 else None)
+                                 x_bf16_shape=tuple(segs[0].shape[2:]) if pre.dtype == torch.int16 else None)
             else:
                 t1p = self._conv(P, name + ".conv20", segs, in_act=True, keep_y=False, emit=mid, **sh)
-            shape = tuple(res.shape[2:]) if both16 else None
-            out = self._conv(P, name + ".conv21", [t1p], use_bias=False, residual=res, x_bf16_shape=shape, **kw)
+            shape = tuple(segs[0].shape[2:]) if both16 else None
+            out = self._conv(P, name + ".conv21", [t1p], use_bias=False, residual=res, x_bf16_shape=shape, **rckw, **kw)
         else:
             assert pre is None
             t1 = self._conv(P, name + ".conv20", segs, in_act=True, **sh)
-            out = self._conv(P, name + ".conv21", [t1], use_bias=False, in_act=True, residual=res, **sc, **kw)
+            out = self._conv(P, name + ".conv21", [t1], use_bias=False, in_act=True, residual=res, **sc, **rckw, **kw)
         return out if emit is not None else (out, None)
+
+    def _fold_res_conv(self, P, name, segs, k1=".res_conv", k3=".conv21"):
+        """(x, the 1x1x1 weight, Cx) when the 1x1x1 convolution `name + k1` -- a ResBlock's res_conv, a down block's Conv_2 --
+        whose result is only ever the residual of the 3x3x3 convolution `name + k3` can ride in that convolution's epilogue
+        (make_conv_desc res_conv=), else None: fp32, one input tensor x of a multiple of 32 channels at the consumer's plane
+        size, the consumer on conv3d_wf (not its pair mode) without splitting its input channels."""
+        if not ops.config.fuse_res_conv or len(segs) != 1 or (name + k3) in P["bf16"] or (name + k1) in P["bf16"]:
+            return None
+        m3, x = self.get_submodule(name + k3), segs[0]
+        b, cx, n, h, w = x.shape
+        if P["w_wino"].get(name + k3) is None or cx % 32 or cx > 512 or m3.groups != 1 or (n == 8 and w == 8):
+            return None
+        from . import routing
+        if routing.conv3_family(b, m3.in_channels, m3.out_channels, n, h, w, 1, plain=False) != "wf":
+            return None
+        if routing.wf_route(b, m3.in_channels, m3.out_channels, n, h, w)[1] != 1:
+            return None
+        return x, self.get_submodule(name + k1).weight.detach(), cx
 
     def _ll_s2d(self, P, blk, h):
         """True when the main branch's down block `blk` runs Conv_0 + LL as conv3d_wf_ll: its weights exist, the ResBlock in
@@ -492,11 +521,18 @@ class WavBEST(nn.Module):
         # Both are linear and act on different axes (channels / the 2x2 pixel block), and the halved LL band of a
         # constant is that constant, so LL(Conv_2(x)) / 2 == Conv_2(LL(x) / 2): the convolution runs on a quarter of
         # the positions and the full-resolution intermediate is never written (same value up to fp32 summation order).
+        rc2 = {}
         if ops.config.conv2_after_ll:
-            xll = self._conv(P, name + ".Conv_2", [ops.haar_dwt2d(x, want_high=False, ll_scale=0.5)[0]])
+            xq = ops.haar_dwt2d(x, want_high=False, ll_scale=0.5)[0]
+            # ... and where Conv_1 runs on conv3d_wf unsplit, Conv_2 rides in its epilogue like a ResBlock's res_conv
+            rc = self._fold_res_conv(P, name, [xq], k1=".Conv_2", k3=".Conv_1")
+            if rc is not None:
+                xll, rc2 = None, {"res_conv": rc, "bias": self.get_submodule(name + ".Conv_2").bias.detach()}
+            else:
+                xll = self._conv(P, name + ".Conv_2", [xq])
         else:
             xll = ops.haar_dwt2d(self._conv(P, name + ".Conv_2", [x]), want_high=False, ll_scale=0.5)[0]
-        kw = {} if emit is None else {"emit": emit}
+        kw = dict(rc2) if emit is None else dict(rc2, emit=emit)
         if w_ll is not None:
             # Conv_0 and the halved LL band of its output as ONE strided convolution (only the LL band is used here); with
             # `fuse` its epilogue applies Conv_1's prologue, as the DWT does below

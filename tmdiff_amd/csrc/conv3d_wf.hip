@@ -105,6 +105,10 @@ struct WfArgs {
   unsigned long long* stamps;
   int stagger;
   unsigned first_round;
+  // folded 1x1x1 "residual convolution" (desc.rc_*): y += rc_w^T rc_x (+ its bias, folded into `bias` by the host)
+  const float* rc_x;          // [B, rc_cin, N, H, W] or NULL
+  const float* rc_w;          // the weight as PyTorch holds it: [Cout][rc_cin]
+  int rc_cin;
 };
 
 // LDS-DMA through a buffer descriptor: 16 bytes per lane from base + voff (bytes) to dst + 16 * lane.  An offset at or beyond
@@ -128,10 +132,15 @@ __device__ __forceinline__ buf_rsrc make_rsrc(const float* base, unsigned bytes)
 __device__ __forceinline__ void dma_b128(buf_rsrc r, unsigned voff, float* dst) {
   __builtin_amdgcn_raw_ptr_buffer_load_lds(r, dst, 16, voff, 0, 0, 0);
 }
+// one dword per lane from base + voff + soff (soff uniform): the address is a 32-bit register, nothing 64-bit per lane
+__device__ __forceinline__ float buf_load(buf_rsrc r, unsigned voff, unsigned soff) {
+  return __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(r, voff, soff, 0));
+}
 #else
 struct buf_rsrc {};
 __device__ __forceinline__ buf_rsrc make_rsrc(const float*, unsigned) { return {}; }
 __device__ __forceinline__ void dma_b128(buf_rsrc, unsigned, float*) {}
+__device__ __forceinline__ float buf_load(buf_rsrc, unsigned, unsigned) { return 0.f; }
 #endif
 
 __device__ __forceinline__ unsigned xcd_remap(unsigned bid, unsigned nwg) {
@@ -563,6 +572,57 @@ __global__ void __launch_bounds__(256, 2) conv3d_wf_kernel(const WfArgs a) {
   f32x16 out[8];                  // block (s, n) = sub-tile s, band n of the wave's band tile
 #pragma unroll
   for (int i = 0; i < 8; ++i) out[i] = acc[(i % MO) * NS + i / MO];
+  // ---- folded residual convolution (ResBlock res_conv, Hyper_unet_general.py:231, :248): out += W1^T x, a 1x1x1 convolution of the
+  // block's RAW input, accumulated by the matrix pipe straight into the output blocks -- no launch of its own, its result is never
+  // written and read back.  K step = 2 input channels (lane half = channel parity, as in the main loop); the weight slab
+  // [rc_cin][32] of this channel tile goes through LDS once per workgroup (the stages are free), a lane's x values come
+  // straight from global memory as its B operands (positions of a block = the MFMA columns: coalesced rows of 16), sixteen
+  // K-steps of the next work item in flight while the current one is multiplied.
+  if constexpr (!PAIR && !LLM) {
+    if (a.rc_x) {
+      __syncthreads();                                    // every wave is done with the stages: they hold the weight slab now
+      float* wl = lds;                                    // [rc_cin][32]
+      for (int e = tid; e < a.rc_cin * 32; e += 256) {    // from the PyTorch-layout weight [Cout][rc_cin]: thread = (co, ci), ci fastest
+        const int co = e / a.rc_cin, ci = e - co * a.rc_cin;
+        wl[ci * 32 + co] = a.rc_w[(long)(co0 + co) * a.rc_cin + ci];
+      }
+      __syncthreads();
+      // x through a buffer descriptor over this sample's rc_cin channels: per-lane byte offset (channel parity, band, row,
+      // column) in one 32-bit register per output block, the channel pair of a K-step as a scalar offset
+      const buf_rsrc xr = make_rsrc(a.rc_x + (long)b * a.rc_cin * plane, (unsigned)((long)a.rc_cin * plane * 4));
+      unsigned xo[8];                                     // lane offset of block (s, n): band, row, column of MFMA column l31
+#pragma unroll
+      for (int i = 0; i < 8; ++i) {
+        const int s_ = i / MO, n_ = i % MO;
+        const int bt = TT == 2 ? l31 >> 4 : 0;
+        const int h = h0 + (TT == 2 ? 2 * wv + s_ : 4 * wv + 2 * s_ + (l31 >> 4)), w = w0 + (l31 & 15);
+        // (outside the image: any valid address, the value is never stored)
+        xo[i] = (unsigned)((khalf * (int)plane + ((h < a.H && w < a.W) ? (MO * bt + n_) * hw + h * a.W + w : 0)) * 4);
+      }
+      constexpr int GJ = 16;                              // K-steps per work item (32 input channels of one output block)
+      const int ngrp = a.rc_cin / (2 * GJ);               // rc_cin % 32 == 0 (host)
+      const unsigned pair_bytes = (unsigned)(2 * plane * 4);
+      float xv[2][GJ];
+      auto fetch = [&](int jg, auto ic, auto bufc) __attribute__((always_inline)) {
+        constexpr int i = decltype(ic)::value, buf = decltype(bufc)::value;
+        const unsigned s0 = (unsigned)(jg * GJ) * pair_bytes;
+#pragma unroll
+        for (int j = 0; j < GJ; ++j) xv[buf][j] = buf_load(xr, xo[i], s0 + (unsigned)j * pair_bytes);
+      };
+      fetch(0, std::integral_constant<int, 0>{}, std::integral_constant<int, 0>{});
+      for (int jg = 0; jg < ngrp; ++jg) {
+        const float* wrow = wl + (jg * 2 * GJ + khalf) * 32 + l31;
+        static_for<0, 8>([&](auto ic) __attribute__((always_inline)) {
+          constexpr int i = decltype(ic)::value, buf = i & 1;
+          if constexpr (i < 7) fetch(jg, std::integral_constant<int, i + 1>{}, std::integral_constant<int, buf ^ 1>{});
+          else if (jg + 1 < ngrp) fetch(jg + 1, std::integral_constant<int, 0>{}, std::integral_constant<int, 0>{});
+#pragma unroll
+          for (int j = 0; j < GJ; ++j) out[i] = __builtin_amdgcn_mfma_f32_32x32x2f32(wrow[2 * j * 32], xv[buf][j], out[i], 0, 0, 0);
+        });
+      }
+      __syncthreads();                                    // the slab is dead before the epilogue borrows the same LDS
+    }
+  }
   float* T = lds + wv * 1024;     // (every wave is past the last barrier: the stages are free)
   const bool full = !PAIR && h0 + TH <= a.H && w0 + TW <= a.W;     // (PAIR: every store is checked -- the second image may not exist)
 #define WF_EPI2(Y, R, Y2)                                                                                                   \
@@ -766,6 +826,15 @@ int wf_forward(const tmdiff_conv3d_desc* d, void* workspace, tmdiff_stream_t str
         return fail(TMDIFF_E_UNSUPPORTED, "conv3d_wf_fwd: a grid that splits its input channels cannot write the space-to-depth second output");
       a.ksplit = ks; a.split_chunks = a.cin_g / 2 / ks; a.part = static_cast<float*>(d->splitk_ws);
     }
+  }
+  a.rc_x = nullptr; a.rc_w = nullptr; a.rc_cin = 0;
+  if (d->rc_x) {       // the ResBlock's 1x1x1 res_conv folded into this launch's epilogue
+    if (llm || wf_pair(d) || a.part || d->groups != 1 || d->residual || !d->rc_w || d->rc_cin <= 0 || d->rc_cin % 32 || d->rc_cin > 512 ||
+        !aligned16(d->rc_x) || !aligned16(d->rc_w))
+      return fail(TMDIFF_E_UNSUPPORTED, "conv3d_wf_fwd: a folded residual convolution needs groups 1, rc_cin %% 32 == 0, no residual tensor, "
+                                        "planes wider than 8 columns and a grid that does not split its input channels");
+    TMDIFF_REQUIRE((long)d->rc_cin * d->N * d->H * d->W < (1L << 30), "conv3d_wf_fwd: rc_x sample too large for 32-bit byte offsets");
+    a.rc_x = d->rc_x; a.rc_w = d->rc_w; a.rc_cin = d->rc_cin;
   }
   if (wf_pair(d))
     TMDIFF_REQUIRE(((long)d->Cin + 2) * d->N * d->H * d->W < (1L << 29), "conv3d_wf_fwd: sample too large for 32-bit offsets");

@@ -43,6 +43,7 @@ class KernelConfig:
     wgrad_wino_bias    TMDIFF_WGRAD_WINO_BIAS   True     ... whose g pass sums the bias gradient on the side
     wgrad_bias         TMDIFF_WGRAD_BIAS        False    direct weight gradient accumulates the bias gradient in-kernel
     wino_multipack     TMDIFF_WINO_MULTIPACK    True     finetune step: all Winograd weight forms re-packed by one launch
+    fuse_res_conv      TMDIFF_FUSE_RES_CONV     True     inference: a ResBlock's 1x1x1 res_conv folded into conv21's epilogue (conv3d_wf)
     train_graph        TMDIFF_TRAIN_GRAPH       False    (model.DDPM) capture the finetune step into a HIP graph
     train_two_streams  TMDIFF_TRAIN_STREAMS     True     forward_train runs the condition branch on a second stream beside the
                                                          main branch's down path (at a local batch of 8 most launches fill half
@@ -65,6 +66,7 @@ class KernelConfig:
         "fp32_staged": ("TMDIFF_FP32_STAGED", str, "auto"), "bf16_pack": ("TMDIFF_BF16_PACK", str, "auto"),
         "wgrad_wino": ("TMDIFF_WGRAD_WINO", _FLAG(True), True), "wgrad_wino_bias": ("TMDIFF_WGRAD_WINO_BIAS", _FLAG(True), True),
         "wgrad_bias": ("TMDIFF_WGRAD_BIAS", _FLAG(False), False), "wino_multipack": ("TMDIFF_WINO_MULTIPACK", _FLAG(True), True),
+        "fuse_res_conv": ("TMDIFF_FUSE_RES_CONV", _FLAG(True), True),
         "train_graph": ("TMDIFF_TRAIN_GRAPH", _FLAG(False), False),
         "train_two_streams": ("TMDIFF_TRAIN_STREAMS", _FLAG(True), True),
     }
@@ -310,7 +312,7 @@ def pack_conv_weight_bf16(w, groups=1):
 def make_conv_desc(segs, w_packed, cout, ksize, y, groups=1, bias=None, bias_scale=1.0, in_shift=None, in_scale=None,
                    shift_stride=0, scale_stride=0, in_act=False, in_mask=None, residual=None, out_scale=1.0,
                    y2=None, y2_shift=None, y2_scale=None, y2_shift_stride=0, y2_scale_stride=0, y2_act=False,
-                   x_bf16_shape=None, drop=None, out_div=1, y2_s2d=False, x_s2d=False):
+                   x_bf16_shape=None, drop=None, out_div=1, y2_s2d=False, x_s2d=False, res_conv=None):
     """Fill a tmdiff_conv3d_desc.  `segs` = list of 1..3 tensors [B, c_i, N, H, W] (concat-free input).
     in_shift / in_scale may be tensors or raw (ptr) ints into a projection bank.  y may be None when only the second
     output y2 = act2(y + y2_shift) * y2_scale (the consumer's prologue, same pointer conventions) is wanted.
@@ -318,8 +320,15 @@ def make_conv_desc(segs, w_packed, cout, ksize, y, groups=1, bias=None, bias_sca
     such a tensor (bf16 entry point only).  drop = (seed, p): in-kernel dropout of the prologue output (no mask tensor).
     out_div = 2: outputs / residual at half the H and W of the input (tmdiff_conv3d_ll_fwd).  y2_s2d: y2 in space-to-depth
     form [B, 4 Cout, N, H/2, W/2] (tmdiff_conv3d_wf_fwd only); x_s2d: segs[0] is such a tensor and the descriptor is that of
-    the convolution on the full-resolution tensor it stands for (tmdiff_conv3d_wfll_fwd)."""
+    the convolution on the full-resolution tensor it stands for (tmdiff_conv3d_wfll_fwd).  res_conv = (x_raw [B, Cx, N, H, W],
+    the 1x1x1 weight [Cout, Cx, 1, 1, 1] itself (contiguous fp32, not packed), Cx): a ResBlock's res_conv folded into the epilogue (tmdiff_conv3d_wf_fwd
+    only; desc.rc_*) -- the caller passes res_conv's bias as `bias` and no residual."""
     d = Conv3dDesc()
+    if res_conv is not None:
+        rx, rw, rcin = res_conv
+        if residual is not None or tuple(rx.shape) != (segs[0].shape[0], rcin, *segs[0].shape[2:]) or rw.numel() != rcin * cout:
+            raise ValueError("conv3d: res_conv = (x [B, Cx, N, H, W], weight [Cout, Cx, 1, 1, 1], Cx) and no residual tensor")
+        d.rc_x, d.rc_w, d.rc_cin = _chk(rx, "res_conv input"), _chk(rw, "res_conv weights"), int(rcin)
     if drop is not None:
         if in_mask is not None:
             raise ValueError("conv3d: give either in_mask (a mask tensor) or drop=(seed, p)")
@@ -472,6 +481,8 @@ def conv3d(segs, w_packed, cout, ksize, out=None, math="fp32", pack_input=None, 
     as its input with x_bf16_shape=(N, H, W), skipping its pack pass.
     xp_out (fp32, 3x3x3): a [B, Cin, N, H, W] tensor that receives the prologue output x' (forces the staged kernel, whose
     prologue pass writes it there instead of the shared scratch) -- the training path keeps it for the weight gradient."""
+    if kw.get("res_conv") is not None:
+        raise ValueError("conv3d: only conv3d_wf folds a residual convolution into its epilogue")
     if x_bf16_shape is not None:
         b, (n, h, w) = segs[0].shape[0], x_bf16_shape
         kw = dict(kw, x_bf16_shape=x_bf16_shape)
@@ -603,8 +614,9 @@ def conv3d_auto(segs, weights, cout, groups=1, math="fp32", emit=None, keep_y=Tr
         planes = 6 if fam == "wino4" else 4
         return fallback.conv3d_wino(segs, weights.wino(planes), cout, planes, emit=emit, keep_y=keep_y, groups=groups,
                                     xp_out=xp_out, **kw)
-    if emit is not None and emit.get("s2d"):
-        raise ValueError("conv3d_auto: only conv3d_wf writes a space-to-depth second output (ask routing.wf_route first)")
+    if (emit is not None and emit.get("s2d")) or kw.get("res_conv") is not None:
+        raise ValueError("conv3d_auto: only conv3d_wf writes a space-to-depth second output / folds a residual convolution "
+                         "(ask routing.wf_route first)")
     staged = fam == "staged" or (fam not in ("staged", "fused") and
                                  routing.direct_family(cin, cout, groups, plain, masked, dropout, xp_out is not None) == "staged")
     return conv3d(segs, weights.direct(), cout, 3, groups=groups, staged=staged, emit=emit, keep_y=keep_y, xp_out=xp_out, **kw)
@@ -636,7 +648,8 @@ def conv3d_wf(segs, w_packed, cout, emit=None, keep_y=True, groups=1, xp_out=Non
     d = make_conv_desc(segs, w_packed, cout, 3, y, y2=y2, groups=groups, **kw)
     if not lib.tmdiff_conv3d_wf_supported(C.byref(d)):
         raise ValueError("conv3d_wf: shape not supported")
-    nsk = lib.tmdiff_conv3d_wf_splitk_workspace_bytes(C.byref(d)) if config.wf_splitk else 0
+    # (a launch that folds a residual convolution or writes a space-to-depth output runs unsplit: no workspace is lent)
+    nsk = lib.tmdiff_conv3d_wf_splitk_workspace_bytes(C.byref(d)) if (config.wf_splitk and not d.rc_cin) else 0
     if nsk:
         d.splitk_ws, d.splitk_ws_bytes = _workspace(dev, nsk, "splitk").data_ptr(), nsk
     nws = lib.tmdiff_conv3d_wf_workspace_bytes(C.byref(d))
@@ -651,7 +664,10 @@ def conv3d_wf(segs, w_packed, cout, emit=None, keep_y=True, groups=1, xp_out=Non
     elif xp_out is not None:          # plain input: x' IS the input
         xp_out.copy_(segs[0] if len(segs) == 1 else torch.cat(segs, 1))
     ret = y if y2 is None else ((y, y2) if y is not None else y2)
-    _count("conv3d_wf_fwd", 2.0 * b * cout * (d.Cin // groups) * 13.5 * n * h * w)
+    # EXECUTED flops: 54 multiply-adds per (ci, co) and tile of four output bands (the direct kernel: 27 per band), plus the
+    # folded res_conv's rc_cin multiply-adds per output
+    flops = 2.0 * b * cout * ((d.Cin // groups) * 13.5 + d.rc_cin) * n * h * w
+    _count("conv3d_wf_fwd", flops)
     if TIMER is None:
         check(lib.tmdiff_conv3d_wf_fwd(C.byref(d), ws, stream_ptr()), "conv3d_wf_fwd")
         return ret
@@ -659,8 +675,7 @@ def conv3d_wf(segs, w_packed, cout, emit=None, keep_y=True, groups=1, xp_out=Non
     e0.record()
     check(lib.tmdiff_conv3d_wf_fwd(C.byref(d), ws, stream_ptr()), "conv3d_wf_fwd")
     e1.record()
-    # EXECUTED flops: 54 multiply-adds per (ci, co) and tile of four output bands (the direct kernel: 27 per band)
-    TIMER.records.append((e0, e1, 2.0 * b * cout * (d.Cin // groups) * 13.5 * n * h * w, 3, "conv3d_wf_fwd", _tag(d)))
+    TIMER.records.append((e0, e1, flops, 3, "conv3d_wf_fwd", _tag(d) + (f" +rc{d.rc_cin}" if d.rc_cin else "")))
     return ret
 
 
