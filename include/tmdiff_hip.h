@@ -115,6 +115,11 @@ typedef struct tmdiff_conv3d_desc {
   const float* rc_x;
   const float* rc_w;
   int32_t rc_cin;
+  /* Optional third output (tmdiff_conv3d_wf_fwd only; ABI v6): the HALVED LL BAND of y, (a + b + c + d) / 4 over every 2 x 2 pixel
+   * block, [B, Cout, N, H/2, W/2] -- all a down block reads of its ResBlock's raw output (its Conv_2 path,
+   * Hyper_unet_general.py:374, :390, :396), so that neither y nor an LL-only DWT pass over it is needed.  Needs y == NULL and
+   * y2 != NULL, 8 bands, even H, W % 4 == 0, planes wider than 8 columns, an unsplit grid; else TMDIFF_E_UNSUPPORTED. */
+  float* y_ll;
   /* != 0 (tmdiff_conv3d_wf_fwd only, even H, W % 4 == 0, a grid that does not split its input channels): y2 is written in
    * "space to depth" form [B, 4 Cout, N, H/2, W/2], channel 4 co + 2 ph + pw holding y2[co][n][2i + ph][2j + pw] -- the input
    * form of tmdiff_conv3d_wfll_fwd (the down blocks' Conv_0 + LL band, Hyper_unet_general.py:371-372, :389, :396). */

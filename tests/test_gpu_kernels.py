@@ -893,6 +893,40 @@ def test_conv3d_wf_folds_the_residual_convolution(ops, case):
         ops.conv3d([cu(t1)], ops.pack_conv_weight(cu(w21)), c, 3, res_conv=(cu(xr), w1d, cx))
 
 
+@pytest.mark.parametrize("case", [(2, 32, 64, 16, 32), (3, 8, 32, 12, 20), (1, 64, 64, 24, 16)])
+def test_conv3d_wf_writes_the_ll_band_instead_of_y(ops, case, request):
+    """desc.y_ll (ABI v6): the epilogue writes LL(y) / 2 -- (a + b + c + d) / 4 over every 2 x 2 pixel block -- instead of y, beside the
+    second output (plain or space-to-depth): what a down block reads of its ResBlock's raw output (reference
+    Hyper_unet_general.py:374, :390, :396).  Against the Haar kernel on the y of an ordinary launch, residual / folded
+    res_conv / scale included; the second output is bit-identical to the ordinary launch's."""
+    B, cin, c, H, W = case
+    torch.manual_seed(900 + cin + c + H)
+    x, res = torch.randn(B, cin, 8, H, W, device="cuda"), torch.randn(B, c, 8, H, W, device="cuda")
+    w, bias = torch.randn(c, cin, 3, 3, 3, device="cuda") / (cin * 27) ** 0.5, torch.randn(c, device="cuda")
+    sh2, sc2 = torch.randn(B, c, device="cuda") * 0.3, torch.rand(B, c, device="cuda") + 0.5
+    wp = ops.pack_conv_weight_wino(w, mode=2, planes=6)
+    em = dict(act=True, shift=sh2, scale=sc2)
+    ctx = ops.config.override(wf_splitk=False)       # (these small grids would split their input channels: such launches write
+    ctx.__enter__()                                   #  neither form -- in the network routing.wf_route is asked first)
+    request.addfinalizer(lambda: ctx.__exit__(None, None, None))
+    for s2d in (False, True):
+        y, y2 = ops.conv3d_wf([x], wp, c, bias=bias, residual=res, out_scale=0.7071, emit=dict(em, s2d=s2d))
+        y2b, yll = ops.conv3d_wf([x], wp, c, bias=bias, residual=res, out_scale=0.7071, emit=dict(em, s2d=s2d, ll=True), keep_y=False)
+        assert torch.equal(y2, y2b)
+        want = ops.haar_dwt2d(y, want_high=False, ll_scale=0.5)[0]
+        assert_close(yll, want.cpu(), 1e-6, 5e-7, "LL output vs the Haar kernel on y")
+        a_ = y[..., 0::2, 0::2] + y[..., 0::2, 1::2] + y[..., 1::2, 0::2] + y[..., 1::2, 1::2]
+        assert_close(yll, (a_ * 0.25).cpu(), 1e-6, 5e-7, "LL output vs the definition")
+    if cin % 32 == 0:      # with a folded res_conv on top (the in-network combination of the 32 -> 64 ResBlocks)
+        xr, w1 = torch.randn(B, 32, 8, H, W, device="cuda"), torch.randn(c, 32, 1, 1, 1, device="cuda") / 32 ** 0.5
+        y, y2 = ops.conv3d_wf([x], wp, c, bias=bias, res_conv=(xr, w1, 32), emit=em)
+        y2b, yll = ops.conv3d_wf([x], wp, c, bias=bias, res_conv=(xr, w1, 32), emit=dict(em, ll=True), keep_y=False)
+        assert torch.equal(y2, y2b)
+        assert_close(yll, ops.haar_dwt2d(y, want_high=False, ll_scale=0.5)[0].cpu(), 1e-6, 5e-7, "LL output with a folded res_conv")
+    with pytest.raises(ValueError):
+        ops.conv3d_wf([x], wp, c, emit=dict(em, ll=True))                    # (the LL output replaces y: keep_y=False)
+
+
 def test_dropout_seed_word_in_device_memory(ops):
     """tmdiff_conv3d_desc.drop_seed_dev (ABI v6): the in-kernel dropout seed is drop_seed + *drop_seed_dev, read when the
     kernel starts -- a launch recorded into a HIP graph draws a fresh mask on every replay once the word is bumped.  The

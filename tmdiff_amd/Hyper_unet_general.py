@@ -434,10 +434,12 @@ class WavBEST(nn.Module):
             d["scale"], d["scale_stride"] = P["scale_bank"].slot(S["scale"], scale)
         return d
 
-    def _resblock(self, P, S, name, segs, flag, pre=None, emit=None):
+    def _resblock(self, P, S, name, segs, flag, pre=None, emit=None, want_ll=False):
         """ResBlockModulateBEST (ref :237-249): conv20 with fused (shift,) SiLU; optional 1x1x1
         res_conv; conv21 with fused SiLU + text modulation + residual add.  Returns (y, y2): y2 = `emit` applied to y
-        (None without emit)."""
+        (None without emit).  want_ll (the block in front of a down block, whose raw output is read by nothing but the LL
+        band of the Conv_2 path): where conv21's launch can (`_emit_ll`), it writes LL(y) / 2 instead of y -- returns
+        (None, y2, y_ll); else (y, y2, None)."""
         rb = self.get_submodule(name)
         sh = {} if flag else self._shift(P, S, name + ".dense1")
         # res_conv (1x1x1, where the channel count changes) folded into conv21's epilogue where conv21 runs on conv3d_wf unsplit:
@@ -464,12 +466,32 @@ class WavBEST(nn.Module):
             else:
                 t1p = self._conv(P, name + ".conv20", segs, in_act=True, keep_y=False, emit=mid, **sh)
             shape = tuple(segs[0].shape[2:]) if both16 else None
+            if want_ll and emit is not None and self._emit_ll(P, name, segs[0]):
+                y2, yll = self._conv(P, name + ".conv21", [t1p], use_bias=False, residual=res, keep_y=False,
+                                     emit=dict(emit, ll=True), **rckw)
+                return None, y2, yll
             out = self._conv(P, name + ".conv21", [t1p], use_bias=False, residual=res, x_bf16_shape=shape, **rckw, **kw)
         else:
             assert pre is None
             t1 = self._conv(P, name + ".conv20", segs, in_act=True, **sh)
             out = self._conv(P, name + ".conv21", [t1], use_bias=False, in_act=True, residual=res, **sc, **rckw, **kw)
-        return out if emit is not None else (out, None)
+        out = out if emit is not None else (out, None)
+        return (*out, None) if want_ll else out
+
+    def _emit_ll(self, P, name, x):
+        """True when ResBlock `name`'s conv21 can write the halved LL band of its output instead of the output itself
+        (desc.y_ll): fp32, 8 bands, even H, planes of at least 16 columns, conv21 on conv3d_wf without splitting its input
+        channels, and the down block's Conv_2 after the LL band (ops.config.conv2_after_ll)."""
+        cfg = ops.config
+        if not (cfg.emit_ll and cfg.conv2_after_ll and cfg.epilogue_fuse) or (name + ".conv21") in P["bf16"]:
+            return False
+        m = self.get_submodule(name + ".conv21")
+        b, _, n, h, w = x.shape
+        if P["w_wino"].get(name + ".conv21") is None or n != 8 or w == 8 or h % 2 or w % 4 or m.groups != 1:
+            return False
+        from . import routing
+        return (routing.conv3_family(b, m.in_channels, m.out_channels, n, h, w, 1, plain=False) == "wf" and
+                routing.wf_route(b, m.in_channels, m.out_channels, n, h, w)[1] == 1)
 
     def _fold_res_conv(self, P, name, segs, k1=".res_conv", k3=".conv21"):
         """(x, the 1x1x1 weight, Cx) when the 1x1x1 convolution `name + k1` -- a ResBlock's res_conv, a down block's Conv_2 --
@@ -510,9 +532,10 @@ class WavBEST(nn.Module):
             return self._conv(P, name + ".Conv_0", [x], in_act=True)
         return self._conv(P, name + ".Conv_0", [pre], x_bf16_shape=tuple(x.shape[2:]) if pre.dtype == torch.int16 else None)
 
-    def _down(self, P, S, name, x, flag, want_high, pre=None, emit=None, fuse=False, pre_s2d=False):
+    def _down(self, P, S, name, x, flag, want_high, pre=None, emit=None, fuse=False, pre_s2d=False, xq=None):
         """WaveletUPorDown(down=True) (ref :369-414); /2 folded into the DWT, LL-only when the
-        caller drops the high bands.  Returns (out, out2, bands).  pre_s2d: `pre` is in space-to-depth form (_ll_s2d)."""
+        caller drops the high bands.  Returns (out, out2, bands).  pre_s2d: `pre` is in space-to-depth form (_ll_s2d).
+        xq: LL(x) / 2 as the producer already wrote it (_resblock(want_ll=True)); x itself may then be None."""
         w_ll = None if want_high or pre is None or pre.dtype != torch.float32 else P["w_wfll" if pre_s2d else "w_ll"].get(name + ".Conv_0")
         assert not pre_s2d or w_ll is not None
         conv_ll = ops.conv3d_wf_ll if pre_s2d else ops.conv3d_ll
@@ -523,7 +546,8 @@ class WavBEST(nn.Module):
         # the positions and the full-resolution intermediate is never written (same value up to fp32 summation order).
         rc2 = {}
         if ops.config.conv2_after_ll:
-            xq = ops.haar_dwt2d(x, want_high=False, ll_scale=0.5)[0]
+            if xq is None:
+                xq = ops.haar_dwt2d(x, want_high=False, ll_scale=0.5)[0]
             # ... and where Conv_1 runs on conv3d_wf unsplit, Conv_2 rides in its epilogue like a ResBlock's res_conv
             rc = self._fold_res_conv(P, name, [xq], k1=".Conv_2", k3=".Conv_1")
             if rc is not None:
@@ -634,10 +658,10 @@ class WavBEST(nn.Module):
             h, hp = out if fuse_c else (out, None)
         cond = {"h0": h, "pan": PAN, "ms": MS, "prompt": prompt, "scale": S["scale"]}
         for lvl, (dn, upn) in enumerate((("down1_1", "up3"), ("down2_1", "up2"), ("down3_1", "up1")), start=1):
-            h, ha = self._resblock(P, S, dn + ".conv20", [h], flag=True, pre=hp, emit=spec())
+            h, ha, hq = self._resblock(P, S, dn + ".conv20", [h], flag=True, pre=hp, emit=spec(), want_ll=True)
             # (the last level's output only feeds the up path's three-segment conv20: nothing to emit)
             h, hp, skip = self._down(P, S, dn + ".down", h, flag=True, want_high=True, pre=ha,
-                                     emit=spec() if lvl < 3 else None, fuse=fuse)
+                                     emit=spec() if lvl < 3 else None, fuse=fuse, xq=hq)
             cond[f"h{lvl}"] = h
             # convH_0(cat(skipH)/2)*2 == grouped conv of the three bands + 2*bias (exact: powers of two)
             cond[f"bands{lvl}"] = self._conv(P, upn + ".up1.convH_0.0", list(skip), bias_scale=2.0)
@@ -721,9 +745,10 @@ class WavBEST(nn.Module):
             # Conv_0 + LL with Winograd on top: the ResBlock hands its second output over in space-to-depth form
             sp = spec()
             s2d = sp is not None and self._ll_s2d(P, dn, h)
-            h, ha = self._resblock(P, S, dn + ".conv20", [h], flag=False, pre=hp, emit=dict(sp, s2d=True) if s2d else sp)
+            h, ha, hq = self._resblock(P, S, dn + ".conv20", [h], flag=False, pre=hp, emit=dict(sp, s2d=True) if s2d else sp,
+                                       want_ll=True)
             h, hp, _ = self._down(P, S, dn + ".down", h, flag=False, want_high=False, pre=ha,
-                                  emit=spec(shift=nxt + ".dense1"), fuse=fuse, pre_s2d=s2d)
+                                  emit=spec(shift=nxt + ".dense1"), fuse=fuse, pre_s2d=s2d, xq=hq)
             hs.append(h)
         h, _ = self._resblock(P, S, "middle1", [hs[3]], flag=False, pre=hp)
         for lvl, upn in ((3, "up1"), (2, "up2"), (1, "up3")):

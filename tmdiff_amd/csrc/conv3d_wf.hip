@@ -106,6 +106,7 @@ struct WfArgs {
   int stagger;
   unsigned first_round;
   // folded 1x1x1 "residual convolution" (desc.rc_*): y += rc_w^T rc_x (+ its bias, folded into `bias` by the host)
+  float* yll;                 // optional third output: the halved LL band of y, [B, Cout, N, H/2, W/2] (epilogue_wf; y itself not written)
   const float* rc_x;          // [B, rc_cin, N, H, W] or NULL
   const float* rc_w;          // the weight as PyTorch holds it: [Cout][rc_cin]
   int rc_cin;
@@ -258,17 +259,25 @@ __device__ __forceinline__ void epilogue_wf(const WfArgs& a, f32x16 (&out)[8], f
       }
     }
   }
-  float4 rs[DEPTH + 1][4];          // block i in slot i % (DEPTH + 1)
-  auto load_res = [&](auto ic) __attribute__((always_inline)) {
-    constexpr int i = decltype(ic)::value, s = i / MO, n = i % MO;
+  // The wave's eight blocks are taken in the order (band n, sub-tile s = 0, 1): step p is block i = s * MO + n with s = p & 1,
+  // n = p >> 1 -- the two rows 2 wv, 2 wv + 1 of one band (TT == 2) follow each other, which is what the LL output below needs.
+  // Third output (a.yll; only where y itself is not wanted, TT == 2, not PAIR): the HALVED LL BAND of y, (a + b + c + d) / 4 over
+  // the 2 x 2 pixel block -- what a down block's Conv_2 path reads of its ResBlock's output (Hyper_unet_general.py:374, :390, :396):
+  // a lane holds four columns of row 2 wv of a band, then the same four of row 2 wv + 1: two LL values per channel, one float2.
+  float4 rs[DEPTH + 1][4];          // step p in slot p % (DEPTH + 1)
+  auto load_res = [&](auto pc) __attribute__((always_inline)) {
+    constexpr int p = decltype(pc)::value, s = p & 1, n = p >> 1;
 #pragma unroll
     for (int j = 0; j < 4; ++j)     // (outside the image: a valid address, the value is never stored)
-      rs[i % (DEPTH + 1)][j] = load_res4(a.residual + cbase + (long)(8 * j) * plane + (long)n * hw + toff[s]);
+      rs[p % (DEPTH + 1)][j] = load_res4(a.residual + cbase + (long)(8 * j) * plane + (long)n * hw + toff[s]);
   };
-  if constexpr (RES) static_for<0, DEPTH>([&](auto ic) __attribute__((always_inline)) { load_res(ic); });
-  static_for<0, 8>([&](auto ic) __attribute__((always_inline)) {
-    constexpr int i = decltype(ic)::value, s = i / MO, n = i % MO;
-    if constexpr (RES && i + DEPTH < 8) load_res(std::integral_constant<int, i + DEPTH>{});
+  constexpr bool LL_OK = !Y && TT == 2 && !PAIR;
+  const bool want_ll = LL_OK && a.yll != nullptr;
+  float vk[4][4];                   // row 2 wv of the current band (LL output only)
+  if constexpr (RES) static_for<0, DEPTH>([&](auto pc) __attribute__((always_inline)) { load_res(pc); });
+  static_for<0, 8>([&](auto pc) __attribute__((always_inline)) {
+    constexpr int p = decltype(pc)::value, s = p & 1, n = p >> 1, i = s * MO + n;
+    if constexpr (RES && p + DEPTH < 8) load_res(std::integral_constant<int, p + DEPTH>{});
 #pragma unroll
     for (int r = 0; r < 16; ++r) T[((r & 3) + 8 * (r >> 2) + 4 * khalf) * 32 + l31] = out[i][r];
     __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
@@ -278,7 +287,7 @@ __device__ __forceinline__ void epilogue_wf(const WfArgs& a, f32x16 (&out)[8], f
       float v[4] = {t.x, t.y, t.z, t.w};
       float q[4] = {0.f, 0.f, 0.f, 0.f};
       if constexpr (RES) {
-        const float4 rq = rs[i % (DEPTH + 1)][j];
+        const float4 rq = rs[p % (DEPTH + 1)][j];
         q[0] = rq.x, q[1] = rq.y, q[2] = rq.z, q[3] = rq.w;
       }
 #pragma unroll
@@ -286,6 +295,20 @@ __device__ __forceinline__ void epilogue_wf(const WfArgs& a, f32x16 (&out)[8], f
       const long o = cbase + (long)(8 * j) * plane + (long)n * hw + toff[s];
       if constexpr (Y) {
         if (FULL || tok[s]) store4(ydst + o, v[0], v[1], v[2], v[3]);
+      }
+      if constexpr (LL_OK) {
+        if (want_ll) {
+          if constexpr (s == 0) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) vk[j][e] = v[e];
+          } else {
+            // band MO * bt + n, row (h0 + 2 wv) / 2, columns (w0 + 4 (tq & 3)) / 2 and the next of the quarter-size plane
+            // (s2off[0] is exactly that offset: row 2 wv of the tile is even, so its row-parity term is zero)
+            const long ol = ((cbase + (long)(8 * j) * plane) >> 2) + (long)n * (hw >> 2) + s2off[0];
+            if (FULL || (tok[0] && tok[1]))
+              store2(a.yll + ol, ((vk[j][0] + vk[j][1]) + (v[0] + v[1])) * 0.25f, ((vk[j][2] + vk[j][3]) + (v[2] + v[3])) * 0.25f);
+          }
+        }
       }
       if constexpr (Y2) {
         float u[4];
@@ -826,6 +849,13 @@ int wf_forward(const tmdiff_conv3d_desc* d, void* workspace, tmdiff_stream_t str
         return fail(TMDIFF_E_UNSUPPORTED, "conv3d_wf_fwd: a grid that splits its input channels cannot write the space-to-depth second output");
       a.ksplit = ks; a.split_chunks = a.cin_g / 2 / ks; a.part = static_cast<float*>(d->splitk_ws);
     }
+  }
+  a.yll = nullptr;
+  if (d->y_ll) {       // third output: the halved LL band of y (y itself not written)
+    if (llm || wf_pair(d) || a.part || d->y || !d->y2 || d->N != 8 || d->H % 2 || d->W % 4 || !aligned16(d->y_ll))
+      return fail(TMDIFF_E_UNSUPPORTED, "conv3d_wf_fwd: the LL output needs 8 bands, even H, W %% 4 == 0, planes wider than 8 columns, "
+                                        "y == NULL with a second output, and a grid that does not split its input channels");
+    a.yll = d->y_ll;
   }
   a.rc_x = nullptr; a.rc_w = nullptr; a.rc_cin = 0;
   if (d->rc_x) {       // the ResBlock's 1x1x1 res_conv folded into this launch's epilogue

@@ -4,8 +4,8 @@
     python tools/wf_resource_report.py > profiles/r04_conv_wf_resource_usage.txt
 
 Per kernel instantiation: the compiler's resource-usage remark (-Rpass-analysis=kernel-resource-usage) and, from the ISA
-(-save-temps), WHERE the scratch (spill) instructions sit relative to the chunk loop -- the loop is the region between the
-backward branches that enclose v_mfma instructions."""
+(-save-temps), WHERE the scratch (spill) instructions sit relative to the chunk loop -- the chunk loop is the first 216 (composed-LL mode: 96)
+v_mfma instructions of a kernel (its body is unrolled over two chunks)."""
 import os, re, subprocess, sys, tempfile
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 src = os.path.join(ROOT, "tmdiff_amd", "csrc", "conv3d_wf.hip")
@@ -33,19 +33,21 @@ for i, l in enumerate(asm):
     name = m.group(1)
     end = next(j for j in range(i, len(asm)) if asm[j].strip().startswith(".Lfunc_end"))
     body = asm[i:end]
+    targs = re.search(r"ILi(\d+)ELi(\d+)ELi(\d+)ELb(\d)ELb(\d)E", name).groups()
     mf = [k for k, x in enumerate(body) if "v_mfma" in x]
     sc = [k for k, x in enumerate(body) if re.search(r"\bscratch_(load|store)", x)]
-    labels = {mm.group(1): k for k, x in enumerate(body) for mm in [re.match(r"^(\.LBB\d+_\d+):", x)] if mm}
-    loops = []
-    for k, x in enumerate(body):
-        mm = re.search(r"s_cbranch\S*\s+(\.LBB\d+_\d+)", x)
-        if mm and mm.group(1) in labels and labels[mm.group(1)] < k and any(labels[mm.group(1)] < q < k for q in mf):
-            loops.append((labels[mm.group(1)], k))
-    lo, hi = min(a for a, _ in loops), max(b for _, b in loops)
+    # the chunk loop's body is unrolled over two chunks: 2 x 54 K-steps x 2 sub-tiles = 216 MFMAs (composed-LL mode: 2 x 24 x 2 = 96);
+    # further MFMAs belong to the folded residual convolution behind the loop (desc.rc_*: 8 blocks x 16 K-steps)
+    nmain = 96 if targs[4] == "1" else 216
+    lo, hi = mf[0], mf[nmain - 1]
+    rc_hi = mf[-1]
     inside = [k for k in sc if lo <= k <= hi]
-    targs = re.search(r"ILi(\d+)ELi(\d+)ELi(\d+)ELb(\d)ELb(\d)E", name).groups()
+    in_rc = [k for k in sc if hi < k <= rc_hi]
     r = rem.get(name, {})
     print(f"\nconv3d_wf_kernel<{', '.join(targs[:3])}, {'true' if targs[3] == '1' else 'false'}, {'true' if targs[4] == '1' else 'false'}>")
     print("  " + "  ".join(f"{k}: {v}" for k, v in r.items() if k in ("VGPRs", "AGPRs", "TotalSGPRs", "ScratchSize [bytes/lane]", "Occupancy [waves/SIMD]", "LDS Size [bytes/block]")))
-    print(f"  ISA: {len(body)} lines, {len(mf)} v_mfma (all inside the chunk loop, lines {lo}-{hi}), {len(sc)} scratch_load/store instructions "
-          f"over all epilogue variants: {len(inside)} inside the chunk loop, {sum(1 for k in sc if k < lo)} before it, {sum(1 for k in sc if k > hi)} after the last MFMA (epilogue)")
+    print(f"  ISA: {len(body)} lines, {len(mf)} v_mfma ({nmain} = the chunk loop, lines {lo}-{hi}" +
+          (f"; {len(mf) - nmain} = the folded residual convolution behind it" if len(mf) > nmain else "") +
+          f"), {len(sc)} scratch_load/store instructions over all epilogue variants: {sum(1 for k in sc if k < lo)} in the set-up before the "
+          f"loop (once per workgroup), {len(inside)} INSIDE THE CHUNK LOOP, {len(in_rc)} in / between loop and residual-convolution phase, "
+          f"{sum(1 for k in sc if k > rc_hi)} after the last MFMA (epilogue)")
