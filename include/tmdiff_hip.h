@@ -120,6 +120,12 @@ typedef struct tmdiff_conv3d_desc {
    * Hyper_unet_general.py:374, :390, :396), so that neither y nor an LL-only DWT pass over it is needed.  Needs y == NULL and
    * y2 != NULL, 8 bands, even H, W % 4 == 0, planes wider than 8 columns, an unsplit grid; else TMDIFF_E_UNSUPPORTED. */
   float* y_ll;
+  /* ... and with y_hi[0..2] != NULL (then y2 == NULL): the WHOLE Haar transform of y instead of y (tmdiff_conv3d_wf_fwd only; ABI v6) --
+   * y_hi = LH, HL, HH = (a - b + c - d) / 2, (a + b - c - d) / 2, (a - b - c + d) / 2 of every 2 x 2 block (a b / c d), and y_ll = the
+   * halved LL band passed through the second output's prologue, act2(LL / 2 + y2_shift) * y2_scale: what a down block whose high
+   * bands are kept makes of its Conv_0 output (DWT, then Conv_1's prologue on the LL band; Hyper_unet_general.py:388-396,
+   * DWT_IDWT_Functions.py:47-57) without a full-resolution tensor or a transform pass.  Same shape conditions as y_ll. */
+  float* y_hi[3];
   /* != 0 (tmdiff_conv3d_wf_fwd only, even H, W % 4 == 0, a grid that does not split its input channels): y2 is written in
    * "space to depth" form [B, 4 Cout, N, H/2, W/2], channel 4 co + 2 ph + pw holding y2[co][n][2i + ph][2j + pw] -- the input
    * form of tmdiff_conv3d_wfll_fwd (the down blocks' Conv_0 + LL band, Hyper_unet_general.py:371-372, :389, :396). */

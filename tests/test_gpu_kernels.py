@@ -925,6 +925,13 @@ def test_conv3d_wf_writes_the_ll_band_instead_of_y(ops, case, request):
         assert_close(yll, ops.haar_dwt2d(y, want_high=False, ll_scale=0.5)[0].cpu(), 1e-6, 5e-7, "LL output with a folded res_conv")
     with pytest.raises(ValueError):
         ops.conv3d_wf([x], wp, c, emit=dict(em, ll=True))                    # (the LL output replaces y: keep_y=False)
+    # desc.y_hi: the WHOLE Haar transform of y instead of y -- LL / 2 through the emit prologue, LH, HL, HH -- against the Haar kernel
+    # (with its LL prologue) on the y of an ordinary launch: what a down block that keeps its high bands makes of Conv_0's output
+    y = ops.conv3d_wf([x], wp, c, bias=bias)
+    got = ops.conv3d_wf([x], wp, c, bias=bias, emit=dict(em, dwt=True), keep_y=False)
+    want = ops.haar_dwt2d(y, want_high=True, ll_scale=0.5, ll_prologue=dict(act=True, shift=sh2, scale=sc2))
+    for nm, g_, w_ in zip(("LL'", "LH", "HL", "HH"), got, want):
+        assert_close(g_, w_.cpu(), 2e-6, 1e-6, f"Haar output {nm} vs the Haar kernel on y")
 
 
 def test_dropout_seed_word_in_device_memory(ops):

@@ -478,16 +478,17 @@ class WavBEST(nn.Module):
         out = out if emit is not None else (out, None)
         return (*out, None) if want_ll else out
 
-    def _emit_ll(self, P, name, x):
-        """True when ResBlock `name`'s conv21 can write the halved LL band of its output instead of the output itself
-        (desc.y_ll): fp32, 8 bands, even H, planes of at least 16 columns, conv21 on conv3d_wf without splitting its input
-        channels, and the down block's Conv_2 after the LL band (ops.config.conv2_after_ll)."""
+    def _emit_ll(self, P, name, x, conv=".conv21", switch="emit_ll"):
+        """True when the convolution `name + conv` (a ResBlock's conv21; a down block's Conv_0 for the whole Haar transform) can
+        write the halved LL band / the Haar transform of its output instead of the output itself (desc.y_ll / y_hi): fp32,
+        8 bands, even H, planes of at least 16 columns, the convolution on conv3d_wf without splitting its input channels, and
+        the down block's Conv_2 after the LL band (ops.config.conv2_after_ll).  x: a tensor of the convolution's input extents."""
         cfg = ops.config
-        if not (cfg.emit_ll and cfg.conv2_after_ll and cfg.epilogue_fuse) or (name + ".conv21") in P["bf16"]:
+        if not (getattr(cfg, switch) and cfg.conv2_after_ll and cfg.epilogue_fuse) or (name + conv) in P["bf16"]:
             return False
-        m = self.get_submodule(name + ".conv21")
+        m = self.get_submodule(name + conv)
         b, _, n, h, w = x.shape
-        if P["w_wino"].get(name + ".conv21") is None or n != 8 or w == 8 or h % 2 or w % 4 or m.groups != 1:
+        if P["w_wino"].get(name + conv) is None or n != 8 or w == 8 or h % 2 or w % 4 or m.groups != 1:
             return False
         from . import routing
         return (routing.conv3_family(b, m.in_channels, m.out_channels, n, h, w, 1, plain=False) == "wf" and
@@ -539,7 +540,14 @@ class WavBEST(nn.Module):
         w_ll = None if want_high or pre is None or pre.dtype != torch.float32 else P["w_wfll" if pre_s2d else "w_ll"].get(name + ".Conv_0")
         assert not pre_s2d or w_ll is not None
         conv_ll = ops.conv3d_wf_ll if pre_s2d else ops.conv3d_ll
-        hh = None if w_ll is not None else self._conv0(P, name, x, pre)
+        # high bands kept (condition branch): where Conv_0 runs on conv3d_wf unsplit, its epilogue writes the Haar transform of its
+        # output -- LL through Conv_1's prologue, LH, HL, HH -- instead of the output: no full-resolution tensor, no DWT pass
+        dwt4 = None
+        if (w_ll is None and fuse and want_high and pre is not None and pre.dtype == torch.float32 and
+                self._emit_ll(P, name, pre, conv=".Conv_0", switch="emit_dwt")):
+            pro = self._spec(P, S, shift=None if flag else name + ".Dense_0", scale=name + ".dense1")
+            dwt4 = self._conv(P, name + ".Conv_0", [pre], keep_y=False, emit=dict(pro, dwt=True))
+        hh = None if (w_ll is not None or dwt4 is not None) else self._conv0(P, name, x, pre)
         # The reference runs the 1x1x1 Conv_2 at full resolution and keeps the halved LL band of its output (:390, :396).
         # Both are linear and act on different axes (channels / the 2x2 pixel block), and the halved LL band of a
         # constant is that constant, so LL(Conv_2(x)) / 2 == Conv_2(LL(x) / 2): the convolution runs on a quarter of
@@ -572,7 +580,10 @@ class WavBEST(nn.Module):
                                  **self._scale(P, S, name + ".dense1"), **sh, **kw)
             out, out2 = out if emit is not None else (out, None)
             return out, out2, (None, None, None)
-        if fuse:   # Conv_1's prologue (shift, SiLU, text modulation) is applied to the LL band where the DWT writes it
+        if dwt4 is not None:
+            hll, lh, hl, hhh = dwt4
+            out = self._conv(P, name + ".Conv_1", [hll], use_bias=False, residual=xll, **kw)
+        elif fuse:   # Conv_1's prologue (shift, SiLU, text modulation) is applied to the LL band where the DWT writes it
             pro = self._spec(P, S, shift=None if flag else name + ".Dense_0", scale=name + ".dense1")
             p16 = name + ".Conv_1" in P["bf16"]          # bf16 mode: ... as the packed bf16 units the convolution reads
             hll, lh, hl, hhh = ops.haar_dwt2d(hh, want_high=want_high, ll_scale=0.5, ll_prologue=pro, pack_bf16=p16)

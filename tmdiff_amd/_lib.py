@@ -29,7 +29,7 @@ class Conv3dDesc(C.Structure):
         ("y2", vp), ("y2_shift", vp), ("y2_scale", vp), ("y2_shift_stride", C.c_int32), ("y2_scale_stride", C.c_int32),
         ("y2_act", C.c_int32), ("y2_bf16", C.c_int32), ("x_bf16", C.c_int32),
         ("splitk_ws", vp), ("splitk_ws_bytes", C.c_int64),
-        ("drop_seed", C.c_uint64), ("drop_p", C.c_float), ("drop_seed_dev", vp), ("rc_x", vp), ("rc_w", vp), ("rc_cin", C.c_int32), ("y_ll", vp),
+        ("drop_seed", C.c_uint64), ("drop_p", C.c_float), ("drop_seed_dev", vp), ("rc_x", vp), ("rc_w", vp), ("rc_cin", C.c_int32), ("y_ll", vp), ("y_hi", vp * 3),
         ("y2_s2d", C.c_int32),
     ]
 

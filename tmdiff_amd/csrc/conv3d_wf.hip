@@ -107,6 +107,8 @@ struct WfArgs {
   unsigned first_round;
   // folded 1x1x1 "residual convolution" (desc.rc_*): y += rc_w^T rc_x (+ its bias, folded into `bias` by the host)
   float* yll;                 // optional third output: the halved LL band of y, [B, Cout, N, H/2, W/2] (epilogue_wf; y itself not written)
+  float* yhi[3];              // ... with these: the whole Haar transform of y -- LH, HL, HH beside an LL band that went through the
+                              //     consumer's prologue (the y2 constants); no full-resolution output at all (desc.y_hi)
   const float* rc_x;          // [B, rc_cin, N, H, W] or NULL
   const float* rc_w;          // the weight as PyTorch holds it: [Cout][rc_cin]
   int rc_cin;
@@ -305,12 +307,25 @@ __device__ __forceinline__ void epilogue_wf(const WfArgs& a, f32x16 (&out)[8], f
             // band MO * bt + n, row (h0 + 2 wv) / 2, columns (w0 + 4 (tq & 3)) / 2 and the next of the quarter-size plane
             // (s2off[0] is exactly that offset: row 2 wv of the tile is even, so its row-parity term is zero)
             const long ol = ((cbase + (long)(8 * j) * plane) >> 2) + (long)n * (hw >> 2) + s2off[0];
-            if (FULL || (tok[0] && tok[1]))
-              store2(a.yll + ol, ((vk[j][0] + vk[j][1]) + (v[0] + v[1])) * 0.25f, ((vk[j][2] + vk[j][3]) + (v[2] + v[3])) * 0.25f);
+            const float ll0 = ((vk[j][0] + vk[j][1]) + (v[0] + v[1])) * 0.25f, ll1 = ((vk[j][2] + vk[j][3]) + (v[2] + v[3])) * 0.25f;
+            if (a.yhi[0]) {
+              // the whole transform of the 2 x 2 blocks (a b / c d): LL / 2 through the consumer's prologue, LH = (a - b + c - d) / 2,
+              // HL = (a + b - c - d) / 2, HH = (a - b - c + d) / 2 (DWT_IDWT_Functions.py:47-57 in closed form)
+              if constexpr (Y2) if (FULL || (tok[0] && tok[1])) {
+                const float x0 = ll0 + sh2_t[j], x1 = ll1 + sh2_t[j];
+                const float a0 = tmdiff::silu_f(x0), a1 = tmdiff::silu_f(x1);
+                store2(a.yll + ol, (a.y2_act ? a0 : x0) * sc2_t[j], (a.y2_act ? a1 : x1) * sc2_t[j]);
+                store2(a.yhi[0] + ol, ((vk[j][0] - vk[j][1]) + (v[0] - v[1])) * 0.5f, ((vk[j][2] - vk[j][3]) + (v[2] - v[3])) * 0.5f);
+                store2(a.yhi[1] + ol, ((vk[j][0] + vk[j][1]) - (v[0] + v[1])) * 0.5f, ((vk[j][2] + vk[j][3]) - (v[2] + v[3])) * 0.5f);
+                store2(a.yhi[2] + ol, ((vk[j][0] - vk[j][1]) - (v[0] - v[1])) * 0.5f, ((vk[j][2] - vk[j][3]) - (v[2] - v[3])) * 0.5f);
+              }
+            } else if (FULL || (tok[0] && tok[1])) {
+              store2(a.yll + ol, ll0, ll1);
+            }
           }
         }
       }
-      if constexpr (Y2) {
+      if constexpr (Y2) if (a.y2) {
         float u[4];
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
@@ -477,8 +492,9 @@ __global__ void __launch_bounds__(256, 2) conv3d_wf_kernel(const WfArgs a) {
   {
     const int col = g * a.cout_g + co0 + l31;
     bias_l = a.bias ? a.bias[col] * a.bias_scale : 0.f;
-    sh2_l = (a.y2 && a.y2_shift) ? a.y2_shift[(long)b * a.y2_shift_stride + col] : 0.f;
-    sc2_l = (a.y2 && a.y2_scale) ? a.y2_scale[(long)b * a.y2_scale_stride + col] : 1.f;
+    const bool has2 = a.y2 || a.yhi[0];     // (the Haar-output mode applies the second output's constants to its LL band)
+    sh2_l = (has2 && a.y2_shift) ? a.y2_shift[(long)b * a.y2_shift_stride + col] : 0.f;
+    sc2_l = (has2 && a.y2_scale) ? a.y2_scale[(long)b * a.y2_scale_stride + col] : 1.f;
     if constexpr (PAIR) {
       const int b1 = pimg_ok ? b + 1 : b;
       sh2_m = (a.y2 && a.y2_shift) ? a.y2_shift[(long)b1 * a.y2_shift_stride + col] : 0.f;
@@ -805,7 +821,7 @@ int wf_forward(const tmdiff_conv3d_desc* d, void* workspace, tmdiff_stream_t str
     return fail(TMDIFF_E_UNSUPPORTED, "conv3d_wf_fwd: fp32 3x3x3, groups 1 or 3, N = 8 or 4, W %% 4 == 0, Cin/g %% 2 == 0, Cout/g %% 32 == 0, no mask");
   TMDIFF_REQUIRE(d->B >= 0, "conv3d_wf_fwd: bad extents");
   if (d->B == 0) return TMDIFF_OK;
-  TMDIFF_REQUIRE(d->w_packed && (d->y || d->y2) && aligned16(d->w_packed), "conv3d_wf_fwd: NULL / unaligned weights or output");
+  TMDIFF_REQUIRE(d->w_packed && (d->y || d->y2 || d->y_ll) && aligned16(d->w_packed), "conv3d_wf_fwd: NULL / unaligned weights or output");
   TMDIFF_REQUIRE((long)2 * d->N * d->H * d->W < (1L << 31), "conv3d_wf_fwd: plane too large for 32-bit offsets");
   int csum = 0;
   for (int i = 0; i < d->nseg; ++i) {
@@ -850,12 +866,16 @@ int wf_forward(const tmdiff_conv3d_desc* d, void* workspace, tmdiff_stream_t str
       a.ksplit = ks; a.split_chunks = a.cin_g / 2 / ks; a.part = static_cast<float*>(d->splitk_ws);
     }
   }
-  a.yll = nullptr;
-  if (d->y_ll) {       // third output: the halved LL band of y (y itself not written)
-    if (llm || wf_pair(d) || a.part || d->y || !d->y2 || d->N != 8 || d->H % 2 || d->W % 4 || !aligned16(d->y_ll))
-      return fail(TMDIFF_E_UNSUPPORTED, "conv3d_wf_fwd: the LL output needs 8 bands, even H, W %% 4 == 0, planes wider than 8 columns, "
-                                        "y == NULL with a second output, and a grid that does not split its input channels");
+  a.yll = nullptr; a.yhi[0] = a.yhi[1] = a.yhi[2] = nullptr;
+  if (d->y_ll) {       // third output: the halved LL band of y (y itself not written); with y_hi: its whole Haar transform
+    const bool dwt = d->y_hi[0] != nullptr;
+    if (llm || wf_pair(d) || a.part || d->y || (dwt ? (d->y2 || !d->y_hi[1] || !d->y_hi[2]) : !d->y2) || d->N != 8 || d->H % 2 ||
+        d->W % 4 || !aligned16(d->y_ll) || !aligned16(d->y_hi[0]) || !aligned16(d->y_hi[1]) || !aligned16(d->y_hi[2]))
+      return fail(TMDIFF_E_UNSUPPORTED, "conv3d_wf_fwd: the LL / Haar output needs 8 bands, even H, W %% 4 == 0, planes wider than 8 columns, "
+                                        "y == NULL (with a second output, or with all three high bands and none), and a grid that "
+                                        "does not split its input channels");
     a.yll = d->y_ll;
+    for (int i = 0; i < 3; ++i) a.yhi[i] = dwt ? d->y_hi[i] : nullptr;
   }
   a.rc_x = nullptr; a.rc_w = nullptr; a.rc_cin = 0;
   if (d->rc_x) {       // the ResBlock's 1x1x1 res_conv folded into this launch's epilogue

@@ -45,6 +45,8 @@ class KernelConfig:
     wino_multipack     TMDIFF_WINO_MULTIPACK    True     finetune step: all Winograd weight forms re-packed by one launch
     fuse_res_conv      TMDIFF_FUSE_RES_CONV     True     inference: a ResBlock's 1x1x1 res_conv folded into conv21's epilogue (conv3d_wf)
     emit_ll            TMDIFF_EMIT_LL           True     inference: the ResBlock in front of a down block writes LL(y) / 2 instead of y
+    emit_dwt           TMDIFF_EMIT_DWT          True     inference: Conv_0 of a down block whose high bands are kept writes the Haar
+                                                         transform of its output instead of the output (no DWT pass)
     train_graph        TMDIFF_TRAIN_GRAPH       False    (model.DDPM) capture the finetune step into a HIP graph
     train_two_streams  TMDIFF_TRAIN_STREAMS     True     forward_train runs the condition branch on a second stream beside the
                                                          main branch's down path (at a local batch of 8 most launches fill half
@@ -68,6 +70,7 @@ class KernelConfig:
         "wgrad_wino": ("TMDIFF_WGRAD_WINO", _FLAG(True), True), "wgrad_wino_bias": ("TMDIFF_WGRAD_WINO_BIAS", _FLAG(True), True),
         "wgrad_bias": ("TMDIFF_WGRAD_BIAS", _FLAG(False), False), "wino_multipack": ("TMDIFF_WINO_MULTIPACK", _FLAG(True), True),
         "fuse_res_conv": ("TMDIFF_FUSE_RES_CONV", _FLAG(True), True), "emit_ll": ("TMDIFF_EMIT_LL", _FLAG(True), True),
+        "emit_dwt": ("TMDIFF_EMIT_DWT", _FLAG(True), True),
         "train_graph": ("TMDIFF_TRAIN_GRAPH", _FLAG(False), False),
         "train_two_streams": ("TMDIFF_TRAIN_STREAMS", _FLAG(True), True),
     }
@@ -313,7 +316,7 @@ def pack_conv_weight_bf16(w, groups=1):
 def make_conv_desc(segs, w_packed, cout, ksize, y, groups=1, bias=None, bias_scale=1.0, in_shift=None, in_scale=None,
                    shift_stride=0, scale_stride=0, in_act=False, in_mask=None, residual=None, out_scale=1.0,
                    y2=None, y2_shift=None, y2_scale=None, y2_shift_stride=0, y2_scale_stride=0, y2_act=False,
-                   x_bf16_shape=None, drop=None, out_div=1, y2_s2d=False, x_s2d=False, res_conv=None, y_ll=None):
+                   x_bf16_shape=None, drop=None, out_div=1, y2_s2d=False, x_s2d=False, res_conv=None, y_ll=None, y_hi=None):
     """Fill a tmdiff_conv3d_desc.  `segs` = list of 1..3 tensors [B, c_i, N, H, W] (concat-free input).
     in_shift / in_scale may be tensors or raw (ptr) ints into a projection bank.  y may be None when only the second
     output y2 = act2(y + y2_shift) * y2_scale (the consumer's prologue, same pointer conventions) is wanted.
@@ -388,7 +391,7 @@ def make_conv_desc(segs, w_packed, cout, ksize, y, groups=1, bias=None, bias_sca
             raise ValueError(f"conv3d: {nm} shape {tuple(t.shape)} != {want}")
     if y2_packed and (tuple(y2.shape) != (b, cout // 8, n * h * w, 8) or not (y2.is_cuda and y2.is_contiguous())):
         raise ValueError(f"conv3d: packed y2 shape {tuple(y2.shape)} != {(b, cout // 8, n * h * w, 8)}")
-    if y is None and y2 is None:
+    if y is None and y2 is None and not (y_ll is not None and y_hi is not None):
         raise ValueError("conv3d: no output")
     d.y = _chk(y, "y")
     d.y2 = y2.data_ptr() if y2_packed else _chk(y2, "y2")
@@ -398,10 +401,16 @@ def make_conv_desc(segs, w_packed, cout, ksize, y, groups=1, bias=None, bias_sca
     d.y2_act = 1 if y2_act else 0
     d.y2_bf16 = 1 if y2_packed else 0
     d.y2_s2d = 1 if (y2_s2d and y2 is not None) else 0
-    if y_ll is not None:       # third output: the halved LL band of y (tmdiff_conv3d_wf_fwd; y itself not written)
-        if y is not None or y2 is None or tuple(y_ll.shape) != (b, cout, n, h // 2, w // 2):
-            raise ValueError("conv3d: y_ll [B, Cout, N, H/2, W/2] goes with y=None and a second output")
+    if y_ll is not None:       # third output: the halved LL band of y (tmdiff_conv3d_wf_fwd; y itself not written) ...
+        q = (b, cout, n, h // 2, w // 2)
+        if y is not None or (y2 is None) == (y_hi is None) or tuple(y_ll.shape) != q:
+            raise ValueError("conv3d: y_ll [B, Cout, N, H/2, W/2] goes with y=None and EITHER a second output OR the three high bands")
         d.y_ll = _chk(y_ll, "y_ll")
+        if y_hi is not None:   # ... or, with the three high bands, the whole Haar transform (LL through the y2 prologue constants)
+            if len(y_hi) != 3 or any(tuple(t.shape) != q for t in y_hi):
+                raise ValueError("conv3d: y_hi = (LH, HL, HH), each [B, Cout, N, H/2, W/2]")
+            for i, t in enumerate(y_hi):
+                d.y_hi[i] = _chk(t, "y_hi")
     return d
 
 
@@ -437,7 +446,7 @@ def _tag(d):
     """Shape label of a launch for ConvTimer.summary(by_entry="layer"): channels, plane, what the epilogue reads / writes."""
     return (f"{d.Cin}->{d.Cout} g{d.groups} {d.N}x{d.H}x{d.W} b{d.B}" + (" seg%d" % d.nseg if d.nseg > 1 else "") +
             (" pro" if (d.in_act or d.in_shift or d.in_scale) else "") + (" +res" if d.residual else "") +
-            (" y" if d.y else "") + (" y2" if d.y2 else "") + (" ll" if d.y_ll else ""))
+            (" y" if d.y else "") + (" y2" if d.y2 else "") + (" dwt" if d.y_hi[0] else (" ll" if d.y_ll else "")))
 
 
 TIMER = None      # set to a ConvTimer() to time every conv launch
@@ -486,7 +495,7 @@ def conv3d(segs, w_packed, cout, ksize, out=None, math="fp32", pack_input=None, 
     as its input with x_bf16_shape=(N, H, W), skipping its pack pass.
     xp_out (fp32, 3x3x3): a [B, Cin, N, H, W] tensor that receives the prologue output x' (forces the staged kernel, whose
     prologue pass writes it there instead of the shared scratch) -- the training path keeps it for the weight gradient."""
-    if kw.get("res_conv") is not None or kw.get("y_ll") is not None or (emit is not None and emit.get("ll")):
+    if kw.get("res_conv") is not None or kw.get("y_ll") is not None or (emit is not None and (emit.get("ll") or emit.get("dwt"))):
         raise ValueError("conv3d: only conv3d_wf folds a residual convolution into its epilogue / writes the LL band")
     if x_bf16_shape is not None:
         b, (n, h, w) = segs[0].shape[0], x_bf16_shape
@@ -619,7 +628,7 @@ def conv3d_auto(segs, weights, cout, groups=1, math="fp32", emit=None, keep_y=Tr
         planes = 6 if fam == "wino4" else 4
         return fallback.conv3d_wino(segs, weights.wino(planes), cout, planes, emit=emit, keep_y=keep_y, groups=groups,
                                     xp_out=xp_out, **kw)
-    if (emit is not None and (emit.get("s2d") or emit.get("ll"))) or kw.get("res_conv") is not None:
+    if (emit is not None and (emit.get("s2d") or emit.get("ll") or emit.get("dwt"))) or kw.get("res_conv") is not None:
         raise ValueError("conv3d_auto: only conv3d_wf writes a space-to-depth second output / folds a residual convolution "
                          "(ask routing.wf_route first)")
     staged = fam == "staged" or (fam not in ("staged", "fused") and
@@ -639,6 +648,10 @@ def conv3d_wf(segs, w_packed, cout, emit=None, keep_y=True, groups=1, xp_out=Non
     dev = segs[0].device
     s2d = bool(emit is not None and emit.get("s2d"))
     want_ll = bool(emit is not None and emit.get("ll"))      # third output: LL(y) / 2 instead of y (returns (y2, y_ll))
+    want_dwt = bool(emit is not None and emit.get("dwt"))    # the whole Haar transform of y instead of y: returns (LL', LH, HL, HH),
+    if want_dwt and (s2d or want_ll):                        # LL' = the halved LL band through the `emit` prologue
+        raise ValueError("conv3d_wf: emit dwt=True excludes s2d / ll")
+    want_ll = want_ll or want_dwt
     if s2d or want_ll:
         cin = sum(s_.shape[1] for s_ in segs)
         if routing.wf_route(b, cin, cout, n, h, w, groups)[1] > 1 or h % 2 or w % 4:
@@ -649,8 +662,11 @@ def conv3d_wf(segs, w_packed, cout, emit=None, keep_y=True, groups=1, xp_out=Non
     y2 = None
     if want_ll:
         kw = dict(kw, y_ll=torch.empty(b, cout, n, h // 2, w // 2, device=dev, dtype=torch.float32))
-    if emit is not None:
+    if want_dwt:
+        kw = dict(kw, y_hi=[torch.empty(b, cout, n, h // 2, w // 2, device=dev, dtype=torch.float32) for _ in range(3)])
+    if emit is not None and not want_dwt:
         y2 = torch.empty((b, 4 * cout, n, h // 2, w // 2) if s2d else (b, cout, n, h, w), device=dev, dtype=torch.float32)
+    if emit is not None:
         kw = dict(kw, y2_act=emit.get("act", False), y2_shift=emit.get("shift"), y2_scale=emit.get("scale"),
                   y2_shift_stride=emit.get("shift_stride", 0), y2_scale_stride=emit.get("scale_stride", 0), y2_s2d=s2d)
     elif y is None:
@@ -674,7 +690,9 @@ def conv3d_wf(segs, w_packed, cout, emit=None, keep_y=True, groups=1, xp_out=Non
     elif xp_out is not None:          # plain input: x' IS the input
         xp_out.copy_(segs[0] if len(segs) == 1 else torch.cat(segs, 1))
     ret = y if y2 is None else ((y, y2) if y is not None else y2)
-    if want_ll:
+    if want_dwt:
+        ret = (kw["y_ll"], *kw["y_hi"])
+    elif want_ll:
         ret = (y2, kw["y_ll"])
     # EXECUTED flops: 54 multiply-adds per (ci, co) and tile of four output bands (the direct kernel: 27 per band), plus the
     # folded res_conv's rc_cin multiply-adds per output
