@@ -110,8 +110,8 @@ typedef struct tmdiff_conv3d_desc {
    * i.e. the 1x1x1 res_conv of a ResBlock (Hyper_unet_general.py:231, :248) on the block's RAW input rc_x [B, rc_cin, N, H, W],
    * accumulated on the matrix pipe where its consumer conv21 would have added it -- no launch of its own, its result never
    * written and read back.  rc_w = the weight [Cout, rc_cin, 1, 1, 1] as PyTorch holds it (contiguous, NOT packed); the
-   * caller adds res_conv's bias into `bias`.  Needs groups 1, rc_cin % 32 == 0, residual NULL, planes wider than 8 columns and
-   * a grid that does not split its input channels (tmdiff_conv3d_wf_plan() == 1); else TMDIFF_E_UNSUPPORTED. */
+   * caller adds res_conv's bias into `bias`.  Needs groups 1, rc_cin % 32 == 0 (at most 512), residual NULL and planes wider
+   * than 8 columns; else TMDIFF_E_UNSUPPORTED.  (A grid that splits its input channels adds it to the partial sums of range 0.) */
   const float* rc_x;
   const float* rc_w;
   int32_t rc_cin;
@@ -126,6 +126,15 @@ typedef struct tmdiff_conv3d_desc {
    * bands are kept makes of its Conv_0 output (DWT, then Conv_1's prologue on the LL band; Hyper_unet_general.py:388-396,
    * DWT_IDWT_Functions.py:47-57) without a full-resolution tensor or a transform pass.  Same shape conditions as y_ll. */
   float* y_hi[3];
+  /* Optional by-product of a 1x1x1 convolution on the bandwidth kernel (tmdiff_conv3d_fwd, ksize 1; ABI v6): xp_out [B, Cin, N, H, W]
+   * receives act(x + xp_shift[b, c]) of every element of the (possibly segmented) input -- the prologue output that ANOTHER
+   * convolution of the same input wants (a ResBlock's conv20 beside its res_conv, Hyper_unet_general.py:243-248: both read the
+   * concatenated block input, one raw, one through SiLU(x + Dense(e))), written by the kernel that loads every element anyway.
+   * xp_shift: [B, Cin] (row stride xp_shift_stride as in_shift_stride) or NULL; xp_act != 0: SiLU.  Shapes the bandwidth kernel
+   * does not take: TMDIFF_E_UNSUPPORTED. */
+  float* xp_out;
+  const float* xp_shift;
+  int32_t xp_shift_stride, xp_act;
   /* != 0 (tmdiff_conv3d_wf_fwd only, even H, W % 4 == 0, a grid that does not split its input channels): y2 is written in
    * "space to depth" form [B, 4 Cout, N, H/2, W/2], channel 4 co + 2 ph + pw holding y2[co][n][2i + ph][2j + pw] -- the input
    * form of tmdiff_conv3d_wfll_fwd (the down blocks' Conv_0 + LL band, Hyper_unet_general.py:371-372, :389, :396). */
@@ -154,6 +163,8 @@ int32_t tmdiff_conv3d_pack_weights_multi_chunks(int32_t Cout, int32_t Cin, int32
 int tmdiff_conv3d_pack_weights_multi(const tmdiff_pack_entry* entries_dev, const int32_t* chunk_tensor_dev,
                                      const int32_t* chunk_index_dev, int32_t n_chunks, tmdiff_stream_t stream);
 int tmdiff_conv3d_fwd(const tmdiff_conv3d_desc* d, tmdiff_stream_t stream);
+/* 1 when tmdiff_conv3d_fwd writes the by-product d->xp_out for this descriptor (else it would fail with TMDIFF_E_UNSUPPORTED) */
+int tmdiff_conv3d_fwd_xp_supported(const tmdiff_conv3d_desc* d);
 /* bytes of d->splitk_ws this convolution would use (0: its grid fills the chip, or the shape is not split) */
 size_t tmdiff_conv3d_fwd_splitk_workspace_bytes(const tmdiff_conv3d_desc* d);
 

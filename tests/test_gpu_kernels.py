@@ -1090,6 +1090,51 @@ torch.save(outs, sys.argv[2])
         assert_close(res["vec"][tag], ref.float(), 2e-5, 2e-6, f"1x1x1 {tag} vs fp64")
 
 
+@pytest.mark.parametrize("case", [(16, (32, 32, 32), 32, (8, 64, 32)), (32, (64, 64), 64, (8, 32, 32)), (16, (16, 48), 96, (4, 64, 64))])
+def test_conv1_writes_the_prologue_of_its_input_on_the_side(ops, case):
+    """desc.xp_* (ABI v6): the 1x1x1 bandwidth kernel also writes SiLU(x + shift) of its segmented input -- what a ResBlock's
+    conv20 reads of the same concat (reference Hyper_unet_general.py:243-248) -- bit for bit the prologue pass it replaces;
+    its own result is unchanged; routing.k1_side_xp agrees with the library about which launches can."""
+    from tmdiff_amd import routing
+    from tmdiff_amd._lib import lib
+    import ctypes as C
+    B, seg_c, cout, shp = case
+    cin = sum(seg_c)
+    torch.manual_seed(cin + cout)
+    xs = [torch.randn(B, c, *shp, device="cuda") for c in seg_c]
+    w = torch.randn(cout, cin, 1, 1, 1, device="cuda") / cin ** 0.5
+    bias, sh = torch.randn(cout, device="cuda"), torch.randn(B, cin, device="cuda") * 0.5
+    wp = ops.pack_conv_weight(w)
+    assert routing.k1_side_xp(B, seg_c, cout, *shp)
+    plain = ops.conv3d(xs, wp, cout, 1, bias=bias)
+    for shift, act in ((sh, True), (None, True), (sh, False)):
+        side = torch.full((B, cin, *shp), float("nan"), device="cuda")
+        y = ops.conv3d(xs, wp, cout, 1, bias=bias, side_xp=dict(out=side, shift=shift, act=act))
+        assert torch.equal(y, plain)
+        v = torch.cat(xs, 1)
+        if shift is not None:
+            v = v + shift[:, :, None, None, None]
+        want = (v.double() * torch.sigmoid(v.double())).float() if act else v
+        assert_close(side, want.cpu(), 2e-6, 1e-6, "side prologue vs torch")
+    # ... and the pass it replaces (conv3d_wf's prologue pass, kept through xp_out): the same bits
+    w3 = torch.randn(32, cin, 3, 3, 3, device="cuda") / (cin * 27) ** 0.5
+    kept = torch.empty(B, cin, *shp, device="cuda")
+    ops.conv3d_wf(xs, ops.pack_conv_weight_wino(w3, mode=2, planes=6), 32, in_act=True, in_shift=sh, xp_out=kept)
+    side = torch.empty_like(kept)
+    ops.conv3d(xs, wp, cout, 1, bias=bias, side_xp=dict(out=side, shift=sh, act=True))
+    assert torch.equal(side, kept)
+    # launches the 16-byte kernel does not take are refused (and the rule says so beforehand)
+    small = [x[:1, :, :, :8, :8].contiguous() for x in xs]
+    assert not routing.k1_side_xp(1, seg_c, cout, shp[0], 8, 8)
+    d = ops.make_conv_desc(small, wp, cout, 1, torch.empty(1, cout, shp[0], 8, 8, device="cuda"),
+                           side_xp=dict(out=torch.empty(1, cin, shp[0], 8, 8, device="cuda"), act=True))
+    assert lib.tmdiff_conv3d_fwd_xp_supported(C.byref(d)) == 0
+    with pytest.raises(ValueError):
+        ops.conv3d(small, wp, cout, 1, side_xp=dict(out=torch.empty(1, cin, shp[0], 8, 8, device="cuda"), act=True))
+    with pytest.raises(ValueError):
+        ops.conv3d(xs, ops.pack_conv_weight(w3), 32, 3, side_xp=dict(out=side, act=True))
+
+
 def test_multi_tensor_weight_packing_equals_single(ops):
     """tmdiff_conv3d_pack_weights_multi (every weight of a network, forward + data-gradient packing, one launch, LDS-tiled
     transposes) against tmdiff_conv3d_pack_weights tensor by tensor: identical buffers; refresh() re-packs on a version bump."""

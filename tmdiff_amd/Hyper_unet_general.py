@@ -445,10 +445,17 @@ class WavBEST(nn.Module):
         # res_conv (1x1x1, where the channel count changes) folded into conv21's epilogue where conv21 runs on conv3d_wf unsplit:
         # W1^T x is accumulated by the matrix pipe into conv21's output blocks -- no launch of its own, no residual tensor
         # written and read back (19 -> 13 1x1x1 launches per step at the benchmark batch)
-        rc = None
+        rc = side = None
         if isinstance(rb.res_conv, nn.Conv3d):
             rc = self._fold_res_conv(P, name, segs)
-            res = None if rc is not None else self._conv(P, name + ".res_conv", segs)
+            if rc is None and pre is None and self._side_xp(P, name, segs):
+                # a segmented input (an up block's concat): res_conv's launch reads every element anyway and also writes
+                # conv20's prologue output SiLU(x + shift) -- conv20 then reads one plain tensor, no prologue pass
+                side = ops.scratch_like(segs, "side_xp")
+                res = self._conv(P, name + ".res_conv", segs, side_xp=dict(
+                    out=side, shift=sh.get("in_shift"), shift_stride=sh.get("shift_stride", 0), act=True))
+            else:
+                res = None if rc is not None else self._conv(P, name + ".res_conv", segs)
         else:
             res = segs[0]
         rckw = {} if rc is None else {"res_conv": rc, "bias": rb.res_conv.bias.detach()}
@@ -460,7 +467,9 @@ class WavBEST(nn.Module):
         kw = {} if emit is None else {"emit": emit}
         if ops.config.epilogue_fuse and (both16 or (name + ".conv20" not in P["bf16"] and name + ".conv21" not in P["bf16"])):
             mid = dict(act=True, scale=sc["in_scale"], scale_stride=sc["scale_stride"])
-            if pre is not None:     # (bf16 mode: `pre` is the packed bf16 form a bf16 producer wrote)
+            if side is not None:    # (res_conv's launch wrote conv20's prologue output: a plain-input convolution)
+                t1p = self._conv(P, name + ".conv20", [side], keep_y=False, emit=mid)
+            elif pre is not None:   # (bf16 mode: `pre` is the packed bf16 form a bf16 producer wrote)
                 t1p = self._conv(P, name + ".conv20", [pre], keep_y=False, emit=mid,
                                  x_bf16_shape=tuple(segs[0].shape[2:]) if pre.dtype == torch.int16 else None)
             else:
@@ -494,11 +503,27 @@ class WavBEST(nn.Module):
         return (routing.conv3_family(b, m.in_channels, m.out_channels, n, h, w, 1, plain=False) == "wf" and
                 routing.wf_route(b, m.in_channels, m.out_channels, n, h, w)[1] == 1)
 
+    def _side_xp(self, P, name, segs):
+        """True when res_conv of the ResBlock `name` can write conv20's prologue output on the side (make_conv_desc side_xp=):
+        fp32 inference with the conv20 -> conv21 epilogue fusion, a segmented input, conv20 on conv3d_wf (whose prologue would
+        otherwise be a pass of its own), res_conv on the 16-byte bandwidth kernel."""
+        cfg = ops.config
+        if not (cfg.side_xp and cfg.epilogue_fuse) or len(segs) < 2 or any((name + k) in P["bf16"] for k in (".conv20", ".conv21", ".res_conv")):
+            return False
+        m = self.get_submodule(name + ".conv20")
+        b, _, n, h, w = segs[0].shape
+        from . import routing
+        if P["w_wino"].get(name + ".conv20") is None or m.groups != 1:
+            return False
+        if routing.conv3_family(b, m.in_channels, m.out_channels, n, h, w, 1, plain=False) not in ("wf", "wf_pair"):
+            return False
+        return routing.k1_side_xp(b, [s.shape[1] for s in segs], self.get_submodule(name + ".res_conv").out_channels, n, h, w)
+
     def _fold_res_conv(self, P, name, segs, k1=".res_conv", k3=".conv21"):
         """(x, the 1x1x1 weight, Cx) when the 1x1x1 convolution `name + k1` -- a ResBlock's res_conv, a down block's Conv_2 --
         whose result is only ever the residual of the 3x3x3 convolution `name + k3` can ride in that convolution's epilogue
         (make_conv_desc res_conv=), else None: fp32, one input tensor x of a multiple of 32 channels at the consumer's plane
-        size, the consumer on conv3d_wf (not its pair mode) without splitting its input channels."""
+        size, the consumer on conv3d_wf (not its pair mode; a split-K grid adds it to the partial sums of its first range)."""
         if not ops.config.fuse_res_conv or len(segs) != 1 or (name + k3) in P["bf16"] or (name + k1) in P["bf16"]:
             return None
         m3, x = self.get_submodule(name + k3), segs[0]
@@ -507,8 +532,6 @@ class WavBEST(nn.Module):
             return None
         from . import routing
         if routing.conv3_family(b, m3.in_channels, m3.out_channels, n, h, w, 1, plain=False) != "wf":
-            return None
-        if routing.wf_route(b, m3.in_channels, m3.out_channels, n, h, w)[1] != 1:
             return None
         return x, self.get_submodule(name + k1).weight.detach(), cx
 

@@ -29,7 +29,7 @@ class Conv3dDesc(C.Structure):
         ("y2", vp), ("y2_shift", vp), ("y2_scale", vp), ("y2_shift_stride", C.c_int32), ("y2_scale_stride", C.c_int32),
         ("y2_act", C.c_int32), ("y2_bf16", C.c_int32), ("x_bf16", C.c_int32),
         ("splitk_ws", vp), ("splitk_ws_bytes", C.c_int64),
-        ("drop_seed", C.c_uint64), ("drop_p", C.c_float), ("drop_seed_dev", vp), ("rc_x", vp), ("rc_w", vp), ("rc_cin", C.c_int32), ("y_ll", vp), ("y_hi", vp * 3),
+        ("drop_seed", C.c_uint64), ("drop_p", C.c_float), ("drop_seed_dev", vp), ("rc_x", vp), ("rc_w", vp), ("rc_cin", C.c_int32), ("y_ll", vp), ("y_hi", vp * 3), ("xp_out", vp), ("xp_shift", vp), ("xp_shift_stride", C.c_int32), ("xp_act", C.c_int32),
         ("y2_s2d", C.c_int32),
     ]
 
@@ -43,6 +43,7 @@ SIGNATURES = {
     "tmdiff_conv3d_pack_weights_multi": (C.c_int, [vp, vp, vp, C.c_int32, vp]),
     "tmdiff_conv3d_fwd": (C.c_int, [C.POINTER(Conv3dDesc), vp]),
     "tmdiff_conv3d_fwd_splitk_workspace_bytes": (C.c_size_t, [C.POINTER(Conv3dDesc)]),
+    "tmdiff_conv3d_fwd_xp_supported": (C.c_int, [C.POINTER(Conv3dDesc)]),
     "tmdiff_conv3d_fwd_staged_supported": (C.c_int, [C.POINTER(Conv3dDesc)]),
     "tmdiff_conv3d_fwd_staged_workspace_bytes": (C.c_size_t, [C.POINTER(Conv3dDesc)]),
     "tmdiff_conv3d_fwd_staged": (C.c_int, [C.POINTER(Conv3dDesc), vp, vp]),

@@ -86,7 +86,7 @@ struct SplitKReduceArgs {
 int launch_splitk_reduce(const SplitKReduceArgs& r, hipStream_t st);
 
 // 1x1x1 forward through the LDS-free bandwidth kernel (conv1.hip); TMDIFF_E_UNSUPPORTED = shape not taken.
-int conv1_fp32_try(const tmdiff_conv3d_desc* d, hipStream_t st);
+int conv1_fp32_try(const tmdiff_conv3d_desc* d, hipStream_t st, bool dry = false);   // dry: no launch, TMDIFF_OK = the 16-byte kernel on a raw input
 
 }  // namespace tmdiff
 

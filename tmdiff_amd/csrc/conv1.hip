@@ -37,6 +37,12 @@ struct K1Args {
   float* y;
   long plane;
   int ptiles, tiles_co;
+  // by-product (desc.xp_out): act(x + xp_shift[b, c]) of every input element, written densely as [B, Cin, plane] by the workgroups of
+  // channel tile 0 -- the prologue output ANOTHER convolution of the same (segmented) input wants (a ResBlock's conv20 beside
+  // its res_conv): this kernel loads every x element anyway
+  float* xp_out;
+  const float* xp_shift;
+  int xp_shift_stride, xp_act;
 };
 
 template <int NS, int MSUB, bool ACT>
@@ -99,7 +105,7 @@ __global__ void __launch_bounds__(256, 2) conv1_fp32_kernel(const K1Args a) {
       }
     }
   };
-  auto mfma_group = [&](int buf) __attribute__((always_inline)) {
+  auto mfma_group = [&](int buf, int q) __attribute__((always_inline)) {
 #pragma unroll
     for (int j = 0; j < G; ++j) {
       float bv[NS];
@@ -119,10 +125,10 @@ __global__ void __launch_bounds__(256, 2) conv1_fp32_kernel(const K1Args a) {
   load_group(0, 0);
   for (int q = 0; q < ngroups; q += 2) {
     if (q + 1 < ngroups) load_group(q + 1, 1);
-    mfma_group(0);
+    mfma_group(0, q);
     if (q + 1 < ngroups) {
       if (q + 2 < ngroups) load_group(q + 2, 0);
-      mfma_group(1);
+      mfma_group(1, q + 1);
     }
   }
 
@@ -156,7 +162,7 @@ __global__ void __launch_bounds__(256, 2) conv1_fp32_kernel(const K1Args a) {
 // whose issue rate, not HBM, capped it at ~3.4 TB/s.  Same accumulation order, so the same bits.
 constexpr int GV = 4;  // K-steps per register group (8 input channels)
 
-template <int MSUB, bool ACT>
+template <int MSUB, bool ACT, bool XP>
 __global__ void __launch_bounds__(256, 2) conv1_fp32_vec_kernel(const K1Args a) {
   constexpr int CO = 32 * MSUB, NS = 4;
   const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
@@ -184,7 +190,8 @@ __global__ void __launch_bounds__(256, 2) conv1_fp32_vec_kernel(const K1Args a) 
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[s][m][r] = 0.f;
 
-  float xr[2][GV][NS], wr[2][GV][MSUB], shr[2][GV], scr[2][GV];
+  float xr[2][GV][NS], wr[2][GV][MSUB], shr[2][GV], scr[2][GV], xsh[2][GV];
+  const bool xp_on = XP && co_tile == 0;      // (XP instantiations only: the by-product costs registers)
   auto load_group = [&](int q, int buf) __attribute__((always_inline)) {
     const int cg = g * a.cin_g + q * 2 * GV;  // first of 8 channels; they lie in one input segment
     const float* src;
@@ -202,6 +209,7 @@ __global__ void __launch_bounds__(256, 2) conv1_fp32_vec_kernel(const K1Args a) 
       xr[buf][j][0] = t.x, xr[buf][j][1] = t.y, xr[buf][j][2] = t.z, xr[buf][j][3] = t.w;
       shr[buf][j] = shp[2 * j + khalf];
       scr[buf][j] = scp[2 * j + khalf];
+      if constexpr (XP) xsh[buf][j] = (xp_on && a.xp_shift) ? a.xp_shift[(long)b * a.xp_shift_stride + cg + 2 * j + khalf] : 0.f;
       if constexpr (MSUB == 2) {
         const float2 w2 = *reinterpret_cast<const float2*>(wq + (long)(2 * j) * a.cout_g);
         wr[buf][j][0] = w2.x, wr[buf][j][1] = w2.y;
@@ -210,7 +218,21 @@ __global__ void __launch_bounds__(256, 2) conv1_fp32_vec_kernel(const K1Args a) 
       }
     }
   };
-  auto mfma_group = [&](int buf) __attribute__((always_inline)) {
+  auto mfma_group = [&](int buf, int q) __attribute__((always_inline)) {
+    if constexpr (XP) if (xp_on && pok) {     // the by-product: channel g * cin_g + q * 8 + 2 j + khalf, this lane's four positions
+      float* dst = a.xp_out + ((long)b * a.Cin + g * a.cin_g + q * 2 * GV + khalf) * plane + p0;
+#pragma unroll
+      for (int j = 0; j < GV; ++j) {
+        float u[4];
+#pragma unroll
+        for (int s = 0; s < 4; ++s) {
+          const float t = xr[buf][j][s] + xsh[buf][j];
+          const float ta = tmdiff::silu_f(t);
+          u[s] = a.xp_act ? ta : t;
+        }
+        *reinterpret_cast<float4*>(dst + (long)(2 * j) * plane) = make_float4(u[0], u[1], u[2], u[3]);
+      }
+    }
 #pragma unroll
     for (int j = 0; j < GV; ++j) {
       float bv[NS];
@@ -230,10 +252,10 @@ __global__ void __launch_bounds__(256, 2) conv1_fp32_vec_kernel(const K1Args a) 
   load_group(0, 0);
   for (int q = 0; q < ngroups; q += 2) {
     if (q + 1 < ngroups) load_group(q + 1, 1);
-    mfma_group(0);
+    mfma_group(0, q);
     if (q + 1 < ngroups) {
       if (q + 2 < ngroups) load_group(q + 2, 0);
-      mfma_group(1);
+      mfma_group(1, q + 1);
     }
   }
 
@@ -270,8 +292,11 @@ int launch_vec(K1Args& a, int in_act, hipStream_t st) {
   a.tiles_co = a.cout_g / (32 * MSUB);
   const long blocks = (long)a.B * a.groups * a.ptiles * a.tiles_co;
   if (blocks <= 0 || blocks > 0x7fffffffL) return tmdiff::fail(TMDIFF_E_INVALID, "conv1: grid of %ld blocks", blocks);
-  if (in_act) conv1_fp32_vec_kernel<MSUB, true><<<(unsigned)blocks, 256, 0, st>>>(a);
-  else conv1_fp32_vec_kernel<MSUB, false><<<(unsigned)blocks, 256, 0, st>>>(a);
+  if (a.xp_out) {          // (the by-product goes with a raw input: res_conv has no prologue of its own)
+    if (in_act) return tmdiff::fail(TMDIFF_E_UNSUPPORTED, "conv1: xp_out with an activated input");
+    conv1_fp32_vec_kernel<MSUB, false, true><<<(unsigned)blocks, 256, 0, st>>>(a);
+  } else if (in_act) conv1_fp32_vec_kernel<MSUB, true, false><<<(unsigned)blocks, 256, 0, st>>>(a);
+  else conv1_fp32_vec_kernel<MSUB, false, false><<<(unsigned)blocks, 256, 0, st>>>(a);
   return tmdiff::check_launch("conv3d_fwd (1x1x1 bandwidth kernel, 16-byte)");
 }
 
@@ -281,6 +306,7 @@ int launch(K1Args& a, int in_act, hipStream_t st) {
   a.tiles_co = a.cout_g / (32 * MSUB);
   const long blocks = (long)a.B * a.groups * a.ptiles * a.tiles_co;
   if (blocks <= 0 || blocks > 0x7fffffffL) return tmdiff::fail(TMDIFF_E_INVALID, "conv1: grid of %ld blocks", blocks);
+  if (a.xp_out) return tmdiff::fail(TMDIFF_E_UNSUPPORTED, "conv1: xp_out needs the 16-byte kernel (plane %% 4 == 0, aligned tensors, >= 512 tiles)");
   if (in_act) conv1_fp32_kernel<NS, MSUB, true><<<(unsigned)blocks, 256, 0, st>>>(a);
   else conv1_fp32_kernel<NS, MSUB, false><<<(unsigned)blocks, 256, 0, st>>>(a);
   return tmdiff::check_launch("conv3d_fwd (1x1x1 bandwidth kernel)");
@@ -290,7 +316,7 @@ int launch(K1Args& a, int in_act, hipStream_t st) {
 
 // 1x1x1 forward through the bandwidth kernel.  Returns TMDIFF_E_UNSUPPORTED (without touching the error string)
 // for shapes it does not take; tmdiff_conv3d_fwd then uses the generic kernel.  `d` has been validated by the caller.
-int tmdiff::conv1_fp32_try(const tmdiff_conv3d_desc* d, hipStream_t st) {
+int tmdiff::conv1_fp32_try(const tmdiff_conv3d_desc* d, hipStream_t st, bool dry) {
   if (d->ksize != 1 || d->in_mask || d->drop_p > 0.f || d->y2 || !d->y) return TMDIFF_E_UNSUPPORTED;
   const int cin_g = d->Cin / d->groups, cout_g = d->Cout / d->groups;
   if (cin_g % (2 * G) || cout_g % 32) return TMDIFF_E_UNSUPPORTED;
@@ -310,14 +336,30 @@ int tmdiff::conv1_fp32_try(const tmdiff_conv3d_desc* d, hipStream_t st) {
   a.scale_stride = d->in_scale_stride > 0 ? d->in_scale_stride : (d->in_scale_stride < 0 ? 0 : d->Cin);
   a.residual = d->residual; a.out_scale = d->out_scale; a.y = d->y;
   a.plane = plane;
+  a.xp_out = d->xp_out; a.xp_shift = d->xp_shift; a.xp_act = d->xp_act;
+  a.xp_shift_stride = d->xp_shift_stride > 0 ? d->xp_shift_stride : (d->xp_shift_stride < 0 ? 0 : d->Cin);
   // channel tiles follow the weight packing: 64-channel interleaved rows when cout_g % 64 == 0
   // (its 512-position tiles must still fill the chip: the 8x8x8 level keeps the dword kernel's 256-position tiles)
   const long blocks_vec = (long)d->B * d->groups * ((plane + 511) / 512) * (cout_g % 64 == 0 ? cout_g / 64 : cout_g / 32);
   static const bool force_vec = getenv("TMDIFF_CONV1_VEC") != nullptr;     // experiments / tests: wherever it is legal
-  bool vec = plane % 4 == 0 && (blocks_vec >= 512 || force_vec) && aligned16(d->y) && aligned16(d->residual);
+  bool vec = plane % 4 == 0 && (blocks_vec >= 512 || force_vec) && aligned16(d->y) && aligned16(d->residual) && aligned16(d->xp_out);
   for (int i = 0; i < d->nseg; ++i) vec = vec && aligned16(d->seg_x[i]);
   static const bool no_vec = getenv("TMDIFF_CONV1_DWORD") != nullptr;      // experiments: the dword kernel everywhere
+  if (dry) return (vec && !no_vec && !d->in_act) ? TMDIFF_OK : TMDIFF_E_UNSUPPORTED;    // (xp_supported: the 16-byte kernel, raw input)
   if (vec && !no_vec) return cout_g % 64 == 0 ? launch_vec<2>(a, d->in_act, st) : launch_vec<1>(a, d->in_act, st);
   if (cout_g % 64 == 0) return launch<2, 2>(a, d->in_act, st);
   return launch<2, 1>(a, d->in_act, st);
+}
+
+// 1 when tmdiff_conv3d_fwd would write the by-product d->xp_out for this descriptor (the 16-byte bandwidth kernel takes it), else 0.
+extern "C" int tmdiff_conv3d_fwd_xp_supported(const tmdiff_conv3d_desc* d) {
+  if (!d || !d->xp_out || d->x_bf16 || d->groups <= 0 || d->Cin <= 0 || d->Cout <= 0 || d->Cin % d->groups || d->Cout % d->groups ||
+      d->nseg < 1 || d->nseg > 3 || d->B <= 0 || !d->w_packed)
+    return 0;
+  int csum = 0;
+  for (int i = 0; i < d->nseg; ++i) {
+    if (!d->seg_x[i] || d->seg_c[i] <= 0) return 0;
+    csum += d->seg_c[i];
+  }
+  return csum == d->Cin && tmdiff::conv1_fp32_try(d, nullptr, true) == TMDIFF_OK ? 1 : 0;
 }

@@ -763,6 +763,9 @@ extern "C" int tmdiff_conv3d_fwd(const tmdiff_conv3d_desc* d, tmdiff_stream_t st
     const int rc = conv1_fp32_try(d, as_stream(stream));
     if (rc != TMDIFF_E_UNSUPPORTED) return rc;
   }
+  if (d->xp_out)
+    return fail(TMDIFF_E_UNSUPPORTED, "conv3d_fwd: only the 1x1x1 bandwidth kernel writes the by-product xp_out (fp32, ksize 1, no mask / "
+                                      "dropout / second output, Cin/g and every segment %% 16 == 0, Cout/g %% 32 == 0)");
 
   ConvArgs a;
   a.B = d->B; a.N = d->N; a.H = d->H; a.W = d->W;

@@ -617,8 +617,10 @@ __global__ void __launch_bounds__(256, 2) conv3d_wf_kernel(const WfArgs a) {
   // [rc_cin][32] of this channel tile goes through LDS once per workgroup (the stages are free), a lane's x values come
   // straight from global memory as its B operands (positions of a block = the MFMA columns: coalesced rows of 16), sixteen
   // K-steps of the next work item in flight while the current one is multiplied.
+  // (a grid that splits its input channels: the workgroups of range 0 add it to THEIR partial sums -- the reduction kernel sums the
+  //  ranges and applies bias / scale / second output as ever)
   if constexpr (!PAIR && !LLM) {
-    if (a.rc_x) {
+    if (a.rc_x && split == 0) {
       __syncthreads();                                    // every wave is done with the stages: they hold the weight slab now
       float* wl = lds;                                    // [rc_cin][32]
       for (int e = tid; e < a.rc_cin * 32; e += 256) {    // from the PyTorch-layout weight [Cout][rc_cin]: thread = (co, ci), ci fastest
@@ -879,10 +881,10 @@ int wf_forward(const tmdiff_conv3d_desc* d, void* workspace, tmdiff_stream_t str
   }
   a.rc_x = nullptr; a.rc_w = nullptr; a.rc_cin = 0;
   if (d->rc_x) {       // the ResBlock's 1x1x1 res_conv folded into this launch's epilogue
-    if (llm || wf_pair(d) || a.part || d->groups != 1 || d->residual || !d->rc_w || d->rc_cin <= 0 || d->rc_cin % 32 || d->rc_cin > 512 ||
+    if (llm || wf_pair(d) || d->groups != 1 || d->residual || !d->rc_w || d->rc_cin <= 0 || d->rc_cin % 32 || d->rc_cin > 512 ||
         !aligned16(d->rc_x) || !aligned16(d->rc_w))
-      return fail(TMDIFF_E_UNSUPPORTED, "conv3d_wf_fwd: a folded residual convolution needs groups 1, rc_cin %% 32 == 0, no residual tensor, "
-                                        "planes wider than 8 columns and a grid that does not split its input channels");
+      return fail(TMDIFF_E_UNSUPPORTED, "conv3d_wf_fwd: a folded residual convolution needs groups 1, rc_cin %% 32 == 0 (at most 512), no residual "
+                                        "tensor and planes wider than 8 columns");
     TMDIFF_REQUIRE((long)d->rc_cin * d->N * d->H * d->W < (1L << 30), "conv3d_wf_fwd: rc_x sample too large for 32-bit byte offsets");
     a.rc_x = d->rc_x; a.rc_w = d->rc_w; a.rc_cin = d->rc_cin;
   }

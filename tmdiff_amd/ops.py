@@ -47,6 +47,8 @@ class KernelConfig:
     emit_ll            TMDIFF_EMIT_LL           True     inference: the ResBlock in front of a down block writes LL(y) / 2 instead of y
     emit_dwt           TMDIFF_EMIT_DWT          True     inference: Conv_0 of a down block whose high bands are kept writes the Haar
                                                          transform of its output instead of the output (no DWT pass)
+    side_xp            TMDIFF_SIDE_XP           True     inference: a ResBlock's res_conv launch (segmented input) also writes conv20's
+                                                         prologue output (no prologue pass in front of conv20)
     train_graph        TMDIFF_TRAIN_GRAPH       False    (model.DDPM) capture the finetune step into a HIP graph
     train_two_streams  TMDIFF_TRAIN_STREAMS     True     forward_train runs the condition branch on a second stream beside the
                                                          main branch's down path (at a local batch of 8 most launches fill half
@@ -70,7 +72,7 @@ class KernelConfig:
         "wgrad_wino": ("TMDIFF_WGRAD_WINO", _FLAG(True), True), "wgrad_wino_bias": ("TMDIFF_WGRAD_WINO_BIAS", _FLAG(True), True),
         "wgrad_bias": ("TMDIFF_WGRAD_BIAS", _FLAG(False), False), "wino_multipack": ("TMDIFF_WINO_MULTIPACK", _FLAG(True), True),
         "fuse_res_conv": ("TMDIFF_FUSE_RES_CONV", _FLAG(True), True), "emit_ll": ("TMDIFF_EMIT_LL", _FLAG(True), True),
-        "emit_dwt": ("TMDIFF_EMIT_DWT", _FLAG(True), True),
+        "emit_dwt": ("TMDIFF_EMIT_DWT", _FLAG(True), True), "side_xp": ("TMDIFF_SIDE_XP", _FLAG(True), True),
         "train_graph": ("TMDIFF_TRAIN_GRAPH", _FLAG(False), False),
         "train_two_streams": ("TMDIFF_TRAIN_STREAMS", _FLAG(True), True),
     }
@@ -316,7 +318,8 @@ def pack_conv_weight_bf16(w, groups=1):
 def make_conv_desc(segs, w_packed, cout, ksize, y, groups=1, bias=None, bias_scale=1.0, in_shift=None, in_scale=None,
                    shift_stride=0, scale_stride=0, in_act=False, in_mask=None, residual=None, out_scale=1.0,
                    y2=None, y2_shift=None, y2_scale=None, y2_shift_stride=0, y2_scale_stride=0, y2_act=False,
-                   x_bf16_shape=None, drop=None, out_div=1, y2_s2d=False, x_s2d=False, res_conv=None, y_ll=None, y_hi=None):
+                   x_bf16_shape=None, drop=None, out_div=1, y2_s2d=False, x_s2d=False, res_conv=None, y_ll=None, y_hi=None,
+                   side_xp=None):
     """Fill a tmdiff_conv3d_desc.  `segs` = list of 1..3 tensors [B, c_i, N, H, W] (concat-free input).
     in_shift / in_scale may be tensors or raw (ptr) ints into a projection bank.  y may be None when only the second
     output y2 = act2(y + y2_shift) * y2_scale (the consumer's prologue, same pointer conventions) is wanted.
@@ -326,8 +329,16 @@ def make_conv_desc(segs, w_packed, cout, ksize, y, groups=1, bias=None, bias_sca
     form [B, 4 Cout, N, H/2, W/2] (tmdiff_conv3d_wf_fwd only); x_s2d: segs[0] is such a tensor and the descriptor is that of
     the convolution on the full-resolution tensor it stands for (tmdiff_conv3d_wfll_fwd).  res_conv = (x_raw [B, Cx, N, H, W],
     the 1x1x1 weight [Cout, Cx, 1, 1, 1] itself (contiguous fp32, not packed), Cx): a ResBlock's res_conv folded into the epilogue (tmdiff_conv3d_wf_fwd
-    only; desc.rc_*) -- the caller passes res_conv's bias as `bias` and no residual."""
+    only; desc.rc_*) -- the caller passes res_conv's bias as `bias` and no residual.  side_xp = dict(out= [B, Cin, N, H, W], shift=, shift_stride=,
+    act=): a 1x1x1 convolution on the bandwidth kernel also writes act(x + shift) of its (segmented) input there -- the prologue
+    output another convolution of the same input wants (desc.xp_*; routing.k1_side_xp)."""
     d = Conv3dDesc()
+    if side_xp is not None:
+        so, ssh = side_xp["out"], side_xp.get("shift")
+        if ksize != 1 or tuple(so.shape) != (segs[0].shape[0], sum(s.shape[1] for s in segs), *segs[0].shape[2:]):
+            raise ValueError("conv3d: side_xp goes with a 1x1x1 convolution; out = [B, Cin, N, H, W]")
+        d.xp_out, d.xp_shift = _chk(so, "side_xp out"), (ssh if isinstance(ssh, int) else _chk(ssh, "side_xp shift"))
+        d.xp_shift_stride, d.xp_act = int(side_xp.get("shift_stride", 0)), 1 if side_xp.get("act") else 0
     if res_conv is not None:
         rx, rw, rcin = res_conv
         if residual is not None or tuple(rx.shape) != (segs[0].shape[0], rcin, *segs[0].shape[2:]) or rw.numel() != rcin * cout:
@@ -475,6 +486,14 @@ _WS = {}     # (device index, stream) -> grow-only scratch tensor (prologue outp
              # on one stream are ordered, so consecutive convolutions can reuse it; other streams get their own
 
 
+def scratch_like(segs, tag):
+    """A [B, sum of channels, N, H, W] fp32 view of the per-stream scratch `tag` (contents live until its next user on the stream)."""
+    b, _, n, h, w = segs[0].shape
+    shape = (b, sum(s.shape[1] for s in segs), n, h, w)
+    numel = shape[0] * shape[1] * n * h * w
+    return _workspace(segs[0].device, numel * 4, tag).view(torch.float32)[:numel].view(shape)
+
+
 def _workspace(device, nbytes, tag="x"):
     key = (device.index, stream_ptr(), tag)
     ws = _WS.get(key)
@@ -513,6 +532,8 @@ def conv3d(segs, w_packed, cout, ksize, out=None, math="fp32", pack_input=None, 
     elif y is None:
         raise ValueError("conv3d: keep_y=False needs emit=")
     d = make_conv_desc(segs, w_packed, cout, ksize, y, **kw)
+    if d.xp_out and (math != "fp32" or not lib.tmdiff_conv3d_fwd_xp_supported(C.byref(d))):
+        raise ValueError("conv3d: side_xp needs the 16-byte 1x1x1 bandwidth kernel (ask routing.k1_side_xp first)")
     ret = y if y2 is None else ((y, y2) if y is not None else y2)
     if math == "bf16":
         if w_packed.dtype != torch.int16:
@@ -674,8 +695,8 @@ def conv3d_wf(segs, w_packed, cout, emit=None, keep_y=True, groups=1, xp_out=Non
     d = make_conv_desc(segs, w_packed, cout, 3, y, y2=y2, groups=groups, **kw)
     if not lib.tmdiff_conv3d_wf_supported(C.byref(d)):
         raise ValueError("conv3d_wf: shape not supported")
-    # (a launch that folds a residual convolution or writes a space-to-depth output runs unsplit: no workspace is lent)
-    nsk = lib.tmdiff_conv3d_wf_splitk_workspace_bytes(C.byref(d)) if (config.wf_splitk and not d.rc_cin and not want_ll) else 0
+    # (a launch that writes an LL / Haar / space-to-depth output runs unsplit: no workspace is lent)
+    nsk = lib.tmdiff_conv3d_wf_splitk_workspace_bytes(C.byref(d)) if (config.wf_splitk and not want_ll) else 0
     if nsk:
         d.splitk_ws, d.splitk_ws_bytes = _workspace(dev, nsk, "splitk").data_ptr(), nsk
     nws = lib.tmdiff_conv3d_wf_workspace_bytes(C.byref(d))
