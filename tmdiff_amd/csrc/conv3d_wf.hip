@@ -32,9 +32,6 @@
 #ifndef TMDIFF_WF_ABLATE
 #define TMDIFF_WF_ABLATE 0       // timing experiments (WRONG results): 1 = no input transform in the loop, 2 = ... and no raw DMA,
 #endif                           // 3 = ... and no weight DMA
-#ifndef TMDIFF_WF_NT
-#define TMDIFF_WF_NT 0           // experiments: 1 = non-temporal stores of y / y2 in the epilogue, 2 = ... and non-temporal residual loads
-#endif
 #ifndef TMDIFF_WF_STAMPS
 #define TMDIFF_WF_STAMPS 0       // diagnostic build: per-wave s_memrealtime stamps (tools/wino_stamps.py)
 #endif
@@ -44,33 +41,6 @@ namespace {
 using f32x16 = __attribute__((ext_vector_type(16))) float;
 using f32x4 = __attribute__((ext_vector_type(4))) float;
 using f32x2 = __attribute__((ext_vector_type(2))) float;
-
-// epilogue stores / residual loads (TMDIFF_WF_NT: streamed past the caches -- nothing of a launch's output is read again
-// before the next launch, whose working set is far larger than L2 anyway)
-__device__ __forceinline__ void store4(float* p, float a, float b, float c, float d) {
-#if TMDIFF_WF_NT >= 1
-  f32x4 v = {a, b, c, d};
-  __builtin_nontemporal_store(v, reinterpret_cast<f32x4*>(p));
-#else
-  *reinterpret_cast<float4*>(p) = make_float4(a, b, c, d);
-#endif
-}
-__device__ __forceinline__ void store2(float* p, float a, float b) {
-#if TMDIFF_WF_NT >= 1
-  f32x2 v = {a, b};
-  __builtin_nontemporal_store(v, reinterpret_cast<f32x2*>(p));
-#else
-  *reinterpret_cast<float2*>(p) = make_float2(a, b);
-#endif
-}
-__device__ __forceinline__ float4 load_res4(const float* p) {
-#if TMDIFF_WF_NT >= 2
-  const f32x4 v = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(p));
-  return make_float4(v.x, v.y, v.z, v.w);
-#else
-  return *reinterpret_cast<const float4*>(p);
-#endif
-}
 
 template <int B, int E, class F>
 __device__ __forceinline__ void static_for(F&& f) {
@@ -114,6 +84,20 @@ struct WfArgs {
   int rc_cin;
 };
 
+// The kernel's (only) argument where it lies in the kernel-argument segment: loads through this pointer are scalar loads at the
+// place of use; the compiler neither shares them with the argument values it already holds nor keeps them afterwards.
+#if defined(__HIP_DEVICE_COMPILE__)
+using KArgs = const WfArgs __attribute__((address_space(4)))*;
+__device__ __forceinline__ KArgs kargs() {
+  KArgs k = (KArgs)__builtin_amdgcn_kernarg_segment_ptr();
+  asm volatile("" : "+s"(k));
+  return k;
+}
+#else
+using KArgs = const WfArgs*;
+__device__ __forceinline__ KArgs kargs() { return nullptr; }
+#endif
+
 // LDS-DMA through a buffer descriptor: 16 bytes per lane from base + voff (bytes) to dst + 16 * lane.  An offset at or beyond
 // the descriptor's size -- kOutside -- reads as zero: the zero padding of the convolution costs a select, not a second
 // source pointer (the address is one 32-bit register per lane; the base lives in scalar registers).
@@ -139,11 +123,29 @@ __device__ __forceinline__ void dma_b128(buf_rsrc r, unsigned voff, float* dst) 
 __device__ __forceinline__ float buf_load(buf_rsrc r, unsigned voff, unsigned soff) {
   return __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(r, voff, soff, 0));
 }
+// the epilogue's quads: 16 / 8 bytes per lane at base + voff; a lane at kOutside reads zero / stores nothing
+using u32x4 = __attribute__((ext_vector_type(4))) unsigned;
+using u32x2 = __attribute__((ext_vector_type(2))) unsigned;
+__device__ __forceinline__ float4 buf_load4(buf_rsrc r, unsigned voff) {
+  const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(r, voff, 0, 0);
+  return make_float4(__uint_as_float(v.x), __uint_as_float(v.y), __uint_as_float(v.z), __uint_as_float(v.w));
+}
+__device__ __forceinline__ void buf_store4(buf_rsrc r, unsigned voff, float a, float b, float c, float d) {
+  const u32x4 v = {__float_as_uint(a), __float_as_uint(b), __float_as_uint(c), __float_as_uint(d)};
+  __builtin_amdgcn_raw_buffer_store_b128(v, r, voff, 0, 0);
+}
+__device__ __forceinline__ void buf_store2(buf_rsrc r, unsigned voff, float a, float b) {
+  const u32x2 v = {__float_as_uint(a), __float_as_uint(b)};
+  __builtin_amdgcn_raw_buffer_store_b64(v, r, voff, 0, 0);
+}
 #else
 struct buf_rsrc {};
 __device__ __forceinline__ buf_rsrc make_rsrc(const float*, unsigned) { return {}; }
 __device__ __forceinline__ void dma_b128(buf_rsrc, unsigned, float*) {}
 __device__ __forceinline__ float buf_load(buf_rsrc, unsigned, unsigned) { return 0.f; }
+__device__ __forceinline__ float4 buf_load4(buf_rsrc, unsigned) { return make_float4(0.f, 0.f, 0.f, 0.f); }
+__device__ __forceinline__ void buf_store4(buf_rsrc, unsigned, float, float, float, float) {}
+__device__ __forceinline__ void buf_store2(buf_rsrc, unsigned, float, float) {}
 #endif
 
 __device__ __forceinline__ unsigned xcd_remap(unsigned bid, unsigned nwg) {
@@ -211,43 +213,58 @@ struct GeoF {
 // Epilogue of a wave: its 8 output blocks (2 sub-tiles x 4 bands, each 32 channels x 32 positions in the MFMA D layout: a lane
 // = one position, 16 channels) leave as in epilogue.h -- through a wave-private 4 KB LDS tile T[channel][position]
 // (ds_write_b32 in the D layout, ds_read_b128 along the positions), lane (tc, tq) = (lane >> 3, lane & 7) then owns channels
-// tc + 8 j and four consecutive positions: bias, residual, scale, the consumer's prologue, dwordx4 stores -- with one
-// difference: the residual quads are requested THREE blocks ahead (the output transform has already freed a third of the
-// accumulators, so there are registers for it).  With one block of look-ahead a wave waited out most of an HBM round trip
+// tc + 8 j and four consecutive positions: bias, residual, scale, the consumer's prologue, dwordx4 stores -- with two
+// differences.  The residual quads are requested THREE blocks ahead (the output transform has already freed a third of the
+// accumulators, so there are registers for it): with one block of look-ahead a wave waited out most of an HBM round trip
 // per block, eight times per tile: 22 of the 33 us of a tile's epilogue at 32 input channels (tools/wino_stamps.py).
+// And every output / residual tensor is addressed through a BUFFER DESCRIPTOR over this tile's 32 channels of sample b (PAIR:
+// up to the same channels of sample b + 1): a lane's address is one 32-bit byte offset, and a lane outside the image carries
+// the offset kOutside -- its loads return zero, its stores are dropped by the bounds check.  No store sits under a branch:
+// ragged tiles run the code of full ones, the wave never diverges (with 190 registers of live accumulators the compiler
+// spilled and reloaded around divergent stores; what a lane that was inactive there reads back is not its own).
 // (PAIR: the lane's four positions belong to image b or b + 1 -- pimg_ok says whether the second exists -- and the second
 // output's per-(b, channel) shift / scale come in both versions, sh2_l / sc2_l for b and sh2_m / sc2_m for b + 1)
-template <bool Y, bool RES, bool Y2, bool FULL, int TT, int TH, int TW, bool PAIR>
-__device__ __forceinline__ void epilogue_wf(const WfArgs& a, f32x16 (&out)[8], float bias_l, float sh2_l, float sc2_l, int b, int g,
+template <bool Y, bool RES, bool Y2, int TT, int TH, int TW, bool PAIR>
+__device__ __forceinline__ void epilogue_wf(KArgs a, f32x16 (&out)[8], float bias_l, float sh2_l, float sc2_l, int b, int g,
                                             int co0, int h0, int w0, int wv, int lane, long plane, float* T, float* ydst,
                                             float oscale, float sh2_m = 0.f, float sc2_m = 1.f, bool pimg_ok = true) {
 #pragma clang fp contract(off)   // (every instantiation rounds alike: without y the compiler would fuse "* scale" and "+ shift")
   constexpr int MO = 4, DEPTH = 3;
   const int l31 = lane & 31, khalf = lane >> 5, tq = lane & 7, tc = lane >> 3;
-  const int hw = a.H * a.W;
-  const long cbase = ((long)b * a.Cout + g * a.cout_g + co0 + tc) * plane;
-  int toff[2], s2off[2];
-  bool tok[2];
-  const long qplane = plane >> 2;
+  const int hw = a->H * a->W;
+  // descriptors: 32 channels of sample b from channel g * cout_g + co0 on (PAIR and a second image: up to its 32 channels)
+  const long cb = ((long)b * a->Cout + g * a->cout_g + co0) * plane;
+  const unsigned span = (unsigned)(((PAIR && pimg_ok ? (long)a->Cout * plane : 0) + 32 * plane) * 4);
+  const buf_rsrc ry = make_rsrc(ydst ? ydst + cb : nullptr, ydst ? span : 0);
+  const buf_rsrc rr = make_rsrc(a->residual ? a->residual + cb : nullptr, a->residual ? span : 0);
+  const buf_rsrc r2 = make_rsrc(a->y2 ? a->y2 + cb : nullptr, a->y2 ? span : 0);
+  unsigned toff[2], s2off[2];     // byte offsets of the lane's quad inside the descriptor (channel tc, band 0 of its band tile)
+  const unsigned qplane4 = (unsigned)plane;                 // a quarter plane in bytes
 #pragma unroll
   for (int s = 0; s < 2; ++s) {
     // the lane's four positions 4 tq .. 4 tq + 3 of sub-tile s (see the operand offsets of the kernel): band tile, row, column
     const int bt = TT == 2 ? tq >> 2 : 0;
     const int h = h0 + (TT == 2 ? 2 * wv + s : 4 * wv + 2 * s + (tq >> 2));
+    bool ok;
+    int e, e2;
     if constexpr (PAIR) {      // columns 0-7 of the tile: image b, 8-15: image b + 1 (a whole sample further on)
       const int img = (tq & 3) >> 1, w = 4 * (tq & 1);
-      tok[s] = h < a.H && (img == 0 || pimg_ok);
-      toff[s] = tok[s] ? img * a.Cout * (int)plane + (MO * bt) * hw + h * a.W + w : 0;
-      s2off[s] = tok[s] ? img * a.Cout * (int)plane + (h & 1) * 2 * (int)qplane + (MO * bt) * (hw >> 2) + (h >> 1) * (a.W >> 1) + (w >> 1) : 0;
+      ok = h < a->H && (img == 0 || pimg_ok);
+      e = img * a->Cout * (int)plane + (MO * bt) * hw + h * a->W + w;
+      e2 = img * a->Cout * (int)plane + (h & 1) * 2 * (int)(plane >> 2) + (MO * bt) * (hw >> 2) + (h >> 1) * (a->W >> 1) + (w >> 1);
     } else {
       const int w = w0 + 4 * (tq & 3);
-      tok[s] = FULL || (h < a.H && w < a.W);                    // (W % 4 == 0: the four positions stand or fall together)
-      toff[s] = tok[s] ? (MO * bt) * hw + h * a.W + w : 0;
+      ok = h < a->H && w < a->W;                    // (W % 4 == 0: the four positions stand or fall together)
+      e = (MO * bt) * hw + h * a->W + w;
       // space-to-depth form of the second output: channel (co, ph, pw) = 4 co + 2 ph + pw at half the resolution -- the channel
       // base is the same (4 channels of a quarter plane each); the lane's four columns are two of either column parity
-      s2off[s] = tok[s] ? (h & 1) * 2 * (int)qplane + (MO * bt) * (hw >> 2) + (h >> 1) * (a.W >> 1) + (w >> 1) : 0;
+      e2 = (h & 1) * 2 * (int)(plane >> 2) + (MO * bt) * (hw >> 2) + (h >> 1) * (a->W >> 1) + (w >> 1);
     }
+    toff[s] = ok ? (unsigned)((tc * (int)plane + e) * 4) : kOutside;
+    s2off[s] = ok ? (unsigned)((tc * (int)plane + e2) * 4) : kOutside;
   }
+  // (offset of channel tc + 8 j, band n from the lane's base: added only where the base is inside -- kOutside + anything would wrap)
+  auto at = [&](unsigned base, unsigned add) __attribute__((always_inline)) { return base >= kOutside ? kOutside : base + add; };
   float bias_t[4], sh2_t[4], sc2_t[4];
   const bool second = PAIR && ((tq & 3) >> 1);
 #pragma unroll
@@ -263,18 +280,28 @@ __device__ __forceinline__ void epilogue_wf(const WfArgs& a, f32x16 (&out)[8], f
   }
   // The wave's eight blocks are taken in the order (band n, sub-tile s = 0, 1): step p is block i = s * MO + n with s = p & 1,
   // n = p >> 1 -- the two rows 2 wv, 2 wv + 1 of one band (TT == 2) follow each other, which is what the LL output below needs.
-  // Third output (a.yll; only where y itself is not wanted, TT == 2, not PAIR): the HALVED LL BAND of y, (a + b + c + d) / 4 over
+  // Third output (a->yll; only where y itself is not wanted, TT == 2, not PAIR): the HALVED LL BAND of y, (a + b + c + d) / 4 over
   // the 2 x 2 pixel block -- what a down block's Conv_2 path reads of its ResBlock's output (Hyper_unet_general.py:374, :390, :396):
   // a lane holds four columns of row 2 wv of a band, then the same four of row 2 wv + 1: two LL values per channel, one float2.
   float4 rs[DEPTH + 1][4];          // step p in slot p % (DEPTH + 1)
   auto load_res = [&](auto pc) __attribute__((always_inline)) {
     constexpr int p = decltype(pc)::value, s = p & 1, n = p >> 1;
 #pragma unroll
-    for (int j = 0; j < 4; ++j)     // (outside the image: a valid address, the value is never stored)
-      rs[p % (DEPTH + 1)][j] = load_res4(a.residual + cbase + (long)(8 * j) * plane + (long)n * hw + toff[s]);
+    for (int j = 0; j < 4; ++j)     // (outside the image: zero, never stored)
+      rs[p % (DEPTH + 1)][j] = buf_load4(rr, at(toff[s], (unsigned)((8 * j * (int)plane + n * hw) * 4)));
   };
   constexpr bool LL_OK = !Y && TT == 2 && !PAIR;
-  const bool want_ll = LL_OK && a.yll != nullptr;
+  const bool want_ll = LL_OK && a->yll != nullptr;
+  // the quarter-size outputs: the same 32 channels, a quarter plane each (the LL pair of a lane: both rows inside or neither)
+  const long cbq = cb >> 2;
+  const unsigned spanq = (unsigned)(32 * plane);
+  const buf_rsrc rll = make_rsrc(want_ll ? a->yll + cbq : nullptr, want_ll ? spanq : 0);
+  const bool want_hi = want_ll && a->yhi[0] != nullptr;
+  const buf_rsrc rh0 = make_rsrc(want_hi ? a->yhi[0] + cbq : nullptr, want_hi ? spanq : 0);
+  const buf_rsrc rh1 = make_rsrc(want_hi ? a->yhi[1] + cbq : nullptr, want_hi ? spanq : 0);
+  const buf_rsrc rh2 = make_rsrc(want_hi ? a->yhi[2] + cbq : nullptr, want_hi ? spanq : 0);
+  // (s2off[0] of row 2 wv, whose row-parity term is zero, IS the quad's place in a quarter plane; channel stride plane / 4)
+  const unsigned lloff = (toff[0] >= kOutside || toff[1] >= kOutside) ? kOutside : s2off[0] - (unsigned)(tc * (int)plane * 4) + (unsigned)(tc * (int)plane);
   float vk[4][4];                   // row 2 wv of the current band (LL output only)
   if constexpr (RES) static_for<0, DEPTH>([&](auto pc) __attribute__((always_inline)) { load_res(pc); });
   static_for<0, 8>([&](auto pc) __attribute__((always_inline)) {
@@ -294,53 +321,48 @@ __device__ __forceinline__ void epilogue_wf(const WfArgs& a, f32x16 (&out)[8], f
       }
 #pragma unroll
       for (int e = 0; e < 4; ++e) v[e] = (v[e] + bias_t[j] + q[e]) * oscale;   // as the scalar epilogue
-      const long o = cbase + (long)(8 * j) * plane + (long)n * hw + toff[s];
-      if constexpr (Y) {
-        if (FULL || tok[s]) store4(ydst + o, v[0], v[1], v[2], v[3]);
-      }
+      const unsigned cj = (unsigned)((8 * j * (int)plane + n * hw) * 4);
+      if constexpr (Y) buf_store4(ry, at(toff[s], cj), v[0], v[1], v[2], v[3]);
       if constexpr (LL_OK) {
-        if (want_ll) {
+        if (want_ll) {      // (uniform)
           if constexpr (s == 0) {
 #pragma unroll
             for (int e = 0; e < 4; ++e) vk[j][e] = v[e];
           } else {
             // band MO * bt + n, row (h0 + 2 wv) / 2, columns (w0 + 4 (tq & 3)) / 2 and the next of the quarter-size plane
-            // (s2off[0] is exactly that offset: row 2 wv of the tile is even, so its row-parity term is zero)
-            const long ol = ((cbase + (long)(8 * j) * plane) >> 2) + (long)n * (hw >> 2) + s2off[0];
+            const unsigned ol = at(lloff, (unsigned)((8 * j * (int)(plane >> 2) + n * (hw >> 2)) * 4));
             const float ll0 = ((vk[j][0] + vk[j][1]) + (v[0] + v[1])) * 0.25f, ll1 = ((vk[j][2] + vk[j][3]) + (v[2] + v[3])) * 0.25f;
-            if (a.yhi[0]) {
+            if (want_hi) {  // (uniform)
               // the whole transform of the 2 x 2 blocks (a b / c d): LL / 2 through the consumer's prologue, LH = (a - b + c - d) / 2,
               // HL = (a + b - c - d) / 2, HH = (a - b - c + d) / 2 (DWT_IDWT_Functions.py:47-57 in closed form)
-              if constexpr (Y2) if (FULL || (tok[0] && tok[1])) {
+              if constexpr (Y2) {
                 const float x0 = ll0 + sh2_t[j], x1 = ll1 + sh2_t[j];
                 const float a0 = tmdiff::silu_f(x0), a1 = tmdiff::silu_f(x1);
-                store2(a.yll + ol, (a.y2_act ? a0 : x0) * sc2_t[j], (a.y2_act ? a1 : x1) * sc2_t[j]);
-                store2(a.yhi[0] + ol, ((vk[j][0] - vk[j][1]) + (v[0] - v[1])) * 0.5f, ((vk[j][2] - vk[j][3]) + (v[2] - v[3])) * 0.5f);
-                store2(a.yhi[1] + ol, ((vk[j][0] + vk[j][1]) - (v[0] + v[1])) * 0.5f, ((vk[j][2] + vk[j][3]) - (v[2] + v[3])) * 0.5f);
-                store2(a.yhi[2] + ol, ((vk[j][0] - vk[j][1]) - (v[0] - v[1])) * 0.5f, ((vk[j][2] - vk[j][3]) - (v[2] - v[3])) * 0.5f);
+                buf_store2(rll, ol, (a->y2_act ? a0 : x0) * sc2_t[j], (a->y2_act ? a1 : x1) * sc2_t[j]);
+                buf_store2(rh0, ol, ((vk[j][0] - vk[j][1]) + (v[0] - v[1])) * 0.5f, ((vk[j][2] - vk[j][3]) + (v[2] - v[3])) * 0.5f);
+                buf_store2(rh1, ol, ((vk[j][0] + vk[j][1]) - (v[0] + v[1])) * 0.5f, ((vk[j][2] + vk[j][3]) - (v[2] + v[3])) * 0.5f);
+                buf_store2(rh2, ol, ((vk[j][0] - vk[j][1]) - (v[0] - v[1])) * 0.5f, ((vk[j][2] - vk[j][3]) - (v[2] - v[3])) * 0.5f);
               }
-            } else if (FULL || (tok[0] && tok[1])) {
-              store2(a.yll + ol, ll0, ll1);
+            } else {
+              buf_store2(rll, ol, ll0, ll1);
             }
           }
         }
       }
-      if constexpr (Y2) if (a.y2) {
+      if constexpr (Y2) if (a->y2) {       // (uniform)
         float u[4];
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
           const float x = v[e] + sh2_t[j];
           const float xa = tmdiff::silu_f(x);
-          u[e] = (a.y2_act ? xa : x) * sc2_t[j];
+          u[e] = (a->y2_act ? xa : x) * sc2_t[j];
         }
-        if (a.y2_s2d) {
-          const long o2 = cbase + (long)(8 * j) * plane + (long)n * (hw >> 2) + s2off[s];
-          if (FULL || tok[s]) {
-            store2(a.y2 + o2, u[0], u[2]);
-            store2(a.y2 + o2 + qplane, u[1], u[3]);
-          }
-        } else if (FULL || tok[s]) {
-          store4(a.y2 + o, u[0], u[1], u[2], u[3]);
+        if (a->y2_s2d) {                   // (uniform)
+          const unsigned o2 = at(s2off[s], (unsigned)((8 * j * (int)plane + n * (hw >> 2)) * 4));
+          buf_store2(r2, o2, u[0], u[2]);
+          buf_store2(r2, at(o2, qplane4), u[1], u[3]);
+        } else {
+          buf_store4(r2, at(toff[s], cj), u[0], u[1], u[2], u[3]);
         }
       }
     }
@@ -665,18 +687,13 @@ __global__ void __launch_bounds__(256, 2) conv3d_wf_kernel(const WfArgs a) {
     }
   }
   float* T = lds + wv * 1024;     // (every wave is past the last barrier: the stages are free)
-  const bool full = !PAIR && h0 + TH <= a.H && w0 + TW <= a.W;     // (PAIR: every store is checked -- the second image may not exist)
-#define WF_EPI2(Y, R, Y2)                                                                                                   \
-  do {                                                                                                                      \
-    if constexpr (!PAIR) {                                                                                                  \
-      if (full) { epilogue_wf<Y, R, Y2, true, TT, TH, TW, false>(a, out, bias_l, sh2_l, sc2_l, b, g, co0, h0, w0, wv, lane, plane, T, a.y, a.out_scale); break; }  \
-    }                                                                                                                       \
-    epilogue_wf<Y, R, Y2, false, TT, TH, TW, PAIR>(a, out, bias_l, sh2_l, sc2_l, b, g, co0, h0, w0, wv, lane, plane, T, a.y, a.out_scale, sh2_m, sc2_m, pimg_ok);  \
-  } while (0)
+  const KArgs ea = kargs();       // (the epilogue's arguments, read from the kernel-argument segment HERE: scalar registers are as scarce
+                                  //  across the chunk loop as vector registers)
+#define WF_EPI2(Y, R, Y2) \
+  epilogue_wf<Y, R, Y2, TT, TH, TW, PAIR>(ea, out, bias_l, sh2_l, sc2_l, b, g, co0, h0, w0, wv, lane, plane, T, a.y, a.out_scale, sh2_m, sc2_m, pimg_ok)
   if (a.part) {     // split-K: this range's partial sums, bare (bias / residual / scale / second output: splitk_reduce_kernel)
     float* pd = a.part + (long)split * a.B * a.Cout * plane;
-    if (full) epilogue_wf<true, false, false, !PAIR, TT, TH, TW, PAIR>(a, out, 0.f, 0.f, 1.f, b, g, co0, h0, w0, wv, lane, plane, T, pd, 1.f);
-    else epilogue_wf<true, false, false, false, TT, TH, TW, PAIR>(a, out, 0.f, 0.f, 1.f, b, g, co0, h0, w0, wv, lane, plane, T, pd, 1.f, 0.f, 1.f, pimg_ok);
+    epilogue_wf<true, false, false, TT, TH, TW, PAIR>(ea, out, 0.f, 0.f, 1.f, b, g, co0, h0, w0, wv, lane, plane, T, pd, 1.f, 0.f, 1.f, pimg_ok);
   } else if (a.y) {
     if (a.residual) { if (a.y2) WF_EPI2(true, true, true); else WF_EPI2(true, true, false); }
     else            { if (a.y2) WF_EPI2(true, false, true); else WF_EPI2(true, false, false); }
@@ -824,7 +841,7 @@ int wf_forward(const tmdiff_conv3d_desc* d, void* workspace, tmdiff_stream_t str
   TMDIFF_REQUIRE(d->B >= 0, "conv3d_wf_fwd: bad extents");
   if (d->B == 0) return TMDIFF_OK;
   TMDIFF_REQUIRE(d->w_packed && (d->y || d->y2 || d->y_ll) && aligned16(d->w_packed), "conv3d_wf_fwd: NULL / unaligned weights or output");
-  TMDIFF_REQUIRE((long)2 * d->N * d->H * d->W < (1L << 31), "conv3d_wf_fwd: plane too large for 32-bit offsets");
+  TMDIFF_REQUIRE((long)d->N * d->H * d->W <= (1L << 24), "conv3d_wf_fwd: plane too large for 32-bit offsets (32 channels of a sample per descriptor)");
   int csum = 0;
   for (int i = 0; i < d->nseg; ++i) {
     TMDIFF_REQUIRE(d->seg_x[i] != nullptr && d->seg_c[i] > 0 && aligned16(d->seg_x[i]), "conv3d_wf_fwd: segment %d is empty / unaligned", i);
