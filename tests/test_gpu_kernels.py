@@ -1090,7 +1090,9 @@ torch.save(outs, sys.argv[2])
         assert_close(res["vec"][tag], ref.float(), 2e-5, 2e-6, f"1x1x1 {tag} vs fp64")
 
 
-@pytest.mark.parametrize("case", [(16, (32, 32, 32), 32, (8, 64, 32)), (32, (64, 64), 64, (8, 32, 32)), (16, (16, 48), 96, (4, 64, 64))])
+@pytest.mark.parametrize("case", [(16, (32, 32, 32), 32, (8, 64, 32)), (32, (64, 64), 64, (8, 32, 32)), (16, (16, 48), 96, (4, 64, 64)),
+                                  (32, (32, 32, 32), 32, (8, 36, 28)),       # a plane that ends inside a 512-position tile
+                                  (40, (64, 64), 64, (4, 44, 36))])
 def test_conv1_writes_the_prologue_of_its_input_on_the_side(ops, case):
     """desc.xp_* (ABI v6): the 1x1x1 bandwidth kernel also writes SiLU(x + shift) of its segmented input -- what a ResBlock's
     conv20 reads of the same concat (reference Hyper_unet_general.py:243-248) -- bit for bit the prologue pass it replaces;

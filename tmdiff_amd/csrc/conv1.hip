@@ -45,6 +45,22 @@ struct K1Args {
   int xp_shift_stride, xp_act;
 };
 
+// the by-product's stores (16-byte kernel): base + 32-bit byte offset through a buffer descriptor, offsets at or beyond its size are dropped
+constexpr unsigned kOutsideXp = 0xFFFFFFF0u;
+#if defined(__HIP_DEVICE_COMPILE__)
+using xp_rsrc = __amdgpu_buffer_rsrc_t;
+__device__ __forceinline__ xp_rsrc xp_make_rsrc(float* base, unsigned bytes) { return __builtin_amdgcn_make_buffer_rsrc(base, 0, bytes, 0x00020000); }
+__device__ __forceinline__ void xp_store4(xp_rsrc r, unsigned voff, float a, float b, float c, float d) {
+  using u32x4 = __attribute__((ext_vector_type(4))) unsigned;
+  const u32x4 v = {__float_as_uint(a), __float_as_uint(b), __float_as_uint(c), __float_as_uint(d)};
+  __builtin_amdgcn_raw_buffer_store_b128(v, r, voff, 0, 0);
+}
+#else
+struct xp_rsrc {};
+__device__ __forceinline__ xp_rsrc xp_make_rsrc(float*, unsigned) { return {}; }
+__device__ __forceinline__ void xp_store4(xp_rsrc, unsigned, float, float, float, float) {}
+#endif
+
 template <int NS, int MSUB, bool ACT>
 __global__ void __launch_bounds__(256, 2) conv1_fp32_kernel(const K1Args a) {
   constexpr int CO = 32 * MSUB;
@@ -192,6 +208,7 @@ __global__ void __launch_bounds__(256, 2) conv1_fp32_vec_kernel(const K1Args a) 
 
   float xr[2][GV][NS], wr[2][GV][MSUB], shr[2][GV], scr[2][GV], xsh[2][GV];
   const bool xp_on = XP && co_tile == 0;      // (XP instantiations only: the by-product costs registers)
+  const xp_rsrc xpr = xp_make_rsrc(XP ? a.xp_out + (long)b * a.Cin * plane : nullptr, XP ? (unsigned)((long)a.Cin * plane * 4) : 0u);
   auto load_group = [&](int q, int buf) __attribute__((always_inline)) {
     const int cg = g * a.cin_g + q * 2 * GV;  // first of 8 channels; they lie in one input segment
     const float* src;
@@ -219,8 +236,10 @@ __global__ void __launch_bounds__(256, 2) conv1_fp32_vec_kernel(const K1Args a) 
     }
   };
   auto mfma_group = [&](int buf, int q) __attribute__((always_inline)) {
-    if constexpr (XP) if (xp_on && pok) {     // the by-product: channel g * cin_g + q * 8 + 2 j + khalf, this lane's four positions
-      float* dst = a.xp_out + ((long)b * a.Cin + g * a.cin_g + q * 2 * GV + khalf) * plane + p0;
+    if constexpr (XP) if (xp_on) {     // the by-product: channel g * cin_g + q * 8 + 2 j + khalf, this lane's four positions
+      // (through a buffer descriptor over sample b: a lane beyond the plane carries an offset outside it and its store is dropped --
+      //  no store under a divergent branch, around which the compiler would spill live accumulators: see conv3d_wf.hip's epilogue)
+      const unsigned d0 = pok ? (unsigned)(((long)(g * a.cin_g + q * 2 * GV + khalf) * plane + p0) * 4) : kOutsideXp;
 #pragma unroll
       for (int j = 0; j < GV; ++j) {
         float u[4];
@@ -230,7 +249,7 @@ __global__ void __launch_bounds__(256, 2) conv1_fp32_vec_kernel(const K1Args a) 
           const float ta = tmdiff::silu_f(t);
           u[s] = a.xp_act ? ta : t;
         }
-        *reinterpret_cast<float4*>(dst + (long)(2 * j) * plane) = make_float4(u[0], u[1], u[2], u[3]);
+        xp_store4(xpr, pok ? d0 + (unsigned)(2 * j) * (unsigned)plane * 4u : kOutsideXp, u[0], u[1], u[2], u[3]);
       }
     }
 #pragma unroll
@@ -294,6 +313,7 @@ int launch_vec(K1Args& a, int in_act, hipStream_t st) {
   if (blocks <= 0 || blocks > 0x7fffffffL) return tmdiff::fail(TMDIFF_E_INVALID, "conv1: grid of %ld blocks", blocks);
   if (a.xp_out) {          // (the by-product goes with a raw input: res_conv has no prologue of its own)
     if (in_act) return tmdiff::fail(TMDIFF_E_UNSUPPORTED, "conv1: xp_out with an activated input");
+    if ((long)a.Cin * a.plane >= (1L << 30)) return tmdiff::fail(TMDIFF_E_UNSUPPORTED, "conv1: xp_out sample too large for 32-bit byte offsets");
     conv1_fp32_vec_kernel<MSUB, false, true><<<(unsigned)blocks, 256, 0, st>>>(a);
   } else if (in_act) conv1_fp32_vec_kernel<MSUB, true, false><<<(unsigned)blocks, 256, 0, st>>>(a);
   else conv1_fp32_vec_kernel<MSUB, false, false><<<(unsigned)blocks, 256, 0, st>>>(a);
@@ -345,7 +365,7 @@ int tmdiff::conv1_fp32_try(const tmdiff_conv3d_desc* d, hipStream_t st, bool dry
   bool vec = plane % 4 == 0 && (blocks_vec >= 512 || force_vec) && aligned16(d->y) && aligned16(d->residual) && aligned16(d->xp_out);
   for (int i = 0; i < d->nseg; ++i) vec = vec && aligned16(d->seg_x[i]);
   static const bool no_vec = getenv("TMDIFF_CONV1_DWORD") != nullptr;      // experiments: the dword kernel everywhere
-  if (dry) return (vec && !no_vec && !d->in_act) ? TMDIFF_OK : TMDIFF_E_UNSUPPORTED;    // (xp_supported: the 16-byte kernel, raw input)
+  if (dry) return (vec && !no_vec && !d->in_act && (long)d->Cin * plane < (1L << 30)) ? TMDIFF_OK : TMDIFF_E_UNSUPPORTED;    // (xp_supported: the 16-byte kernel, raw input)
   if (vec && !no_vec) return cout_g % 64 == 0 ? launch_vec<2>(a, d->in_act, st) : launch_vec<1>(a, d->in_act, st);
   if (cout_g % 64 == 0) return launch<2, 2>(a, d->in_act, st);
   return launch<2, 1>(a, d->in_act, st);

@@ -221,7 +221,8 @@ struct GeoF {
 // up to the same channels of sample b + 1): a lane's address is one 32-bit byte offset, and a lane outside the image carries
 // the offset kOutside -- its loads return zero, its stores are dropped by the bounds check.  No store sits under a branch:
 // ragged tiles run the code of full ones, the wave never diverges (with 190 registers of live accumulators the compiler
-// spilled and reloaded around divergent stores; what a lane that was inactive there reads back is not its own).
+// spills around divergent stores, and one experimental build computed ragged tiles wrongly in exactly the lanes such stores
+// mask off: profiles/r04_wf_experiments.txt), and no address is 64-bit arithmetic per lane.
 // (PAIR: the lane's four positions belong to image b or b + 1 -- pimg_ok says whether the second exists -- and the second
 // output's per-(b, channel) shift / scale come in both versions, sh2_l / sc2_l for b and sh2_m / sc2_m for b + 1)
 template <bool Y, bool RES, bool Y2, int TT, int TH, int TW, bool PAIR>

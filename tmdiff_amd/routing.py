@@ -145,7 +145,7 @@ def k1_side_xp(b, seg_c, cout, n, h, w, groups=1):
         return False
     cout_g = cout // groups
     tiles = b * groups * ((plane + 511) // 512) * (cout_g // 64 if cout_g % 64 == 0 else cout_g // 32)
-    return tiles >= 512 and plane * 16 < (1 << 31)
+    return tiles >= 512 and plane * 16 < (1 << 31) and cin * plane < (1 << 30)
 
 
 def ll_family(b, cin, cout, n, h, w, producer_s2d=True):
