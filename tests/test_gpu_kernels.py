@@ -1090,6 +1090,30 @@ torch.save(outs, sys.argv[2])
         assert_close(res["vec"][tag], ref.float(), 2e-5, 2e-6, f"1x1x1 {tag} vs fp64")
 
 
+@pytest.mark.parametrize("case", [(2, (64, 64, 128), 128, (8, 8, 8)), (3, (192,), 32, (4, 8, 12)), (32, (256, 256, 256), 128, (8, 8, 8)),
+                                  (1, (128,), 64, (8, 16, 16))])
+def test_conv1_small_planes_split_the_channels_over_the_waves(ops, case):
+    """The 1x1x1 kernel on small grids (the 8x8 / 16x16 levels: fewer than 512 tiles of 256 positions, at least 128 input
+    channels): the four waves of a workgroup take every fourth 16-channel group of the same 64 positions and their partial sums
+    meet in LDS (conv1.hip, KS = 4) -- prologue, segments, bias, residual, scale against fp64."""
+    B, seg_c, cout, shp = case
+    cin = sum(seg_c)
+    torch.manual_seed(cin + cout + B)
+    xs = [torch.randn(B, c, *shp) for c in seg_c]
+    w = torch.randn(cout, cin, 1, 1, 1) / cin ** 0.5
+    bias, res = torch.randn(cout), torch.randn(B, cout, *shp)
+    sh, sc = torch.randn(B, cin) * 0.3, torch.rand(B, cin) + 0.5
+    wp = ops.pack_conv_weight(cu(w))
+    x = torch.cat(xs, 1).double()
+    want = F.conv3d(x, w.double(), bias.double())
+    assert_close(ops.conv3d([cu(t) for t in xs], wp, cout, 1, bias=cu(bias)), want.float(), 2e-5, 2e-6, "1x1x1, channels over the waves")
+    xd = x + sh.double()[:, :, None, None, None]
+    xd = xd * torch.sigmoid(xd) * sc.double()[:, :, None, None, None]
+    want = (F.conv3d(xd, w.double(), bias.double()) + res.double()) * 0.5
+    y = ops.conv3d([cu(t) for t in xs], wp, cout, 1, bias=cu(bias), residual=cu(res), out_scale=0.5, in_shift=cu(sh), in_scale=cu(sc), in_act=True)
+    assert_close(y, want.float(), 2e-5, 2e-6, "1x1x1, channels over the waves, prologue + residual")
+
+
 @pytest.mark.parametrize("case", [(16, (32, 32, 32), 32, (8, 64, 32)), (32, (64, 64), 64, (8, 32, 32)), (16, (16, 48), 96, (4, 64, 64)),
                                   (32, (32, 32, 32), 32, (8, 36, 28)),       # a plane that ends inside a 512-position tile
                                   (40, (64, 64), 64, (4, 44, 36))])

@@ -61,10 +61,14 @@ __device__ __forceinline__ xp_rsrc xp_make_rsrc(float*, unsigned) { return {}; }
 __device__ __forceinline__ void xp_store4(xp_rsrc, unsigned, float, float, float, float) {}
 #endif
 
-template <int NS, int MSUB, bool ACT>
+// KS = 4 (small planes: the 8x8 / 16x16 levels, whose grids leave most CUs with one workgroup or none and whose waves then walk
+// the whole channel loop one memory round trip at a time -- 768 -> 128 at 8x8x8: 48 round trips, 81 us for 58 MB): the FOUR WAVES of
+// a workgroup share the same NS x 32 positions and take every fourth 16-channel group each; their partial sums meet in LDS (fixed
+// order: wave 0 + 1 + 2 + 3), and wave (s, m) finishes accumulator (s, m).  Four times the workgroups, a quarter of the round trips.
+template <int NS, int MSUB, bool ACT, int KS = 1>
 __global__ void __launch_bounds__(256, 2) conv1_fp32_kernel(const K1Args a) {
   constexpr int CO = 32 * MSUB;
-  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+  const int tid = threadIdx.x, lane = tid & 63, wv = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int l31 = lane & 31, khalf = lane >> 5;
   unsigned id = blockIdx.x;
   const int co_tile = __builtin_amdgcn_readfirstlane(id % a.tiles_co); id /= a.tiles_co;
@@ -79,7 +83,7 @@ __global__ void __launch_bounds__(256, 2) conv1_fp32_kernel(const K1Args a) {
   bool pok[NS];
 #pragma unroll
   for (int s = 0; s < NS; ++s) {
-    const long p = (long)ptile * (4 * NS * 32) + (wv * NS + s) * 32 + l31;
+    const long p = KS == 1 ? (long)ptile * (4 * NS * 32) + (wv * NS + s) * 32 + l31 : (long)ptile * (NS * 32) + s * 32 + l31;
     pok[s] = p < plane;
     pos[s] = (unsigned)(pok[s] ? p : plane - 1);  // clamped loads, no store
   }
@@ -138,13 +142,39 @@ __global__ void __launch_bounds__(256, 2) conv1_fp32_kernel(const K1Args a) {
           acc[s][m] = __builtin_amdgcn_mfma_f32_32x32x2f32(wr[buf][j][m], bv[s], acc[s][m], 0, 0, 0);
     }
   };
-  load_group(0, 0);
-  for (int q = 0; q < ngroups; q += 2) {
-    if (q + 1 < ngroups) load_group(q + 1, 1);
+  // this wave's groups: q0, q0 + KS, ... (KS = 1: all of them)
+  const int q0 = KS == 1 ? 0 : wv;
+  if (q0 < ngroups) load_group(q0, 0);
+  for (int q = q0; q < ngroups; q += 2 * KS) {
+    if (q + KS < ngroups) load_group(q + KS, 1);
     mfma_group(0, q);
-    if (q + 1 < ngroups) {
-      if (q + 2 < ngroups) load_group(q + 2, 0);
-      mfma_group(1, q + 1);
+    if (q + KS < ngroups) {
+      if (q + 2 * KS < ngroups) load_group(q + 2 * KS, 0);
+      mfma_group(1, q + KS);
+    }
+  }
+  if constexpr (KS > 1) {
+    static_assert(KS == 4 && NS * MSUB <= 4, "one wave per accumulator");
+    // partial sums through LDS: red[wave][accumulator][register][lane]; wave i then sums accumulator i over the waves in order
+    __shared__ float red[4 * NS * MSUB * 16 * 64];
+#pragma unroll
+    for (int s = 0; s < NS; ++s)
+#pragma unroll
+      for (int m = 0; m < MSUB; ++m)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) red[((wv * NS * MSUB + s * MSUB + m) * 16 + r) * 64 + lane] = acc[s][m][r];
+    __syncthreads();
+    if (wv >= NS * MSUB) return;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      float t = red[((0 * NS * MSUB + wv) * 16 + r) * 64 + lane];
+#pragma unroll
+      for (int k = 1; k < 4; ++k) t += red[((k * NS * MSUB + wv) * 16 + r) * 64 + lane];
+#pragma unroll
+      for (int s = 0; s < NS; ++s)
+#pragma unroll
+        for (int m = 0; m < MSUB; ++m)
+          if (s * MSUB + m == wv) acc[s][m][r] = t;      // (wv is wave-uniform: a scalar branch)
     }
   }
 
@@ -154,6 +184,7 @@ __global__ void __launch_bounds__(256, 2) conv1_fp32_kernel(const K1Args a) {
     const int cbase = g * a.cout_g + co0 + m * 32 + 4 * khalf;
 #pragma unroll
     for (int s = 0; s < NS; ++s) {
+      if (KS > 1 && s * MSUB + m != wv) continue;       // (KS = 4: this wave's accumulator only)
       const long obase = ((long)b * a.Cout + cbase) * plane + pos[s];
       float res[16], bs[16];
 #pragma unroll
@@ -320,15 +351,15 @@ int launch_vec(K1Args& a, int in_act, hipStream_t st) {
   return tmdiff::check_launch("conv3d_fwd (1x1x1 bandwidth kernel, 16-byte)");
 }
 
-template <int NS, int MSUB>
+template <int NS, int MSUB, int KS = 1>
 int launch(K1Args& a, int in_act, hipStream_t st) {
-  a.ptiles = (int)((a.plane + 4 * NS * 32 - 1) / (4 * NS * 32));
+  a.ptiles = (int)((a.plane + (KS == 1 ? 4 : 1) * NS * 32 - 1) / ((KS == 1 ? 4 : 1) * NS * 32));
   a.tiles_co = a.cout_g / (32 * MSUB);
   const long blocks = (long)a.B * a.groups * a.ptiles * a.tiles_co;
   if (blocks <= 0 || blocks > 0x7fffffffL) return tmdiff::fail(TMDIFF_E_INVALID, "conv1: grid of %ld blocks", blocks);
   if (a.xp_out) return tmdiff::fail(TMDIFF_E_UNSUPPORTED, "conv1: xp_out needs the 16-byte kernel (plane %% 4 == 0, aligned tensors, >= 512 tiles)");
-  if (in_act) conv1_fp32_kernel<NS, MSUB, true><<<(unsigned)blocks, 256, 0, st>>>(a);
-  else conv1_fp32_kernel<NS, MSUB, false><<<(unsigned)blocks, 256, 0, st>>>(a);
+  if (in_act) conv1_fp32_kernel<NS, MSUB, true, KS><<<(unsigned)blocks, 256, 0, st>>>(a);
+  else conv1_fp32_kernel<NS, MSUB, false, KS><<<(unsigned)blocks, 256, 0, st>>>(a);
   return tmdiff::check_launch("conv3d_fwd (1x1x1 bandwidth kernel)");
 }
 
@@ -367,8 +398,16 @@ int tmdiff::conv1_fp32_try(const tmdiff_conv3d_desc* d, hipStream_t st, bool dry
   static const bool no_vec = getenv("TMDIFF_CONV1_DWORD") != nullptr;      // experiments: the dword kernel everywhere
   if (dry) return (vec && !no_vec && !d->in_act && (long)d->Cin * plane < (1L << 30)) ? TMDIFF_OK : TMDIFF_E_UNSUPPORTED;    // (xp_supported: the 16-byte kernel, raw input)
   if (vec && !no_vec) return cout_g % 64 == 0 ? launch_vec<2>(a, d->in_act, st) : launch_vec<1>(a, d->in_act, st);
-  if (cout_g % 64 == 0) return launch<2, 2>(a, d->in_act, st);
-  return launch<2, 1>(a, d->in_act, st);
+  // small grids (fewer than two workgroups per CU of 256-position tiles) with at least 8 channel groups: the four waves of a
+  // workgroup split the channels (KS = 4).  TMDIFF_CONV1_KSPLIT=0: never (experiments; tests force either form).
+  static const int ksplit_mode = [] {
+    const char* e = getenv("TMDIFF_CONV1_KSPLIT");
+    return e ? atoi(e) : -1;      // -1: by grid size, 0: never, 1: wherever it is legal
+  }();
+  const long blocks_dword = (long)d->B * d->groups * ((plane + 255) / 256) * (cout_g % 64 == 0 ? cout_g / 64 : cout_g / 32);
+  const bool ks = ksplit_mode != 0 && cin_g / (2 * G) >= 8 && (ksplit_mode == 1 || blocks_dword < 512);
+  if (cout_g % 64 == 0) return ks ? launch<2, 2, 4>(a, d->in_act, st) : launch<2, 2>(a, d->in_act, st);
+  return ks ? launch<2, 1, 4>(a, d->in_act, st) : launch<2, 1>(a, d->in_act, st);
 }
 
 // 1 when tmdiff_conv3d_fwd would write the by-product d->xp_out for this descriptor (the 16-byte bandwidth kernel takes it), else 0.
