@@ -707,8 +707,10 @@ def main():
                                      "tb_per_s": round(k1_bytes / (k1_ms * 1e-3) / 1e12, 2) if k1_ms > 0 else 0.0,
                                      "frac_of_copy_rate": round(k1_bytes / (k1_ms * 1e-3) / 1e12 / COPY_RATE_TB_S, 3) if k1_ms > 0 else 0.0,
                                      "copy_rate_tb_s": COPY_RATE_TB_S,
-                                     "note": "19 launches per step, most of them small (8x8 / 16x16 levels: 4-60 MB each, "
-                                             "20-40 us = launch + ramp, not bandwidth); the level-0 ones run at 3.9-4.6 TB/s"}},
+                                     "note": f"{n1 // max(args.steps, 1)} launches per step (the res_conv / Conv_2 launches that do not ride in a "
+                                             "3x3x3 epilogue), most of them small (8x8 / 16x16 levels: 4-60 MB each, 10-30 us = launch + "
+                                             "ramp + a short channel loop, not bandwidth); the two level-0 / level-1 ones, which also "
+                                             "write conv20's prologue output, run at 4.9-5.1 TB/s"}},
         }
         if not args.no_extras:
             line["cond_cached"] = {"value": round(world * args.steps / dt_cached, 4), "unit": "batch32-steps/s",

@@ -1116,7 +1116,9 @@ def test_conv1_small_planes_split_the_channels_over_the_waves(ops, case):
 
 @pytest.mark.parametrize("case", [(16, (32, 32, 32), 32, (8, 64, 32)), (32, (64, 64), 64, (8, 32, 32)), (16, (16, 48), 96, (4, 64, 64)),
                                   (32, (32, 32, 32), 32, (8, 36, 28)),       # a plane that ends inside a 512-position tile
-                                  (40, (64, 64), 64, (4, 44, 36))])
+                                  (40, (64, 64), 64, (4, 44, 36)),
+                                  (32, (256, 256, 256), 128, (8, 8, 8)),     # small grids: the kernel that splits the channels over its waves
+                                  (32, (128, 128, 128), 64, (8, 16, 16)), (3, (64, 64), 32, (4, 14, 20))])
 def test_conv1_writes_the_prologue_of_its_input_on_the_side(ops, case):
     """desc.xp_* (ABI v6): the 1x1x1 bandwidth kernel also writes SiLU(x + shift) of its segmented input -- what a ResBlock's
     conv20 reads of the same concat (reference Hyper_unet_general.py:243-248) -- bit for bit the prologue pass it replaces;
@@ -1149,14 +1151,18 @@ def test_conv1_writes_the_prologue_of_its_input_on_the_side(ops, case):
     side = torch.empty_like(kept)
     ops.conv3d(xs, wp, cout, 1, bias=bias, side_xp=dict(out=side, shift=sh, act=True))
     assert torch.equal(side, kept)
-    # launches the 16-byte kernel does not take are refused (and the rule says so beforehand)
+    # launches neither form of the kernel takes are refused, and the rule says so beforehand: a small grid of fewer than 128 input
+    # channels (the dword kernel without the channel split), a small grid with a prologue of its own
     small = [x[:1, :, :, :8, :8].contiguous() for x in xs]
-    assert not routing.k1_side_xp(1, seg_c, cout, shp[0], 8, 8)
     d = ops.make_conv_desc(small, wp, cout, 1, torch.empty(1, cout, shp[0], 8, 8, device="cuda"),
                            side_xp=dict(out=torch.empty(1, cin, shp[0], 8, 8, device="cuda"), act=True))
-    assert lib.tmdiff_conv3d_fwd_xp_supported(C.byref(d)) == 0
-    with pytest.raises(ValueError):
-        ops.conv3d(small, wp, cout, 1, side_xp=dict(out=torch.empty(1, cin, shp[0], 8, 8, device="cuda"), act=True))
+    assert bool(lib.tmdiff_conv3d_fwd_xp_supported(C.byref(d))) == routing.k1_side_xp(1, seg_c, cout, shp[0], 8, 8) == (cin >= 128)
+    if cin < 128:
+        with pytest.raises(ValueError):
+            ops.conv3d(small, wp, cout, 1, side_xp=dict(out=torch.empty(1, cin, shp[0], 8, 8, device="cuda"), act=True))
+    else:
+        with pytest.raises(ValueError):
+            ops.conv3d(small, wp, cout, 1, in_shift=sh[:1].contiguous(), side_xp=dict(out=torch.empty(1, cin, shp[0], 8, 8, device="cuda"), act=True))
     with pytest.raises(ValueError):
         ops.conv3d(xs, ops.pack_conv_weight(w3), 32, 3, side_xp=dict(out=side, act=True))
 

@@ -55,18 +55,23 @@ __device__ __forceinline__ void xp_store4(xp_rsrc r, unsigned voff, float a, flo
   const u32x4 v = {__float_as_uint(a), __float_as_uint(b), __float_as_uint(c), __float_as_uint(d)};
   __builtin_amdgcn_raw_buffer_store_b128(v, r, voff, 0, 0);
 }
+__device__ __forceinline__ void xp_store1(xp_rsrc r, unsigned voff, float a) { __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(a), r, voff, 0, 0); }
 #else
 struct xp_rsrc {};
 __device__ __forceinline__ xp_rsrc xp_make_rsrc(float*, unsigned) { return {}; }
 __device__ __forceinline__ void xp_store4(xp_rsrc, unsigned, float, float, float, float) {}
+__device__ __forceinline__ void xp_store1(xp_rsrc, unsigned, float) {}
 #endif
 
 // KS = 4 (small planes: the 8x8 / 16x16 levels, whose grids leave most CUs with one workgroup or none and whose waves then walk
 // the whole channel loop one memory round trip at a time -- 768 -> 128 at 8x8x8: 48 round trips, 81 us for 58 MB): the FOUR WAVES of
 // a workgroup share the same NS x 32 positions and take every fourth 16-channel group each; their partial sums meet in LDS (fixed
 // order: wave 0 + 1 + 2 + 3), and wave (s, m) finishes accumulator (s, m).  Four times the workgroups, a quarter of the round trips.
-template <int NS, int MSUB, bool ACT, int KS = 1>
+// XP (with KS = 4 only, where every wave holds other channels of the same positions): the by-product desc.xp_out, as in the 16-byte
+// kernel below.
+template <int NS, int MSUB, bool ACT, int KS = 1, bool XP = false>
 __global__ void __launch_bounds__(256, 2) conv1_fp32_kernel(const K1Args a) {
+  static_assert(!XP || KS == 4, "the by-product: channels split over the waves");
   constexpr int CO = 32 * MSUB;
   const int tid = threadIdx.x, lane = tid & 63, wv = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int l31 = lane & 31, khalf = lane >> 5;
@@ -99,7 +104,9 @@ __global__ void __launch_bounds__(256, 2) conv1_fp32_kernel(const K1Args a) {
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[s][m][r] = 0.f;
 
-  float xr[2][G][NS], wr[2][G][MSUB], shr[2][G], scr[2][G];
+  float xr[2][G][NS], wr[2][G][MSUB], shr[2][G], scr[2][G], xsh[2][G];
+  const bool xp_on = XP && co_tile == 0;
+  const xp_rsrc xpr = xp_make_rsrc(XP ? a.xp_out + (long)b * a.Cin * plane : nullptr, XP ? (unsigned)((long)a.Cin * plane * 4) : 0u);
   auto load_group = [&](int q, int buf) __attribute__((always_inline)) {
     const int cg = g * a.cin_g + q * 2 * G;  // first of 16 channels; they lie in one input segment
     const float* src;
@@ -115,8 +122,12 @@ __global__ void __launch_bounds__(256, 2) conv1_fp32_kernel(const K1Args a) {
     for (int j = 0; j < G; ++j) {
 #pragma unroll
       for (int s = 0; s < NS; ++s) xr[buf][j][s] = base[(unsigned)(2 * j) * (unsigned)plane + chan_off + pos[s]];
-      shr[buf][j] = shp[2 * j + khalf];
-      scr[buf][j] = scp[2 * j + khalf];
+      if constexpr (!XP) {      // (XP: a raw input -- the host's condition -- so no prologue constants of its own to hold)
+        shr[buf][j] = shp[2 * j + khalf];
+        scr[buf][j] = scp[2 * j + khalf];
+      } else {
+        xsh[buf][j] = (xp_on && a.xp_shift) ? a.xp_shift[(long)b * a.xp_shift_stride + cg + 2 * j + khalf] : 0.f;
+      }
       if constexpr (MSUB == 2) {
         const float2 t = *reinterpret_cast<const float2*>(wq + (long)(2 * j) * a.cout_g);
         wr[buf][j][0] = t.x, wr[buf][j][1] = t.y;
@@ -126,14 +137,29 @@ __global__ void __launch_bounds__(256, 2) conv1_fp32_kernel(const K1Args a) {
     }
   };
   auto mfma_group = [&](int buf, int q) __attribute__((always_inline)) {
+    if constexpr (XP) if (xp_on) {     // the by-product: channel g * cin_g + q * 16 + 2 j + khalf at this lane's NS positions
+      const unsigned c0 = (unsigned)(g * a.cin_g + q * 2 * G + khalf) * (unsigned)plane;
+#pragma unroll
+      for (int j = 0; j < G; ++j)
+#pragma unroll
+        for (int s = 0; s < NS; ++s) {
+          const float t = xr[buf][j][s] + xsh[buf][j];
+          const float ta = tmdiff::silu_f(t);
+          xp_store1(xpr, pok[s] ? (c0 + (unsigned)(2 * j) * (unsigned)plane + pos[s]) * 4u : kOutsideXp, a.xp_act ? ta : t);
+        }
+    }
 #pragma unroll
     for (int j = 0; j < G; ++j) {
       float bv[NS];
 #pragma unroll
       for (int s = 0; s < NS; ++s) {
-        float v = xr[buf][j][s] + shr[buf][j];
-        if constexpr (ACT) v = tmdiff::silu_f(v);
-        bv[s] = v * scr[buf][j];
+        if constexpr (XP) {
+          bv[s] = xr[buf][j][s];
+        } else {
+          float v = xr[buf][j][s] + shr[buf][j];
+          if constexpr (ACT) v = tmdiff::silu_f(v);
+          bv[s] = v * scr[buf][j];
+        }
       }
 #pragma unroll
       for (int s = 0; s < NS; ++s)
@@ -357,7 +383,16 @@ int launch(K1Args& a, int in_act, hipStream_t st) {
   a.tiles_co = a.cout_g / (32 * MSUB);
   const long blocks = (long)a.B * a.groups * a.ptiles * a.tiles_co;
   if (blocks <= 0 || blocks > 0x7fffffffL) return tmdiff::fail(TMDIFF_E_INVALID, "conv1: grid of %ld blocks", blocks);
-  if (a.xp_out) return tmdiff::fail(TMDIFF_E_UNSUPPORTED, "conv1: xp_out needs the 16-byte kernel (plane %% 4 == 0, aligned tensors, >= 512 tiles)");
+  if (a.xp_out) {
+    if constexpr (KS == 4) {
+      if (in_act || a.in_shift || a.in_scale) return tmdiff::fail(TMDIFF_E_UNSUPPORTED, "conv1: xp_out on a small grid goes with a raw input (no prologue of its own)");
+      if ((long)a.Cin * a.plane >= (1L << 30)) return tmdiff::fail(TMDIFF_E_UNSUPPORTED, "conv1: xp_out sample too large for 32-bit byte offsets");
+      conv1_fp32_kernel<NS, MSUB, false, 4, true><<<(unsigned)blocks, 256, 0, st>>>(a);
+      return tmdiff::check_launch("conv3d_fwd (1x1x1 bandwidth kernel, channels over the waves + x')");
+    } else {
+      return tmdiff::fail(TMDIFF_E_UNSUPPORTED, "conv1: xp_out needs the 16-byte kernel or the small-grid kernel");
+    }
+  }
   if (in_act) conv1_fp32_kernel<NS, MSUB, true, KS><<<(unsigned)blocks, 256, 0, st>>>(a);
   else conv1_fp32_kernel<NS, MSUB, false, KS><<<(unsigned)blocks, 256, 0, st>>>(a);
   return tmdiff::check_launch("conv3d_fwd (1x1x1 bandwidth kernel)");
@@ -396,8 +431,6 @@ int tmdiff::conv1_fp32_try(const tmdiff_conv3d_desc* d, hipStream_t st, bool dry
   bool vec = plane % 4 == 0 && (blocks_vec >= 512 || force_vec) && aligned16(d->y) && aligned16(d->residual) && aligned16(d->xp_out);
   for (int i = 0; i < d->nseg; ++i) vec = vec && aligned16(d->seg_x[i]);
   static const bool no_vec = getenv("TMDIFF_CONV1_DWORD") != nullptr;      // experiments: the dword kernel everywhere
-  if (dry) return (vec && !no_vec && !d->in_act && (long)d->Cin * plane < (1L << 30)) ? TMDIFF_OK : TMDIFF_E_UNSUPPORTED;    // (xp_supported: the 16-byte kernel, raw input)
-  if (vec && !no_vec) return cout_g % 64 == 0 ? launch_vec<2>(a, d->in_act, st) : launch_vec<1>(a, d->in_act, st);
   // small grids (fewer than two workgroups per CU of 256-position tiles) with at least 8 channel groups: the four waves of a
   // workgroup split the channels (KS = 4).  TMDIFF_CONV1_KSPLIT=0: never (experiments; tests force either form).
   static const int ksplit_mode = [] {
@@ -406,6 +439,9 @@ int tmdiff::conv1_fp32_try(const tmdiff_conv3d_desc* d, hipStream_t st, bool dry
   }();
   const long blocks_dword = (long)d->B * d->groups * ((plane + 255) / 256) * (cout_g % 64 == 0 ? cout_g / 64 : cout_g / 32);
   const bool ks = ksplit_mode != 0 && cin_g / (2 * G) >= 8 && (ksplit_mode == 1 || blocks_dword < 512);
+  // (xp_supported: a raw input on the 16-byte kernel or on the small-grid kernel)
+  if (dry) return (((vec && !no_vec) || (ks && !d->in_shift && !d->in_scale)) && !d->in_act && (long)d->Cin * plane < (1L << 30)) ? TMDIFF_OK : TMDIFF_E_UNSUPPORTED;
+  if (vec && !no_vec) return cout_g % 64 == 0 ? launch_vec<2>(a, d->in_act, st) : launch_vec<1>(a, d->in_act, st);
   if (cout_g % 64 == 0) return ks ? launch<2, 2, 4>(a, d->in_act, st) : launch<2, 2>(a, d->in_act, st);
   return ks ? launch<2, 1, 4>(a, d->in_act, st) : launch<2, 1>(a, d->in_act, st);
 }

@@ -582,8 +582,11 @@ def conv3d(segs, w_packed, cout, ksize, out=None, math="fp32", pack_input=None, 
     # algorithmic HBM bytes of the launch: input once (2 B per element for packed bf16 units, else 4), outputs once
     in_b = 2.0 if d.x_bf16 else 4.0
     y2_b = 0.0 if y2 is None else (2.0 if d.y2_bf16 else 4.0)
-    nbytes = b * n * h * w * (in_b * d.Cin + cout * (4.0 * ((1 if y is not None else 0) + (1 if kw.get("residual") is not None else 0)) + y2_b))
-    TIMER.records.append((e0, e1, 2.0 * b * cout * (d.Cin // d.groups) * ksize ** 3 * n * h * w, ksize, what, _tag(d), nbytes))
+    # (+ the by-product x' of a side_xp launch: Cin more channels written)
+    nbytes = b * n * h * w * (in_b * d.Cin + cout * (4.0 * ((1 if y is not None else 0) + (1 if kw.get("residual") is not None else 0)) + y2_b) +
+                              (4.0 * d.Cin if d.xp_out else 0.0))
+    TIMER.records.append((e0, e1, 2.0 * b * cout * (d.Cin // d.groups) * ksize ** 3 * n * h * w, ksize, what,
+                          _tag(d) + (" +xp" if d.xp_out else ""), nbytes))
     return ret
 
 

@@ -136,16 +136,19 @@ def direct_family(cin, cout, groups=1, plain=True, masked=False, dropout=False, 
 
 
 def k1_side_xp(b, seg_c, cout, n, h, w, groups=1):
-    """True when a 1x1x1 convolution of the segments seg_c (channels each) runs on the 16-byte bandwidth kernel, which can also
+    """True when a 1x1x1 convolution of the segments seg_c (channels each) runs on a form of the bandwidth kernel that can also
     write the prologue output of its input (make_conv_desc side_xp=; csrc/conv1.hip conv1_fp32_try): segments and Cin / groups
-    of multiples of 16 channels, Cout / groups % 32 == 0, planes of multiples of 4 positions, at least 512 tiles (contiguous
-    torch tensors are 16-byte aligned).  tmdiff_conv3d_fwd_xp_supported is the library's own answer for a filled descriptor."""
+    of multiples of 16 channels, Cout / groups % 32 == 0, planes of multiples of 4 positions, and either at least 512 tiles of
+    512 positions (the 16-byte kernel) or a small grid of at least 128 input channels per group (the kernel that splits the
+    channels over its waves); contiguous torch tensors are 16-byte aligned.  tmdiff_conv3d_fwd_xp_supported is the library's own answer for a filled descriptor."""
     cin, plane = sum(seg_c), n * h * w
     if cin % groups or cout % groups or any(c % 16 for c in seg_c) or (cin // groups) % 16 or (cout // groups) % 32 or plane % 4:
         return False
     cout_g = cout // groups
-    tiles = b * groups * ((plane + 511) // 512) * (cout_g // 64 if cout_g % 64 == 0 else cout_g // 32)
-    return tiles >= 512 and plane * 16 < (1 << 31) and cin * plane < (1 << 30)
+    co_tiles = cout_g // 64 if cout_g % 64 == 0 else cout_g // 32
+    vec = b * groups * ((plane + 511) // 512) * co_tiles >= 512                                   # the 16-byte kernel
+    small = b * groups * ((plane + 255) // 256) * co_tiles < 512 and (cin // groups) // 16 >= 8    # channels over the waves
+    return (vec or small) and plane * 16 < (1 << 31) and cin * plane < (1 << 30)
 
 
 def ll_family(b, cin, cout, n, h, w, producer_s2d=True):
