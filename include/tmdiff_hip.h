@@ -130,8 +130,11 @@ typedef struct tmdiff_conv3d_desc {
    * receives act(x + xp_shift[b, c]) of every element of the (possibly segmented) input -- the prologue output that ANOTHER
    * convolution of the same input wants (a ResBlock's conv20 beside its res_conv, Hyper_unet_general.py:243-248: both read the
    * concatenated block input, one raw, one through SiLU(x + Dense(e))), written by the kernel that loads every element anyway.
-   * xp_shift: [B, Cin] (row stride xp_shift_stride as in_shift_stride) or NULL; xp_act != 0: SiLU.  Shapes the bandwidth kernel
-   * does not take: TMDIFF_E_UNSUPPORTED. */
+   * xp_shift: [B, Cin] (row stride xp_shift_stride as in_shift_stride) or NULL; xp_act != 0: SiLU.  Taken by the 16-byte form of
+   * the kernel (planes of multiples of 4 positions, 16-byte aligned tensors, at least 512 tiles of 512 positions; any prologue of
+   * its own except an activation) and by the small-grid form (fewer than 512 tiles of 256 positions, at least 128 input channels
+   * per group, a raw input: no in_shift / in_scale / in_act); a sample of fewer than 2^30 elements.  tmdiff_conv3d_fwd_xp_supported()
+   * answers for a descriptor; any other launch: TMDIFF_E_UNSUPPORTED. */
   float* xp_out;
   const float* xp_shift;
   int32_t xp_shift_stride, xp_act;
