@@ -846,7 +846,9 @@ class WavBEST(nn.Module):
             parts = A.split_cols(out, [l.out_features for _, l in layers])
             return {n_: p for (n_, _), p in zip(layers, parts)}
 
-        shifts, scales = bank(temb, shift_layers), bank(pemb, scale_layers)
+        # (the prompt embedding is one row for the whole batch: expanded HERE, so that every scale block is a [B, C] table and the
+        #  gradient's sum over the batch happens once, in this expand's backward, not once per convolution)
+        shifts, scales = bank(temb, shift_layers), bank(pemb.expand(temb.shape[0], -1) if pemb.shape[0] == 1 else pemb, scale_layers)
         sh = lambda name: shifts.get(name)          # flag=True blocks have no shift entry (and ignore it)
 
         def resblock(name, segs):

@@ -35,6 +35,16 @@ def _wf_weights(w, groups, mode):
     return ops.pack_conv_weight_wino(w, groups, mode=mode, planes=6)
 
 
+def _rows(t, what):
+    """make_conv_desc arguments for a per-(sample, channel) prologue table [B, C] that may be a column block of a projection
+    bank (rows `stride(0)` floats apart, as _SplitCols hands them out): pointer + row stride, no contiguous copy."""
+    if t is None:
+        return {}
+    if not (t.is_cuda and t.dtype == torch.float32 and t.dim() == 2 and t.stride(1) == 1 and t.stride(0) >= t.shape[1]):
+        raise ValueError(f"{what}: need a float32 [B, C] tensor on the GPU with unit column stride")
+    return {"in_" + what: t.data_ptr(), what + "_stride": t.stride(0)}
+
+
 class _FusedConv3d(torch.autograd.Function):
     """y = (conv3d(act(cat(segs) + shift) * scale * mask, w) + bias_scale*bias + residual) * out_scale"""
 
@@ -58,8 +68,8 @@ class _FusedConv3d(torch.autograd.Function):
             cin = sum(s.shape[1] for s in segs)
             if cin % groups == 0 and (cin // groups) % 4 == 0 and (cout // groups) % 32 == 0:   # shapes the staged kernel takes
                 xp = torch.empty(b, cin, n, h, wd, device=segs[0].device, dtype=torch.float32)
-        kw = dict(bias=bias, bias_scale=bias_scale, in_shift=shift, in_scale=scale, in_act=act, in_mask=mask, drop=drop,
-                  residual=residual, out_scale=out_scale, xp_out=xp)
+        kw = dict(bias=bias, bias_scale=bias_scale, in_act=act, in_mask=mask, drop=drop, residual=residual, out_scale=out_scale,
+                  xp_out=xp, **_rows(shift, "shift"), **_rows(scale, "scale"))
         cin = sum(s.shape[1] for s in segs)
         # 3x3x3 convolutions (in-kernel dropout included): the family tmdiff_amd.routing picks -- Winograd along the bands where
         # its grid fills the chip (conv3d_wf's prologue pass writes x' where the weight gradient will read it), else direct
@@ -100,8 +110,8 @@ class _FusedConv3d(torch.autograd.Function):
         d_res = g if (has_res and need[5]) else None
         # descriptor of the forward prologue (what x' was): used by wgrad and by the prologue backward
         dummy = torch.empty(b, cout, n, h, wd, device=g.device, dtype=torch.float32) if False else g
-        desc = ops.make_conv_desc(segs, 0, cout, ksize, dummy, groups=groups, in_shift=shift, in_scale=scale,
-                                  in_act=act, in_mask=mask, drop=ctx.drop)
+        desc = ops.make_conv_desc(segs, 0, cout, ksize, dummy, groups=groups, in_act=act, in_mask=mask, drop=ctx.drop,
+                                  **_rows(shift, "shift"), **_rows(scale, "scale"))
         if need[1]:   # x' kept by the forward: a plain single-tensor input, no prologue pass inside the weight gradient
             desc_w = ops.make_conv_desc([xp], 0, cout, ksize, dummy, groups=groups) if xp is not None else desc
             if has_bias and need[2] and (ops.config.wgrad_bias or (ops.config.wgrad_wino_bias and ops.wgrad_wino_takes(desc_w))):   # the bias gradient rides along in the weight-gradient kernel
@@ -136,7 +146,14 @@ def conv3d(segs, weight, bias=None, bias_scale=1.0, shift=None, scale=None, act=
            groups=1, out_scale=1.0):
     """Differentiable fused convolution; shift / scale are dense [B, Cin] tensors."""
     b = segs[0].shape[0]
-    fix = lambda t: None if t is None else (t.expand(b, t.shape[1]) if t.shape[0] != b else t).contiguous()
+    # (a column block of a projection bank stays the view it is: the kernels take a row stride; only a table that is not [B, C]
+    #  with unit column stride -- one row broadcast over the batch -- is materialised)
+    def fix(t):
+        if t is None:
+            return None
+        if t.shape[0] != b:
+            t = t.expand(b, t.shape[1])
+        return t if (t.dim() == 2 and t.stride(1) == 1 and t.stride(0) >= t.shape[1]) else t.contiguous()
     return _FusedConv3d.apply((bool(act), int(groups), float(bias_scale), float(out_scale)), weight, bias, fix(shift),
                               fix(scale), residual, mask, *segs)
 
@@ -318,14 +335,14 @@ def linear(x, weight, bias=None, act=False):
 
 
 class _SplitCols(torch.autograd.Function):
-    """[B, sum(sizes)] -> contiguous [B, size_k] blocks.  Plain slicing would do, but its backward builds a zero-filled
+    """[B, sum(sizes)] -> the [B, size_k] column blocks (views).  Plain slicing would do, but its backward builds a zero-filled
     full-width tensor per slice and adds them up (three tiny kernels per Dense() projection, ~180 launches per training
     step for the two projection banks); here the backward is one concatenation."""
 
     @staticmethod
     def forward(ctx, out, sizes):
         ctx.sizes = sizes
-        return tuple(t.contiguous() for t in torch.split(out, sizes, dim=1))
+        return torch.split(out, sizes, dim=1)       # views: their consumers take a row stride (autograd._rows)
 
     @staticmethod
     def backward(ctx, *grads):
