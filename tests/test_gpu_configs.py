@@ -60,6 +60,44 @@ def test_config2_batch32_full_width(golden):
     assert_close(y32[12:16], y4, 1e-5, 1e-5, "rows 12..15 of a batch of 32 vs a batch of 4")
 
 
+@pytest.mark.parametrize("switch,what", [
+    ("fuse_res_conv", "k1"),        # res_conv / Conv_2 folded into the consumer's epilogue: fewer 1x1x1 launches
+    ("emit_ll", "dwt"),             # the ResBlock in front of a down block writes LL(y) / 2: no LL-only Haar pass
+    ("emit_dwt", "dwt"),            # Conv_0 of the condition branch's down blocks writes the Haar transform: no DWT pass
+    ("side_xp", "prologue"),        # res_conv also writes conv20's prologue output: no prologue pass
+])
+def test_config2_batch32_epilogue_fusions_switched_off(switch, what):
+    """Every host-side fusion of the round-4 inference graph (ops.config: fuse_res_conv, emit_ll, emit_dwt, side_xp) replaces
+    launches, never an operator's result: the batch-32 forward of the benchmark workload with one of them switched off equals the
+    default graph's (another summation order where a folded convolution is involved: 1e-5); the folded 1x1x1 convolutions are
+    launches of their own again, the other switches leave the convolution launches as they are (ops.COUNTS)."""
+    import collections
+    from tmdiff_amd import ops
+    net = _hip_net(FULL)
+    d = {k: cu(v) for k, v in case_inputs(23, 32, 8, 64).items()}
+    t = torch.arange(1, 33, dtype=torch.float32).reshape(32, 1).cuda() * 29
+
+    def run():
+        ops.COUNTS = collections.Counter()
+        try:
+            with torch.no_grad():
+                y = net(d["x_t"], t, d["PAN"], d["MS"], "WV3")
+            return y, ops.COUNTS
+        finally:
+            ops.COUNTS = None
+
+    y_on, c_on = run()
+    with ops.config.override(**{switch: False}):
+        y_off, c_off = run()
+    assert_close(y_off, y_on, 1e-5, 2e-6, f"{switch} off vs on")
+    k1 = lambda c: sum(v for k, v in c.items() if k.endswith("_k1"))
+    print(switch, "on:", dict(c_on), "off:", dict(c_off))
+    if what == "k1":        # the folded convolutions are launches of their own again
+        assert k1(c_off) > k1(c_on)
+    else:                   # (the Haar / prologue passes these switches remove are not convolution launches: the same convolutions run)
+        assert c_off == c_on
+
+
 # ---- configs[2]: the WorldView-3 network of config/general.json ---------------------------------------------------------
 @pytest.fixture(scope="module")
 def wide_net():
