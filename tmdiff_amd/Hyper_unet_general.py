@@ -134,8 +134,12 @@ class ResBlockModulateBEST(nn.Module):
         b, _, n, h, w = segs[0].shape
         cin = sum(s.shape[1] for s in segs)
         dev = segs[0].device
-        t1 = A.conv3d(segs, self.conv20.weight, self.conv20.bias, shift=None if self.flag else shift, act=True,
-                      mask=_drop_mask(self, (b, cin, n, h, w), self.dropout.p, dev))
+        m20 = _drop_mask(self, (b, cin, n, h, w), self.dropout.p, dev)
+        if isinstance(self.res_conv, nn.Conv3d) and ops.config.train_fused_resblock:      # one autograd node: the two gradients of every input segment meet in a kernel
+            m21 = _drop_mask(self, (b, self.conv20.out_channels, n, h, w), self.dropout.p, dev)
+            return A.resblock_rc(segs, self.conv20.weight, self.conv20.bias, self.conv21.weight, self.res_conv.weight,
+                                 self.res_conv.bias, None if self.flag else shift, scale, m20, m21)
+        t1 = A.conv3d(segs, self.conv20.weight, self.conv20.bias, shift=None if self.flag else shift, act=True, mask=m20)
         res = A.conv3d(segs, self.res_conv.weight, self.res_conv.bias) if isinstance(self.res_conv, nn.Conv3d) else segs[0]
         return A.conv3d([t1], self.conv21.weight, None, scale=scale, act=True,
                         mask=_drop_mask(self, t1.shape, self.dropout.p, dev), residual=res)

@@ -45,115 +45,196 @@ def _rows(t, what):
     return {"in_" + what: t.data_ptr(), what + "_stride": t.stride(0)}
 
 
+def _conv_forward(meta, weight, bias, shift, scale, residual, mask, segs, need_w):
+    """y = (conv3d(act(cat(segs) + shift) * scale * mask, w) + bias_scale*bias + residual) * out_scale, and what its backward needs:
+    (y, state) with state = dict(meta, drop, w, shift, scale, mask, xp, segs, wp_dgrad, has_bias, has_res)."""
+    act, groups, bias_scale, out_scale = meta
+    segs = [s.contiguous() for s in segs]
+    w = weight.contiguous()
+    cout, ksize = w.shape[0], w.shape[2]
+    pre = ops.PACKED.lookup(w) if ops.PACKED is not None else None     # packed once per step for the whole network
+    wp = pre[0] if pre is not None else ops.pack_conv_weight(w, groups=groups, mode=0)
+    # mask: None, a tensor (caller-supplied dropout mask, parity runs) or a DropSpec (seed, p): in-kernel dropout
+    drop = mask if isinstance(mask, DropSpec) else None
+    mask = None if drop is not None else mask
+    # a 3x3x3 convolution with dropout runs as prologue pass + staged kernel anyway: let the pass write x' into a
+    # tensor of its own and keep it -- the weight gradient then needs no prologue pass of its own
+    xp = None
+    if ksize == 3 and (drop is not None or mask is not None) and need_w:
+        b, _, n, h, wd = segs[0].shape
+        cin = sum(s.shape[1] for s in segs)
+        if cin % groups == 0 and (cin // groups) % 4 == 0 and (cout // groups) % 32 == 0:   # shapes the staged kernel takes
+            xp = torch.empty(b, cin, n, h, wd, device=segs[0].device, dtype=torch.float32)
+    kw = dict(bias=bias, bias_scale=bias_scale, in_act=act, in_mask=mask, drop=drop, residual=residual, out_scale=out_scale,
+              xp_out=xp, **_rows(shift, "shift"), **_rows(scale, "scale"))
+    cin = sum(s.shape[1] for s in segs)
+    # 3x3x3 convolutions (in-kernel dropout included): the family tmdiff_amd.routing picks -- Winograd along the bands where
+    # its grid fills the chip (conv3d_wf's prologue pass writes x' where the weight gradient will read it), else direct
+    if ksize == 3:
+        wino_ok = ops.config.winograd and ops.wino_conv_supported(cout, cin, ksize, groups)
+        weights = ops.ConvWeights(lambda: wp, (lambda: _wf_weights(w, groups, 2)) if wino_ok else None,
+                                  (lambda planes: ops.pack_conv_weight_wino(w, groups, planes=planes)) if wino_ok else None)
+        y = ops.conv3d_auto(segs, weights, cout, groups=groups, **kw)
+    else:
+        y = ops.conv3d(segs, wp, cout, ksize, groups=groups, **kw)
+    state = dict(meta=meta, drop=drop, w=w, shift=shift, scale=scale, mask=mask, xp=xp, segs=segs,
+                 wp_dgrad=pre[1] if pre is not None else None, has_bias=bias is not None, has_res=residual is not None)
+    return y, state
+
+
+def _conv_backward(st, gy, need_w, need_b, need_shift, need_scale, need_res, need_segs, outs=None, accumulate=None):
+    """Gradients of _conv_forward: (d_w, d_bias, d_shift, d_scale, d_res, d_segs).  outs / accumulate: tensors the input
+    gradients are ADDED to instead of fresh ones (the other consumer's gradient of the same segments: no sum pass afterwards)."""
+    act, groups, bias_scale, out_scale = st["meta"]
+    w, shift, scale, mask, xp, segs = st["w"], st["shift"], st["scale"], st["mask"], st["xp"], st["segs"]
+    has_bias, has_shift, has_scale = st["has_bias"], shift is not None, scale is not None
+    g = gy.contiguous()
+    if out_scale != 1.0:
+        g = ops.axpby([g], [out_scale])
+    cout, cin_g, ksize = w.shape[0], w.shape[1], w.shape[2]
+    cin = cin_g * groups
+    d_bias = None
+    d_res = g if (st["has_res"] and need_res) else None
+    # descriptor of the forward prologue (what x' was): used by wgrad and by the prologue backward
+    desc = ops.make_conv_desc(segs, 0, cout, ksize, g, groups=groups, in_act=act, in_mask=mask, drop=st["drop"],
+                              **_rows(shift, "shift"), **_rows(scale, "scale"))
+    if need_w:   # x' kept by the forward: a plain single-tensor input, no prologue pass inside the weight gradient
+        desc_w = ops.make_conv_desc([xp], 0, cout, ksize, g, groups=groups) if xp is not None else desc
+        if has_bias and need_b and (ops.config.wgrad_bias or (ops.config.wgrad_wino_bias and ops.wgrad_wino_takes(desc_w))):   # the bias gradient rides along in the weight-gradient kernel
+            desc_w.bias_scale = bias_scale
+            d_w, d_bias = ops.conv3d_wgrad(desc_w, g, tuple(w.shape), want_bias=True)
+        else:
+            d_w = ops.conv3d_wgrad(desc_w, g, tuple(w.shape))
+    else:
+        d_w = None
+    if has_bias and need_b and d_bias is None:
+        d_bias = ops.channel_sum(g, bias_scale)
+    need_x = any(need_segs) or (has_shift and need_shift) or (has_scale and need_scale)
+    d_shift = d_scale = None
+    d_segs = [None] * len(segs)
+    if need_x:
+        wp_t = st["wp_dgrad"] if st["wp_dgrad"] is not None else ops.pack_conv_weight(w, groups=groups, mode=1)
+        if ksize == 3:     # the data gradient is a 3x3x3 convolution too (a plain input: no pass at all)
+            wino_ok = ops.config.winograd and ops.wino_conv_supported(cin, cout, ksize, groups)
+            weights = ops.ConvWeights(lambda: wp_t, (lambda: _wf_weights(w, groups, 3)) if wino_ok else None,
+                                      (lambda planes: ops.pack_conv_weight_wino(w, groups, mode=1, planes=planes)) if wino_ok else None)
+            gp = ops.conv3d_auto([g], weights, cin, groups=groups)                # dL/dx'
+        else:
+            gp = ops.conv3d([g], wp_t, cin, ksize, groups=groups)
+        plain = not (act or has_shift or has_scale or mask is not None or st["drop"] is not None)
+        if plain and len(segs) == 1 and outs is None:      # x' IS x: dL/dx' is the input gradient (no pass to copy it)
+            return d_w, d_bias, None, None, d_res, [gp]
+        if outs is None:
+            outs = [torch.empty_like(s_) if need_segs[i] else None for i, s_ in enumerate(segs)]
+            accumulate = [False] * len(segs)
+        d_shift, d_scale = ops.conv3d_prologue_bwd(desc, gp, outs, accumulate, has_shift and need_shift, has_scale and need_scale)
+        d_segs = outs
+    return d_w, d_bias, d_shift, d_scale, d_res, d_segs
+
+
+_STATE_TENSORS = ("w", "shift", "scale", "mask", "xp")
+
+
+def _stash(ctx, prefix, st, tensors):
+    """Move a _conv_forward state's tensors into the list save_for_backward will get; the rest stays on ctx."""
+    idx = {}
+    for k in _STATE_TENSORS:
+        if st[k] is not None:
+            idx[k] = len(tensors)
+            tensors.append(st[k])
+    idx["segs"] = [len(tensors) + i for i in range(len(st["segs"]))]
+    tensors.extend(st["segs"])
+    setattr(ctx, prefix, (idx, {k: v for k, v in st.items() if k not in _STATE_TENSORS and k != "segs"}))
+
+
+def _unstash(ctx, prefix, saved):
+    idx, rest = getattr(ctx, prefix)
+    st = dict(rest)
+    for k in _STATE_TENSORS:
+        st[k] = saved[idx[k]] if k in idx else None
+    st["segs"] = [saved[i] for i in idx["segs"]]
+    return st
+
+
 class _FusedConv3d(torch.autograd.Function):
     """y = (conv3d(act(cat(segs) + shift) * scale * mask, w) + bias_scale*bias + residual) * out_scale"""
 
     @staticmethod
     def forward(ctx, meta, weight, bias, shift, scale, residual, mask, *segs):
-        act, groups, bias_scale, out_scale = meta
-        segs = [s.contiguous() for s in segs]
-        w = weight.contiguous()
-        cout, ksize = w.shape[0], w.shape[2]
-        pre = ops.PACKED.lookup(w) if ops.PACKED is not None else None     # packed once per step for the whole network
-        wp = pre[0] if pre is not None else ops.pack_conv_weight(w, groups=groups, mode=0)
-        ctx.wp_dgrad = pre[1] if pre is not None else None
-        # mask: None, a tensor (caller-supplied dropout mask, parity runs) or a DropSpec (seed, p): in-kernel dropout
-        drop = mask if isinstance(mask, DropSpec) else None
-        mask = None if drop is not None else mask
-        # a 3x3x3 convolution with dropout runs as prologue pass + staged kernel anyway: let the pass write x' into a
-        # tensor of its own and keep it -- the weight gradient then needs no prologue pass of its own
-        xp = None
-        if ksize == 3 and (drop is not None or mask is not None) and ctx.needs_input_grad[1]:
-            b, _, n, h, wd = segs[0].shape
-            cin = sum(s.shape[1] for s in segs)
-            if cin % groups == 0 and (cin // groups) % 4 == 0 and (cout // groups) % 32 == 0:   # shapes the staged kernel takes
-                xp = torch.empty(b, cin, n, h, wd, device=segs[0].device, dtype=torch.float32)
-        kw = dict(bias=bias, bias_scale=bias_scale, in_act=act, in_mask=mask, drop=drop, residual=residual, out_scale=out_scale,
-                  xp_out=xp, **_rows(shift, "shift"), **_rows(scale, "scale"))
-        cin = sum(s.shape[1] for s in segs)
-        # 3x3x3 convolutions (in-kernel dropout included): the family tmdiff_amd.routing picks -- Winograd along the bands where
-        # its grid fills the chip (conv3d_wf's prologue pass writes x' where the weight gradient will read it), else direct
-        if ksize == 3:
-            wino_ok = ops.config.winograd and ops.wino_conv_supported(cout, cin, ksize, groups)
-            weights = ops.ConvWeights(lambda: wp, (lambda: _wf_weights(w, groups, 2)) if wino_ok else None,
-                                      (lambda planes: ops.pack_conv_weight_wino(w, groups, planes=planes)) if wino_ok else None)
-            y = ops.conv3d_auto(segs, weights, cout, groups=groups, **kw)
-        else:
-            y = ops.conv3d(segs, wp, cout, ksize, groups=groups, **kw)
-        ctx.meta = meta
-        ctx.nseg = len(segs)
-        ctx.drop = drop
-        ctx.has = (bias is not None, shift is not None, scale is not None, residual is not None, mask is not None,
-                   xp is not None)
-        ctx.save_for_backward(w, *(t for t in (shift, scale, mask, xp) if t is not None), *segs)
+        y, st = _conv_forward(meta, weight, bias, shift, scale, residual, mask, segs, ctx.needs_input_grad[1])
+        tensors = []
+        _stash(ctx, "st", st, tensors)
+        ctx.save_for_backward(*tensors)
         return y
 
     @staticmethod
     def backward(ctx, gy):
-        act, groups, bias_scale, out_scale = ctx.meta
-        has_bias, has_shift, has_scale, has_res, has_mask, has_xp = ctx.has
-        saved = list(ctx.saved_tensors)
-        w = saved.pop(0)
-        shift = saved.pop(0) if has_shift else None
-        scale = saved.pop(0) if has_scale else None
-        mask = saved.pop(0) if has_mask else None
-        xp = saved.pop(0) if has_xp else None
-        segs = saved
+        st = _unstash(ctx, "st", ctx.saved_tensors)
         need = ctx.needs_input_grad  # (meta, weight, bias, shift, scale, residual, mask, *segs)
-        g = gy.contiguous()
-        if out_scale != 1.0:
-            g = ops.axpby([g], [out_scale])
-        cout, cin_g, ksize = w.shape[0], w.shape[1], w.shape[2]
-        cin = cin_g * groups
-        b, _, n, h, wd = segs[0].shape
-        d_bias = None
-        d_res = g if (has_res and need[5]) else None
-        # descriptor of the forward prologue (what x' was): used by wgrad and by the prologue backward
-        dummy = torch.empty(b, cout, n, h, wd, device=g.device, dtype=torch.float32) if False else g
-        desc = ops.make_conv_desc(segs, 0, cout, ksize, dummy, groups=groups, in_act=act, in_mask=mask, drop=ctx.drop,
-                                  **_rows(shift, "shift"), **_rows(scale, "scale"))
-        if need[1]:   # x' kept by the forward: a plain single-tensor input, no prologue pass inside the weight gradient
-            desc_w = ops.make_conv_desc([xp], 0, cout, ksize, dummy, groups=groups) if xp is not None else desc
-            if has_bias and need[2] and (ops.config.wgrad_bias or (ops.config.wgrad_wino_bias and ops.wgrad_wino_takes(desc_w))):   # the bias gradient rides along in the weight-gradient kernel
-                desc_w.bias_scale = bias_scale
-                d_w, d_bias = ops.conv3d_wgrad(desc_w, g, tuple(w.shape), want_bias=True)
-            else:
-                d_w = ops.conv3d_wgrad(desc_w, g, tuple(w.shape))
-        else:
-            d_w = None
-        if has_bias and need[2] and d_bias is None:
-            d_bias = ops.channel_sum(g, bias_scale)
-        need_x = any(need[7:]) or (has_shift and need[3]) or (has_scale and need[4])
-        d_shift = d_scale = None
-        d_segs = [None] * len(segs)
-        if need_x:
-            wp_t = ctx.wp_dgrad if ctx.wp_dgrad is not None else ops.pack_conv_weight(w, groups=groups, mode=1)
-            if ksize == 3:     # the data gradient is a 3x3x3 convolution too (a plain input: no pass at all)
-                wino_ok = ops.config.winograd and ops.wino_conv_supported(cin, cout, ksize, groups)
-                weights = ops.ConvWeights(lambda: wp_t, (lambda: _wf_weights(w, groups, 3)) if wino_ok else None,
-                                          (lambda planes: ops.pack_conv_weight_wino(w, groups, mode=1, planes=planes)) if wino_ok else None)
-                gp = ops.conv3d_auto([g], weights, cin, groups=groups)                # dL/dx'
-            else:
-                gp = ops.conv3d([g], wp_t, cin, ksize, groups=groups)
-            outs = [torch.empty_like(s) if need[7 + i] else None for i, s in enumerate(segs)]
-            d_shift, d_scale = ops.conv3d_prologue_bwd(desc, gp, outs, [False] * len(segs),
-                                                       has_shift and need[3], has_scale and need[4])
-            d_segs = outs
+        d_w, d_bias, d_shift, d_scale, d_res, d_segs = _conv_backward(st, gy, need[1], need[2], need[3], need[4], need[5], need[7:])
         return (None, d_w, d_bias, d_shift, d_scale, d_res, None, *d_segs)
+
+
+class _ResBlockRC(torch.autograd.Function):
+    """ResBlockModulateBEST with a res_conv (reference Hyper_unet_general.py:237-249) as ONE node:
+    y = conv21(act(t1) * scale * mask21) + res_conv(x), t1 = conv20(act(x + shift) * mask20) + b20.  Same launches as the three
+    _FusedConv3d nodes it replaces, except in the backward: every input segment has two consumers (conv20 and res_conv), and
+    autograd would sum their two gradients with a launch per segment -- here conv20's prologue backward ADDS into the tensors
+    res_conv's data gradient has just written (fresh tensors that nothing else holds)."""
+
+    @staticmethod
+    def forward(ctx, metas, w20, b20, w21, wrc, brc, shift, scale, mask20, mask21, *segs):
+        m20, m21, mrc = metas
+        need = ctx.needs_input_grad
+        t1, s20 = _conv_forward(m20, w20, b20, shift, None, None, mask20, segs, need[1])
+        res, src = _conv_forward(mrc, wrc, brc, None, None, None, None, segs, need[4])
+        y, s21 = _conv_forward(m21, w21, None, None, scale, res, mask21, [t1], need[3])
+        tensors = []
+        for prefix, st in (("s20", s20), ("src", src), ("s21", s21)):
+            _stash(ctx, prefix, st, tensors)
+        ctx.save_for_backward(*tensors)
+        return y
+
+    @staticmethod
+    def backward(ctx, gy):
+        saved = ctx.saved_tensors
+        s20, src, s21 = (_unstash(ctx, k, saved) for k in ("s20", "src", "s21"))
+        need = ctx.needs_input_grad  # (metas, w20, b20, w21, wrc, brc, shift, scale, mask20, mask21, *segs)
+        need_segs = list(need[10:])
+        any_x = any(need_segs) or need[6]
+        d_w21, _, _, d_scale, d_res, (d_t1,) = _conv_backward(s21, gy, need[3], False, False, need[7], True, [True])
+        d_wrc, d_brc, _, _, _, d_segs = _conv_backward(src, d_res, need[4], need[5], False, False, False, need_segs)
+        if all(need_segs):      # conv20's input gradients are added to res_conv's (no sum pass)
+            d_w20, d_b20, d_shift, _, _, d_segs = _conv_backward(s20, d_t1, need[1], need[2], need[6], False, False, need_segs,
+                                                                 outs=d_segs, accumulate=[True] * len(d_segs))
+        else:
+            d_w20, d_b20, d_shift, _, _, d2 = _conv_backward(s20, d_t1, need[1], need[2], need[6], False, False, need_segs)
+            d_segs = [a if b_ is None else (b_ if a is None else a + b_) for a, b_ in zip(d_segs, d2)] if any_x else d_segs
+        return (None, d_w20, d_b20, d_w21, d_wrc, d_brc, d_shift, d_scale, None, None, *d_segs)
+
+
+def resblock_rc(segs, w20, b20, w21, wrc, brc, shift, scale, mask20, mask21):
+    """The differentiable ResBlock with a res_conv as one autograd node (see _ResBlockRC); arguments as for three conv3d() calls."""
+    b = segs[0].shape[0]
+    metas = ((True, 1, 1.0, 1.0), (True, 1, 1.0, 1.0), (False, 1, 1.0, 1.0))
+    return _ResBlockRC.apply(metas, w20, b20, w21, wrc, brc, _fix_rows(shift, b), _fix_rows(scale, b), mask20, mask21, *segs)
+
+
+def _fix_rows(t, b):
+    # (a column block of a projection bank stays the view it is: the kernels take a row stride; only a table that is not [B, C]
+    #  with unit column stride -- one row broadcast over the batch -- is materialised)
+    if t is None:
+        return None
+    if t.shape[0] != b:
+        t = t.expand(b, t.shape[1])
+    return t if (t.dim() == 2 and t.stride(1) == 1 and t.stride(0) >= t.shape[1]) else t.contiguous()
 
 
 def conv3d(segs, weight, bias=None, bias_scale=1.0, shift=None, scale=None, act=False, mask=None, residual=None,
            groups=1, out_scale=1.0):
     """Differentiable fused convolution; shift / scale are dense [B, Cin] tensors."""
     b = segs[0].shape[0]
-    # (a column block of a projection bank stays the view it is: the kernels take a row stride; only a table that is not [B, C]
-    #  with unit column stride -- one row broadcast over the batch -- is materialised)
-    def fix(t):
-        if t is None:
-            return None
-        if t.shape[0] != b:
-            t = t.expand(b, t.shape[1])
-        return t if (t.dim() == 2 and t.stride(1) == 1 and t.stride(0) >= t.shape[1]) else t.contiguous()
+    fix = lambda t: _fix_rows(t, b)
     return _FusedConv3d.apply((bool(act), int(groups), float(bias_scale), float(out_scale)), weight, bias, fix(shift),
                               fix(scale), residual, mask, *segs)
 

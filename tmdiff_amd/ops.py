@@ -49,6 +49,8 @@ class KernelConfig:
                                                          transform of its output instead of the output (no DWT pass)
     side_xp            TMDIFF_SIDE_XP           True     inference: a ResBlock's res_conv launch (segmented input) also writes conv20's
                                                          prologue output (no prologue pass in front of conv20)
+    train_fused_resblock TMDIFF_TRAIN_FUSED_RESBLOCK True finetune: a ResBlock with a res_conv is ONE autograd node (conv20's input gradients
+                                                         are added to res_conv's by the prologue-backward kernel, not by a sum launch)
     train_graph        TMDIFF_TRAIN_GRAPH       False    (model.DDPM) capture the finetune step into a HIP graph
     train_two_streams  TMDIFF_TRAIN_STREAMS     True     forward_train runs the condition branch on a second stream beside the
                                                          main branch's down path (at a local batch of 8 most launches fill half
@@ -73,6 +75,7 @@ class KernelConfig:
         "wgrad_bias": ("TMDIFF_WGRAD_BIAS", _FLAG(False), False), "wino_multipack": ("TMDIFF_WINO_MULTIPACK", _FLAG(True), True),
         "fuse_res_conv": ("TMDIFF_FUSE_RES_CONV", _FLAG(True), True), "emit_ll": ("TMDIFF_EMIT_LL", _FLAG(True), True),
         "emit_dwt": ("TMDIFF_EMIT_DWT", _FLAG(True), True), "side_xp": ("TMDIFF_SIDE_XP", _FLAG(True), True),
+        "train_fused_resblock": ("TMDIFF_TRAIN_FUSED_RESBLOCK", _FLAG(True), True),
         "train_graph": ("TMDIFF_TRAIN_GRAPH", _FLAG(False), False),
         "train_two_streams": ("TMDIFF_TRAIN_STREAMS", _FLAG(True), True),
     }
