@@ -363,6 +363,12 @@ size_t tmdiff_conv3d_prologue_bwd_workspace_bytes(const tmdiff_conv3d_desc* d);
 int tmdiff_conv3d_prologue_bwd_ws(const tmdiff_conv3d_desc* d, const float* gp, float* const dx_seg[3],
                                   const int32_t accumulate[3], float* d_shift, float* d_scale, void* workspace,
                                   tmdiff_stream_t stream);
+/* Three-operand form: dx_seg[i] = add_seg[i] + dL/dx_i (add_seg[i] == NULL: just dL/dx_i) -- the gradient ANOTHER consumer of the
+ * same segment has produced (a ResBlock's identity residual, Hyper_unet_general.py:248) is read here instead of being summed with
+ * this one by a launch of its own.  add_seg[i] is only read; dx_seg[i] is a tensor of its own. */
+int tmdiff_conv3d_prologue_bwd_add(const tmdiff_conv3d_desc* d, const float* gp, float* const dx_seg[3],
+                                   const float* const add_seg[3], float* d_shift, float* d_scale, void* workspace,
+                                   tmdiff_stream_t stream);
 
 /* ------------------------------------------------------------------------------------
  * Stem / head pointwise convolutions (bandwidth kernels):

@@ -934,6 +934,35 @@ def test_conv3d_wf_writes_the_ll_band_instead_of_y(ops, case, request):
         assert_close(g_, w_.cpu(), 2e-6, 1e-6, f"Haar output {nm} vs the Haar kernel on y")
 
 
+@pytest.mark.parametrize("case", [(2, (32,), (8, 16, 16)), (3, (8, 16, 8), (4, 10, 7)), (8, (32,), (8, 64, 64))])
+def test_prologue_backward_adds_another_gradient(ops, case):
+    """tmdiff_conv3d_prologue_bwd_add: dx_i = add_i + dL/dx_i in one pass (the identity residual's gradient joins conv20's input
+    gradient inside the kernel: tmdiff_amd.autograd._ResBlockId) -- bit for bit the separate sum, the added tensor untouched; the
+    in-place form (accumulate) gives the same."""
+    B, seg_c, shp = case
+    cin = sum(seg_c)
+    torch.manual_seed(cin + B)
+    xs = [torch.randn(B, c, *shp, device="cuda") for c in seg_c]
+    gp = torch.randn(B, cin, *shp, device="cuda")
+    sh, sc = torch.randn(B, cin, device="cuda") * 0.3, torch.rand(B, cin, device="cuda") + 0.5
+    adds = [torch.randn_like(x) for x in xs]
+    keep = [a.clone() for a in adds]
+    d = ops.make_conv_desc(xs, 0, 32, 3, torch.empty(B, 32, *shp, device="cuda"), in_shift=sh, in_scale=sc, in_act=True, drop=(77, 0.2))
+    plain = [torch.empty_like(x) for x in xs]
+    dsh0, dsc0 = ops.conv3d_prologue_bwd(d, gp, plain, [False] * len(xs), True, True)
+    out = [torch.full_like(x, float("nan")) for x in xs]
+    dsh1, dsc1 = ops.conv3d_prologue_bwd(d, gp, out, [False] * len(xs), True, True, add_segs=adds)
+    assert torch.equal(dsh0, dsh1) and torch.equal(dsc0, dsc1)
+    for o, p, a, k in zip(out, plain, adds, keep):
+        assert torch.equal(o, a + p) and torch.equal(a, k)
+    acc = [a.clone() for a in adds]
+    ops.conv3d_prologue_bwd(d, gp, acc, [True] * len(xs), False, False)
+    for o, c in zip(out, acc):
+        assert torch.equal(o, c)
+    with pytest.raises(ValueError):
+        ops.conv3d_prologue_bwd(d, gp, acc, [True] * len(xs), False, False, add_segs=adds)
+
+
 def test_dropout_seed_word_in_device_memory(ops):
     """tmdiff_conv3d_desc.drop_seed_dev (ABI v6): the in-kernel dropout seed is drop_seed + *drop_seed_dev, read when the
     kernel starts -- a launch recorded into a HIP graph draws a fresh mask on every replay once the word is bumped.  The

@@ -139,6 +139,9 @@ class ResBlockModulateBEST(nn.Module):
             m21 = _drop_mask(self, (b, self.conv20.out_channels, n, h, w), self.dropout.p, dev)
             return A.resblock_rc(segs, self.conv20.weight, self.conv20.bias, self.conv21.weight, self.res_conv.weight,
                                  self.res_conv.bias, None if self.flag else shift, scale, m20, m21)
+        if not isinstance(self.res_conv, nn.Conv3d) and len(segs) == 1 and ops.config.train_fused_resblock:
+            m21 = _drop_mask(self, (b, self.conv20.out_channels, n, h, w), self.dropout.p, dev)
+            return A.resblock_id(segs[0], self.conv20.weight, self.conv20.bias, self.conv21.weight, None if self.flag else shift, scale, m20, m21)
         t1 = A.conv3d(segs, self.conv20.weight, self.conv20.bias, shift=None if self.flag else shift, act=True, mask=m20)
         res = A.conv3d(segs, self.res_conv.weight, self.res_conv.bias) if isinstance(self.res_conv, nn.Conv3d) else segs[0]
         return A.conv3d([t1], self.conv21.weight, None, scale=scale, act=True,

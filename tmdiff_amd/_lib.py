@@ -91,6 +91,7 @@ SIGNATURES = {
     "tmdiff_conv3d_prologue_bwd": (C.c_int, [C.POINTER(Conv3dDesc), vp, vp * 3, C.c_int32 * 3, vp, vp, vp]),
     "tmdiff_conv3d_prologue_bwd_workspace_bytes": (C.c_size_t, [C.POINTER(Conv3dDesc)]),
     "tmdiff_conv3d_prologue_bwd_ws": (C.c_int, [C.POINTER(Conv3dDesc), vp, vp * 3, C.c_int32 * 3, vp, vp, vp, vp]),
+    "tmdiff_conv3d_prologue_bwd_add": (C.c_int, [C.POINTER(Conv3dDesc), vp, vp * 3, vp * 3, vp, vp, vp, vp]),
     "tmdiff_stem_bwd": (C.c_int, [vp, vp, vp, vp, vp, vp, vp, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32, vp]),
     "tmdiff_stem_bwd_input": (C.c_int, [vp, vp, vp, vp, vp, vp, vp, vp, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32,
                                         vp]),

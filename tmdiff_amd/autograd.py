@@ -82,9 +82,10 @@ def _conv_forward(meta, weight, bias, shift, scale, residual, mask, segs, need_w
     return y, state
 
 
-def _conv_backward(st, gy, need_w, need_b, need_shift, need_scale, need_res, need_segs, outs=None, accumulate=None):
+def _conv_backward(st, gy, need_w, need_b, need_shift, need_scale, need_res, need_segs, outs=None, accumulate=None, adds=None):
     """Gradients of _conv_forward: (d_w, d_bias, d_shift, d_scale, d_res, d_segs).  outs / accumulate: tensors the input
-    gradients are ADDED to instead of fresh ones (the other consumer's gradient of the same segments: no sum pass afterwards)."""
+    gradients are ADDED to instead of fresh ones (the other consumer's gradient of the same segments: no sum pass afterwards);
+    adds: tensors that are only READ and added into fresh outputs (a gradient that may be shared: the identity residual's)."""
     act, groups, bias_scale, out_scale = st["meta"]
     w, shift, scale, mask, xp, segs = st["w"], st["shift"], st["scale"], st["mask"], st["xp"], st["segs"]
     has_bias, has_shift, has_scale = st["has_bias"], shift is not None, scale is not None
@@ -127,7 +128,8 @@ def _conv_backward(st, gy, need_w, need_b, need_shift, need_scale, need_res, nee
         if outs is None:
             outs = [torch.empty_like(s_) if need_segs[i] else None for i, s_ in enumerate(segs)]
             accumulate = [False] * len(segs)
-        d_shift, d_scale = ops.conv3d_prologue_bwd(desc, gp, outs, accumulate, has_shift and need_shift, has_scale and need_scale)
+        d_shift, d_scale = ops.conv3d_prologue_bwd(desc, gp, outs, accumulate, has_shift and need_shift, has_scale and need_scale,
+                                                   add_segs=adds)
         d_segs = outs
     return d_w, d_bias, d_shift, d_scale, d_res, d_segs
 
@@ -211,6 +213,42 @@ class _ResBlockRC(torch.autograd.Function):
             d_w20, d_b20, d_shift, _, _, d2 = _conv_backward(s20, d_t1, need[1], need[2], need[6], False, False, need_segs)
             d_segs = [a if b_ is None else (b_ if a is None else a + b_) for a, b_ in zip(d_segs, d2)] if any_x else d_segs
         return (None, d_w20, d_b20, d_w21, d_wrc, d_brc, d_shift, d_scale, None, None, *d_segs)
+
+
+class _ResBlockId(torch.autograd.Function):
+    """ResBlockModulateBEST without a res_conv (channel_in == channel_out; reference Hyper_unet_general.py:248: the block's input is
+    the residual) as ONE node: y = conv21(act(t1) * scale * mask21) + x, t1 = conv20(act(x + shift) * mask20) + b20.  In the backward
+    x has two gradients -- the incoming one itself (the residual) and conv20's -- and conv20's prologue backward writes their SUM
+    (three-operand form: the incoming gradient is only read, it may be shared)."""
+
+    @staticmethod
+    def forward(ctx, metas, w20, b20, w21, shift, scale, mask20, mask21, x):
+        m20, m21 = metas
+        need = ctx.needs_input_grad
+        t1, s20 = _conv_forward(m20, w20, b20, shift, None, None, mask20, [x], need[1])
+        y, s21 = _conv_forward(m21, w21, None, None, scale, s20["segs"][0], mask21, [t1], need[3])
+        tensors = []
+        for prefix, st in (("s20", s20), ("s21", s21)):
+            _stash(ctx, prefix, st, tensors)
+        ctx.save_for_backward(*tensors)
+        return y
+
+    @staticmethod
+    def backward(ctx, gy):
+        saved = ctx.saved_tensors
+        s20, s21 = (_unstash(ctx, k, saved) for k in ("s20", "s21"))
+        need = ctx.needs_input_grad  # (metas, w20, b20, w21, shift, scale, mask20, mask21, x)
+        d_w21, _, _, d_scale, d_res, (d_t1,) = _conv_backward(s21, gy, need[3], False, False, need[5], True, [True])
+        d_w20, d_b20, d_shift, _, _, (d_x,) = _conv_backward(s20, d_t1, need[1], need[2], need[4], False, False, [True],
+                                                             adds=[d_res] if need[8] else None)
+        return (None, d_w20, d_b20, d_w21, d_shift, d_scale, None, None, d_x if need[8] else None)
+
+
+def resblock_id(x, w20, b20, w21, shift, scale, mask20, mask21):
+    """The differentiable ResBlock without a res_conv as one autograd node (see _ResBlockId)."""
+    b = x.shape[0]
+    metas = ((True, 1, 1.0, 1.0), (True, 1, 1.0, 1.0))
+    return _ResBlockId.apply(metas, w20, b20, w21, _fix_rows(shift, b), _fix_rows(scale, b), mask20, mask21, x)
 
 
 def resblock_rc(segs, w20, b20, w21, wrc, brc, shift, scale, mask20, mask21):

@@ -453,6 +453,7 @@ struct PrologueBwdArgs {
   const float* seg_x[3];
   float* dx[3];
   int accumulate[3];
+  const float* add[3];     // != NULL: dx = add + (the computed gradient) -- another consumer's gradient of the same segment, read here
   const float* in_shift;
   const float* in_scale;
   int shift_stride, scale_stride;
@@ -483,7 +484,9 @@ __global__ void __launch_bounds__(256) prologue_bwd_kernel(const PrologueBwdArgs
   const float* xs = (seg == 0 ? a.seg_x[0] : (seg == 1 ? a.seg_x[1] : a.seg_x[2])) + ((long)b * segc + cs) * a.plane;
   float* dxs = seg == 0 ? a.dx[0] : (seg == 1 ? a.dx[1] : a.dx[2]);
   const int accum = seg == 0 ? a.accumulate[0] : (seg == 1 ? a.accumulate[1] : a.accumulate[2]);
+  const float* adds = seg == 0 ? a.add[0] : (seg == 1 ? a.add[1] : a.add[2]);
   if (dxs) dxs += ((long)b * segc + cs) * a.plane;
+  if (adds) adds += ((long)b * segc + cs) * a.plane;
   const float* gp = a.gp + ((long)b * a.Cin + c) * a.plane;
   const float* msk = a.in_mask ? a.in_mask + ((long)b * a.Cin + c) * a.plane : nullptr;
   const bool drop = a.drop_inv > 0.f;
@@ -491,7 +494,7 @@ __global__ void __launch_bounds__(256) prologue_bwd_kernel(const PrologueBwdArgs
   const uint64_t ebase = ((uint64_t)b * a.Cin + c) * (uint64_t)a.plane;
   // this slice's element range (multiples of 4 when vectorised)
   const bool vec = (a.plane & 3) == 0 && tmdiff_aligned16_dev(xs) && tmdiff_aligned16_dev(gp) &&
-                   (!dxs || tmdiff_aligned16_dev(dxs)) && (!msk || tmdiff_aligned16_dev(msk));
+                   (!dxs || tmdiff_aligned16_dev(dxs)) && (!msk || tmdiff_aligned16_dev(msk)) && (!adds || tmdiff_aligned16_dev(adds));
   const long unit = vec ? 4 : 1;
   const long units = a.plane / unit;
   const long per = (units + a.slices - 1) / a.slices;
@@ -514,6 +517,7 @@ __global__ void __launch_bounds__(256) prologue_bwd_kernel(const PrologueBwdArgs
       float4 m4 = make_float4(1.f, 1.f, 1.f, 1.f), d4 = make_float4(0.f, 0.f, 0.f, 0.f), o4;
       if (msk) m4 = *reinterpret_cast<const float4*>(msk + i);
       if (dxs && accum) d4 = *reinterpret_cast<const float4*>(dxs + i);
+      else if (dxs && adds) d4 = *reinterpret_cast<const float4*>(adds + i);
       one(x4.x, g4.x, m4.x, i, o4.x);
       one(x4.y, g4.y, m4.y, i + 1, o4.y);
       one(x4.z, g4.z, m4.z, i + 2, o4.z);
@@ -524,7 +528,7 @@ __global__ void __launch_bounds__(256) prologue_bwd_kernel(const PrologueBwdArgs
     for (long i = lo + threadIdx.x; i < hi; i += 256) {
       float o;
       one(xs[i], gp[i], msk ? msk[i] : 1.f, i, o);
-      if (dxs) dxs[i] = accum ? dxs[i] + o : o;
+      if (dxs) dxs[i] = accum ? dxs[i] + o : (adds ? adds[i] + o : o);
     }
   }
   const long oidx = ((long)b * a.Cin + c) * a.slices + sl;
@@ -849,9 +853,31 @@ extern "C" size_t tmdiff_conv3d_prologue_bwd_workspace_bytes(const tmdiff_conv3d
   return s > 1 ? (size_t)2 * d->B * d->Cin * s * sizeof(float) : 0;
 }
 
+namespace {
+int prologue_bwd_impl(const tmdiff_conv3d_desc* d, const float* gp, float* const dx_seg[3], const int32_t accumulate[3],
+                      const float* const add_seg[3], float* d_shift, float* d_scale, void* workspace, tmdiff_stream_t stream);
+}
+
 extern "C" int tmdiff_conv3d_prologue_bwd_ws(const tmdiff_conv3d_desc* d, const float* gp, float* const dx_seg[3],
                                              const int32_t accumulate[3], float* d_shift, float* d_scale, void* workspace,
                                              tmdiff_stream_t stream) {
+  return prologue_bwd_impl(d, gp, dx_seg, accumulate, nullptr, d_shift, d_scale, workspace, stream);
+}
+
+/* Three-operand form: dx_seg[i] = add_seg[i] + dL/dx_i (add_seg[i] == NULL: just dL/dx_i) -- the gradient another consumer of the
+ * same segment has produced (a ResBlock's identity residual, Hyper_unet_general.py:248) is read here instead of being summed with
+ * this one by a launch of its own; add_seg[i] is only read (it may be shared), dx_seg[i] is a tensor of its own. */
+extern "C" int tmdiff_conv3d_prologue_bwd_add(const tmdiff_conv3d_desc* d, const float* gp, float* const dx_seg[3],
+                                              const float* const add_seg[3], float* d_shift, float* d_scale, void* workspace,
+                                              tmdiff_stream_t stream) {
+  static const int32_t none[3] = {0, 0, 0};
+  TMDIFF_REQUIRE(add_seg != nullptr, "prologue_bwd_add: NULL pointer");
+  return prologue_bwd_impl(d, gp, dx_seg, none, add_seg, d_shift, d_scale, workspace, stream);
+}
+
+namespace {
+int prologue_bwd_impl(const tmdiff_conv3d_desc* d, const float* gp, float* const dx_seg[3], const int32_t accumulate[3],
+                      const float* const add_seg[3], float* d_shift, float* d_scale, void* workspace, tmdiff_stream_t stream) {
   using namespace tmdiff;
   TMDIFF_REQUIRE(d && gp && dx_seg && accumulate, "prologue_bwd: NULL pointer");
   TMDIFF_REQUIRE(d->B > 0 && d->Cin > 0 && d->B <= 65535 && d->nseg >= 1 && d->nseg <= 3, "prologue_bwd: bad extents");
@@ -864,6 +890,7 @@ extern "C" int tmdiff_conv3d_prologue_bwd_ws(const tmdiff_conv3d_desc* d, const 
     a.seg_x[i] = i < d->nseg ? d->seg_x[i] : nullptr;
     a.dx[i] = i < d->nseg ? dx_seg[i] : nullptr;
     a.accumulate[i] = i < d->nseg ? accumulate[i] : 0;
+    a.add[i] = (add_seg && i < d->nseg) ? add_seg[i] : nullptr;
     if (i < d->nseg) {
       TMDIFF_REQUIRE(d->seg_x[i] != nullptr, "prologue_bwd: segment %d is NULL", i);
       csum += d->seg_c[i];
@@ -892,6 +919,7 @@ extern "C" int tmdiff_conv3d_prologue_bwd_ws(const tmdiff_conv3d_desc* d, const 
   if (d_scale) rowsum_kernel<<<(unsigned)((planes + 255) / 256), 256, 0, st>>>(a.d_scale, d_scale, planes, a.slices);
   return check_launch("conv3d_prologue_bwd(rowsum)");
 }
+}  // namespace
 
 extern "C" int tmdiff_conv3d_prologue_bwd(const tmdiff_conv3d_desc* d, const float* gp, float* const dx_seg[3],
                                           const int32_t accumulate[3], float* d_shift, float* d_scale,

@@ -1083,7 +1083,10 @@ def channel_sum(x, scale=1.0):
     return out
 
 
-def conv3d_prologue_bwd(desc, gp, dx_segs, accumulate, want_shift, want_scale):
+def conv3d_prologue_bwd(desc, gp, dx_segs, accumulate, want_shift, want_scale, add_segs=None):
+    """dL/dx (per segment, into dx_segs; accumulate[i]: added to what dx_segs[i] holds), dL/dshift, dL/dscale of a convolution's
+    prologue from dL/dx'.  add_segs (then accumulate must be all False): dx_segs[i] = add_segs[i] + dL/dx_i -- another consumer's
+    gradient of the same segment, only read (tmdiff_conv3d_prologue_bwd_add)."""
     b, cin = desc.B, desc.Cin
     d_shift = torch.empty(b, cin, device=gp.device, dtype=torch.float32) if want_shift else None
     d_scale = torch.empty(b, cin, device=gp.device, dtype=torch.float32) if want_scale else None
@@ -1091,6 +1094,13 @@ def conv3d_prologue_bwd(desc, gp, dx_segs, accumulate, want_shift, want_scale):
     acc = (C.c_int32 * 3)(*[1 if a else 0 for a in accumulate], *([0] * (3 - len(accumulate))))
     nws = lib.tmdiff_conv3d_prologue_bwd_workspace_bytes(C.byref(desc))
     ws = _workspace(gp.device, nws, "prologue_bwd").data_ptr() if nws else None
+    if add_segs is not None:
+        if any(accumulate):
+            raise ValueError("conv3d_prologue_bwd: add_segs goes with accumulate all False")
+        addp = (C.c_void_p * 3)(*[_chk(t, "add") for t in add_segs], *([None] * (3 - len(add_segs))))
+        check(lib.tmdiff_conv3d_prologue_bwd_add(C.byref(desc), _chk(gp, "gp"), dxp, addp, _chk(d_shift, "d_shift"),
+                                                 _chk(d_scale, "d_scale"), ws, stream_ptr()), "conv3d_prologue_bwd_add")
+        return d_shift, d_scale
     check(lib.tmdiff_conv3d_prologue_bwd_ws(C.byref(desc), _chk(gp, "gp"), dxp, acc, _chk(d_shift, "d_shift"),
                                             _chk(d_scale, "d_scale"), ws, stream_ptr()), "conv3d_prologue_bwd")
     return d_shift, d_scale
