@@ -133,19 +133,31 @@ __global__ void __launch_bounds__(256) linear_kernel(const float* __restrict__ x
     wr[k] = i < I ? w[(long)o * I + i] : 0.f;
   }
   const float bo = bias ? bias[o] : 0.f;
-  for (int b = 0; b < B; ++b) {
-    float s = 0.f;
+  // four batch rows per iteration: their loads and lane reductions overlap (one row at a time was one L2 round trip + six
+  // dependent shuffles per row: 28 us for 32 rows); every row's sum keeps its order of additions
+  for (int b0 = 0; b0 < B; b0 += 4) {
+    float s[4] = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
     for (int k = 0; k < 16; ++k) {
       const int i = lane + 64 * k;
-      if (i < I) s = fmaf(wr[k], x[(long)b * I + i], s);
+      if (i < I) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+          if (b0 + r < B) s[r] = fmaf(wr[k], x[(long)(b0 + r) * I + i], s[r]);
+      }
     }
 #pragma unroll
-    for (int off = 32; off > 0; off >>= 1) s += __shfl_xor(s, off, 64);
+    for (int off = 32; off > 0; off >>= 1)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) s[r] += __shfl_xor(s[r], off, 64);
     if (lane == 0) {
-      float v = s + bo;
-      if (act) v = tmdiff::silu_f(v);
-      y[(long)b * O + o] = v;
+#pragma unroll
+      for (int r = 0; r < 4; ++r)
+        if (b0 + r < B) {
+          float v = s[r] + bo;
+          if (act) v = tmdiff::silu_f(v);
+          y[(long)(b0 + r) * O + o] = v;
+        }
     }
   }
 }
