@@ -446,3 +446,20 @@ def test_kernel_routing_rules_and_support_queries():
         e = _lib.Conv3dDesc.from_buffer_copy(d)
         setattr(e, field, bad)
         assert L.tmdiff_conv3d_wgrad_wino_supported(C.byref(e)) == 0, field
+
+
+def test_side_prologue_rule_on_the_benchmark_workload():
+    """routing.k1_side_xp (which 1x1x1 launches can also write the prologue output of their input: conv1.hip's 16-byte form on
+    large grids, the channels-over-the-waves form on small ones): the four three-segment res_conv launches of the benchmark
+    workload's up path all qualify -- which is why no prologue pass is left in its step -- and the shapes neither form takes
+    do not."""
+    from tmdiff_amd import routing
+    up_path = [((32, 32, 32), 32, 64, 64), ((64, 64, 64), 32, 32, 32), ((128, 128, 128), 64, 16, 16), ((256, 256, 256), 128, 8, 8)]
+    for seg_c, cout, h, w in up_path:
+        assert routing.k1_side_xp(32, seg_c, cout, 8, h, w), (seg_c, cout, h, w)
+    assert routing.k1_side_xp(1, (256, 256, 256), 128, 8, 8, 8)             # a single tile: still the small-grid form
+    assert not routing.k1_side_xp(1, (32, 32, 32), 32, 8, 8, 8)             # a small grid of fewer than 128 input channels
+    assert not routing.k1_side_xp(32, (32, 24, 40), 32, 8, 64, 64)          # a segment that is not a multiple of 16 channels
+    assert not routing.k1_side_xp(32, (32, 32, 32), 48, 8, 64, 64)          # Cout not a multiple of 32
+    assert not routing.k1_side_xp(32, (32, 32, 32), 32, 3, 7, 9)            # a plane that is not a multiple of 4 positions
+
