@@ -9,7 +9,7 @@ HIPFLAGS := -O3 -std=c++17 -fPIC --offload-arch=$(ARCH) -Iinclude -I$(CSRC) -Wal
 
 all: $(LIB)
 
-build/%.o: $(CSRC)/% include/tmdiff_hip.h $(CSRC)/common.h $(CSRC)/epilogue.h
+build/%.o: $(CSRC)/% include/tmdiff_hip.h $(CSRC)/common.h $(CSRC)/epilogue.h $(CSRC)/bufaddr.h
 	@mkdir -p build
 	$(HIPCC) $(HIPFLAGS) -x hip -c $< -o $@
 

@@ -9,6 +9,11 @@
 //   [ci][co], tmdiff_conv3d_pack_weights) is one 4/8-byte load per lane from L2.
 // A workgroup = 4 waves x (NS x 32 positions) x (MSUB x 32 channels); 16 input channels (8 K-steps) are in flight
 // in registers while the previous 16 are multiplied.  Same accumulation order as the generic kernel.
+// Three forms (conv1_fp32_try picks): the 16-byte kernel (a lane owns four consecutive positions; grids of at least 512 tiles),
+// the dword kernel above (anything else), and -- round 4 -- the dword kernel with the input channels split over the four waves of
+// a workgroup (KS = 4: small planes, where the channel loop was a chain of memory round trips).  The 16-byte and the KS = 4 form
+// can also write act(x + shift) of their input as a by-product (desc.xp_*: the prologue output another convolution of the same
+// input wants), stored through a buffer descriptor.
 #include <cstdlib>
 
 #include "common.h"

@@ -23,6 +23,7 @@
 #include <cstdint>
 #include <type_traits>
 
+#include "bufaddr.h"
 #include "common.h"
 
 // Experiment switches of the packed-input kernel (tools/build_variant.sh; every one of them gives wrong results):
@@ -210,33 +211,41 @@ __device__ __forceinline__ void store_tile(const BfArgs& a, f32x16 (&acc)[NS][MS
 // output is wanted on top of a residual the finished values make the trip back (ds_write_b128 / ds_read_b32) into the D
 // layout, which is what the packed bf16 units want (one position, 8 channels per lane).  LDS traffic of one wave is
 // processed in order, so the tile needs no barrier, only the compiler kept from reordering (wavefront fence).
-template <int NS, int MSUB, int TW, bool Y, bool RES, bool Y2, bool FULL>
+// Every tensor is addressed through a buffer descriptor over this tile's channels of sample b (bufaddr.h): a lane outside the
+// image carries an offset outside the descriptor, ragged tiles run the code of full ones, no store sits under a branch.
+template <int NS, int MSUB, int TW, bool Y, bool RES, bool Y2>
 __device__ __forceinline__ void store_tile_v(const BfArgs& a, f32x16 (&acc)[NS][MSUB], const float (&bias_v)[MSUB],
                                              const float (&sh2_v)[MSUB], const float (&sc2_v)[MSUB], int b, int g, int co0,
                                              int n0, int h0, int w0, int wv, int l31, int kg, long plane, float* T) {
+  namespace bf = tmdiff::buf;
   constexpr int per_row = TW / 8;
   const int lane = l31 + 32 * kg, tq = lane & 7, tc = lane >> 3;
   const int n = n0 + wv;
-  int toff[NS], poff[NS];      // offsets inside a channel plane: the transposed lane's quad, the D-layout lane's position
-  bool tok[NS], pok[NS];
+  // descriptors: MSUB x 32 channels of sample b from channel g * cout_g + co0 on (fp32 tensors); the packed second output:
+  // their MSUB x 4 units of 8 channels, 16 bytes per (unit, position)
+  const long cb = ((long)b * a.Cout + g * a.cout_g + co0) * plane;
+  const unsigned span = (unsigned)((long)MSUB * 32 * plane * 4);
+  const bf::rsrc ry = bf::make(a.y ? a.y + cb : nullptr, a.y ? span : 0u);
+  const bf::rsrc rr = bf::make(a.residual ? a.residual + cb : nullptr, a.residual ? span : 0u);
+  const bf::rsrc r2 = bf::make(a.y2 ? a.y2 + ((long)b * (a.Cout / 8) + (g * a.cout_g + co0) / 8) * plane : nullptr,
+                               a.y2 ? (unsigned)((long)MSUB * 4 * plane * 16) : 0u);
+  unsigned toff[NS], poff[NS];      // byte offsets: the transposed lane's quad of channel tc, the D-layout lane's position of unit kg
 #pragma unroll
   for (int s = 0; s < NS; ++s) {
     const int hs = h0 + (s / per_row) * 4, ws = w0 + (s % per_row) * 8;
     const int ht = hs + (tq >> 1), wt = ws + (tq & 1) * 4;      // (W % 4 == 0: the four positions stand or fall together)
     const int h = hs + (l31 >> 3), w = ws + (l31 & 7);
-    tok[s] = FULL || (n < a.N && ht < a.H && wt < a.W);
-    pok[s] = FULL || (n < a.N && h < a.H && w < a.W);
-    toff[s] = tok[s] ? (n * a.H + ht) * a.W + wt : 0;
-    poff[s] = pok[s] ? (n * a.H + h) * a.W + w : 0;
+    const bool tok = n < a.N && ht < a.H && wt < a.W, pok = n < a.N && h < a.H && w < a.W;
+    toff[s] = tok ? (unsigned)((tc * (int)plane + (n * a.H + ht) * a.W + wt) * 4) : bf::kOutside;
+    poff[s] = pok ? (unsigned)((kg * (int)plane + (n * a.H + h) * a.W + w) * 16) : bf::kOutside;
   }
-  const long cbase = ((long)b * a.Cout + g * a.cout_g + co0 + tc) * plane;
   // residual quads of sub-tile (s, m): requested one sub-tile ahead of their use
   float4 rs[NS * MSUB + 1][4];
   auto load_res = [&](int i) __attribute__((always_inline)) {
     const int m = i / NS, s = i % NS;
 #pragma unroll
-    for (int j = 0; j < 4; ++j)   // (outside the image: a valid address, the value is never stored)
-      rs[i][j] = *reinterpret_cast<const float4*>(a.residual + cbase + (long)(m * 32 + 8 * j) * plane + toff[s]);
+    for (int j = 0; j < 4; ++j)   // (outside the image: zero, never stored)
+      rs[i][j] = bf::load4(rr, bf::at(toff[s], (unsigned)(m * 32 + 8 * j) * (unsigned)plane * 4u));
   };
   if constexpr (RES) load_res(0);
 #pragma unroll
@@ -264,10 +273,7 @@ __device__ __forceinline__ void store_tile_v(const BfArgs& a, f32x16 (&acc)[NS][
             t.x += q.x, t.y += q.y, t.z += q.z, t.w += q.w;
           }
           t.x *= a.out_scale, t.y *= a.out_scale, t.z *= a.out_scale, t.w *= a.out_scale;
-          if constexpr (Y) {
-            float4* dst = reinterpret_cast<float4*>(a.y + cbase + (long)(m * 32 + 8 * j) * plane + toff[s]);
-            if (FULL || tok[s]) *dst = t;
-          }
+          if constexpr (Y) bf::store4(ry, bf::at(toff[s], (unsigned)(m * 32 + 8 * j) * (unsigned)plane * 4u), t);
           if constexpr (Y2 && RES) *reinterpret_cast<float4*>(T + (tc + 8 * j) * 32 + tq * 4) = t;
         }
         __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
@@ -283,19 +289,20 @@ __device__ __forceinline__ void store_tile_v(const BfArgs& a, f32x16 (&acc)[NS][
         }
         uint4 lo, hi;
         second_output_units(acc[s][m], sh2_r, sc2_r, a.y2_act != 0, lo, hi);
-        uint4* dst = a.y2 + ((long)b * (a.Cout / 8) + (g * a.cout_g + co0 + m * 32) / 8 + kg) * plane + poff[s];
-        if (FULL || pok[s]) dst[0] = lo, dst[2 * plane] = hi;
+        const unsigned o2 = bf::at(poff[s], (unsigned)(m * 4) * (unsigned)plane * 16u);
+        bf::store4(r2, o2, lo);
+        bf::store4(r2, bf::at(o2, 2u * (unsigned)plane * 16u), hi);
       }
     }
   }
 }
 
-template <int NS, int MSUB, int TW, bool FULL>
+template <int NS, int MSUB, int TW>
 __device__ __forceinline__ void store_tile_vec(const BfArgs& a, f32x16 (&acc)[NS][MSUB], const float (&bias_v)[MSUB],
                                                const float (&sh2_v)[MSUB], const float (&sc2_v)[MSUB], int b, int g, int co0,
                                                int n0, int h0, int w0, int wv, int l31, int kg, long plane, float* T) {
 #define TMDIFF_EPI(Y, R, Y2) \
-  store_tile_v<NS, MSUB, TW, Y, R, Y2, FULL>(a, acc, bias_v, sh2_v, sc2_v, b, g, co0, n0, h0, w0, wv, l31, kg, plane, T)
+  store_tile_v<NS, MSUB, TW, Y, R, Y2>(a, acc, bias_v, sh2_v, sc2_v, b, g, co0, n0, h0, w0, wv, l31, kg, plane, T)
   if (a.y) {
     if (a.residual) { if (a.y2) TMDIFF_EPI(true, true, true); else TMDIFF_EPI(true, true, false); }
     else            { if (a.y2) TMDIFF_EPI(true, false, true); else TMDIFF_EPI(true, false, false); }
@@ -717,10 +724,8 @@ __global__ void __launch_bounds__(256, 2) conv3d_bf16_dma_kernel(const BfArgs a,
   float* const T = reinterpret_cast<float*>(st0) + wv * 1024;
   if (!a.vec4)
     store_tile<NS, MSUB, TW>(a, acc, bias_v, sh2_v, sc2_v, b, g, co0, n0, h0, w0, wv, l31, kg, plane);
-  else if (n0 + TN <= a.N && h0 + TH <= a.H && w0 + TW <= a.W)
-    store_tile_vec<NS, MSUB, TW, true>(a, acc, bias_v, sh2_v, sc2_v, b, g, co0, n0, h0, w0, wv, l31, kg, plane, T);
   else
-    store_tile_vec<NS, MSUB, TW, false>(a, acc, bias_v, sh2_v, sc2_v, b, g, co0, n0, h0, w0, wv, l31, kg, plane, T);
+    store_tile_vec<NS, MSUB, TW>(a, acc, bias_v, sh2_v, sc2_v, b, g, co0, n0, h0, w0, wv, l31, kg, plane, T);
 #if TMDIFF_BF16_STAMPS
   __builtin_amdgcn_s_waitcnt(0x0F70);     // (stores issued and acknowledged)
   STAMP_PHASE(4);
@@ -1003,7 +1008,8 @@ extern "C" int tmdiff_conv3d_fwd_bf16(const tmdiff_conv3d_desc* d, void* workspa
   a.y2 = reinterpret_cast<uint4*>(d->y2); a.y2_shift = d->y2_shift; a.y2_scale = d->y2_scale; a.y2_act = d->y2_act;
   a.y2_shift_stride = d->y2_shift_stride > 0 ? d->y2_shift_stride : (d->y2_shift_stride < 0 ? 0 : d->Cout);
   a.y2_scale_stride = d->y2_scale_stride > 0 ? d->y2_scale_stride : (d->y2_scale_stride < 0 ? 0 : d->Cout);
-  a.vec4 = d->W % 4 == 0 && (!d->y || aligned16(d->y)) && (!d->residual || aligned16(d->residual));
+  // (the dwordx4 epilogue addresses its tensors through descriptors of 32-bit offsets: planes of at most 2^24 positions)
+  a.vec4 = d->W % 4 == 0 && (!d->y || aligned16(d->y)) && (!d->residual || aligned16(d->residual)) && (long)d->N * d->H * d->W <= (1L << 24);
   a.stamps = TMDIFF_BF16_STAMPS ? static_cast<unsigned long long*>(d->splitk_ws) : nullptr;
   hipStream_t st = as_stream(stream);
   if (d->x_bf16) {  // input already packed by its producer: straight to the staging-free kernel
