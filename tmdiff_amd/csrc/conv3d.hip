@@ -649,7 +649,9 @@ bool epilogue_vec_ok(const tmdiff_conv3d_desc* d) {
     const char* e = getenv("TMDIFF_EPILOGUE_VEC");   // experiments: "0" = the scalar epilogue everywhere
     return !(e && e[0] == '0');
   }();
-  return on && d->W % 4 == 0 && aligned16(d->y) && aligned16(d->residual) && (d->y2_bf16 || aligned16(d->y2));
+  // (the dwordx4 epilogue addresses up to 128 channels of a sample through one descriptor of 32-bit offsets: planes <= 2^23)
+  return on && d->W % 4 == 0 && aligned16(d->y) && aligned16(d->residual) && (d->y2_bf16 || aligned16(d->y2)) &&
+         (long)d->N * d->H * d->W <= (1L << 23);
 }
 
 Conv3Plan plan_conv3(const tmdiff_conv3d_desc* d) {

@@ -409,7 +409,7 @@ extern "C" int tmdiff_conv3d_ll_fwd(const tmdiff_conv3d_desc* d, float ll_scale,
     const char* e = getenv("TMDIFF_EPILOGUE_VEC");
     return !(e && e[0] == '0');
   }();
-  a.vec4 = vec_on && a.W % 4 == 0 && aligned16(d->y) && aligned16(d->y2) && aligned16(d->residual);
+  a.vec4 = vec_on && a.W % 4 == 0 && aligned16(d->y) && aligned16(d->y2) && aligned16(d->residual) && (long)a.N * a.H * a.W <= (1L << 23);
   hipStream_t st = as_stream(stream);
   const LlPlan plan = plan_ll(d);
   a.ksplit = 1; a.split_chunks = a.Cin / 2; a.part = nullptr;

@@ -694,8 +694,8 @@ extern "C" int tmdiff_conv3d_wino_fwd_planes(const tmdiff_conv3d_desc* d, void* 
   a.y2_scale_stride = d->y2_scale_stride > 0 ? d->y2_scale_stride : (d->y2_scale_stride < 0 ? 0 : d->Cout);
   a.vec4 = 1;
   a.stamps = TMDIFF_WINO_STAMPS ? static_cast<unsigned long long*>(d->splitk_ws) : nullptr;
-  if (!(d->W % 4 == 0 && aligned16(d->y) && aligned16(d->y2) && aligned16(d->residual)))
-    return fail(TMDIFF_E_UNSUPPORTED, "conv3d_wino_fwd: W %% 4 == 0 and 16-byte aligned outputs / residual");
+  if (!(d->W % 4 == 0 && aligned16(d->y) && aligned16(d->y2) && aligned16(d->residual) && (long)d->N * d->H * d->W <= (1L << 23)))
+    return fail(TMDIFF_E_UNSUPPORTED, "conv3d_wino_fwd: W %% 4 == 0, 16-byte aligned outputs / residual, planes of at most 2^23 positions");
   if (np == 6) {
     if (a.cout_g % 64 == 0) return launch<2, 2, 2, 2, 8, 8, 6>(a, st);
     return launch<4, 1, 2, 2, 8, 16, 6>(a, st);

@@ -14,6 +14,7 @@
 // the same bits.  The LDS traffic of one wave is processed in order: no barrier, only the compiler kept from reordering.
 // Needs W % 4 == 0 and 16-byte aligned y / y2 / residual (Args::vec4, set by the entry points).
 #pragma once
+#include "bufaddr.h"
 #include "common.h"
 
 namespace tmdiff {
@@ -22,33 +23,40 @@ __device__ __forceinline__ float lane_value(float v, int src_lane) {
   return __int_as_float(__builtin_amdgcn_ds_bpermute(src_lane * 4, __float_as_int(v)));
 }
 
+// Every tensor is addressed through a buffer descriptor over this tile's MSUB x 32 channels of sample b (bufaddr.h): a lane's
+// address is one 32-bit byte offset, a lane outside the image carries an offset outside the descriptor -- ragged tiles run the
+// code of full ones and no store sits under a branch.  Needs planes of at most 2^23 positions (epilogue_vec_ok).
 // xxx_v[m]: per-lane vectors, lane l (and l + 32) holds the value of channel co0 + m*32 + (l & 31).
-template <int NS, int MSUB, int TH, int TW, bool Y, bool RES, bool Y2, bool FULL, class Args, class Acc>
+template <int NS, int MSUB, int TH, int TW, bool Y, bool RES, bool Y2, class Args, class Acc>
 __device__ __forceinline__ void epilogue_vec_v(const Args& a, Acc (&acc)[NS][MSUB], const float (&bias_v)[MSUB],
                                                const float (&sh2_v)[MSUB], const float (&sc2_v)[MSUB], int b, int g, int co0,
                                                int n0, int h0, int w0, int wv, int lane, long plane, float* T,
                                                const int* sub_base = nullptr) {
+#pragma clang fp contract(off)   // (every instantiation rounds alike: without y the compiler would fuse "* scale" and "+ shift")
   // sub_base[s]: linear index (over the TN x TH x TW output tile, w fastest) of the first position of sub-tile s; by
   // default the waves' sub-tiles follow one another ((wv * NS + s) * 32)
   static_assert(TW % 4 == 0, "a quad of positions lies in one row");
   const int l31 = lane & 31, khalf = lane >> 5, tq = lane & 7, tc = lane >> 3;
-  int toff[NS];
-  bool tok[NS];
+  const long cb = ((long)b * a.Cout + g * a.cout_g + co0) * plane;
+  const unsigned span = (unsigned)((long)MSUB * 32 * plane * 4);
+  const buf::rsrc ry = buf::make(a.y ? a.y + cb : nullptr, a.y ? span : 0u);
+  const buf::rsrc rr = buf::make(a.residual ? a.residual + cb : nullptr, a.residual ? span : 0u);
+  const buf::rsrc r2 = buf::make(a.y2 ? a.y2 + cb : nullptr, a.y2 ? span : 0u);
+  unsigned toff[NS];      // byte offset of the lane's quad of channel tc inside the descriptor
 #pragma unroll
   for (int s = 0; s < NS; ++s) {
     const int p = (sub_base ? sub_base[s] : (wv * NS + s) * 32) + 4 * tq;
     const int n = n0 + p / (TW * TH), h = h0 + (p / TW) % TH, w = w0 + p % TW;
-    tok[s] = FULL || (n < a.N && h < a.H && w < a.W);      // (W % 4 == 0: the four positions stand or fall together)
-    toff[s] = tok[s] ? (n * a.H + h) * a.W + w : 0;
+    const bool ok = n < a.N && h < a.H && w < a.W;      // (W % 4 == 0: the four positions stand or fall together)
+    toff[s] = ok ? (unsigned)((tc * (int)plane + (n * a.H + h) * a.W + w) * 4) : buf::kOutside;
   }
-  const long cbase = ((long)b * a.Cout + g * a.cout_g + co0 + tc) * plane;
   // residual quads of sub-tile (s, m): requested one sub-tile ahead of their use
   float4 rs[NS * MSUB + 1][4];
   auto load_res = [&](int i) __attribute__((always_inline)) {
     const int m = i / NS, s = i % NS;
 #pragma unroll
-    for (int j = 0; j < 4; ++j)   // (outside the image: a valid address, the value is never stored)
-      rs[i][j] = *reinterpret_cast<const float4*>(a.residual + cbase + (long)(m * 32 + 8 * j) * plane + toff[s]);
+    for (int j = 0; j < 4; ++j)   // (outside the image: zero, never stored)
+      rs[i][j] = buf::load4(rr, buf::at(toff[s], (unsigned)(m * 32 + 8 * j) * (unsigned)plane * 4u));
   };
   if constexpr (RES) load_res(0);
 #pragma unroll
@@ -75,10 +83,8 @@ __device__ __forceinline__ void epilogue_vec_v(const Args& a, Acc (&acc)[NS][MSU
         if constexpr (RES) q[0] = rs[m * NS + s][j].x, q[1] = rs[m * NS + s][j].y, q[2] = rs[m * NS + s][j].z, q[3] = rs[m * NS + s][j].w;
 #pragma unroll
         for (int e = 0; e < 4; ++e) v[e] = (v[e] + bias_t[j] + q[e]) * a.out_scale;   // as the scalar epilogue
-        const long o = cbase + (long)(m * 32 + 8 * j) * plane + toff[s];
-        if constexpr (Y) {
-          if (FULL || tok[s]) *reinterpret_cast<float4*>(a.y + o) = make_float4(v[0], v[1], v[2], v[3]);
-        }
+        const unsigned o = buf::at(toff[s], (unsigned)(m * 32 + 8 * j) * (unsigned)plane * 4u);
+        if constexpr (Y) buf::store4(ry, o, make_float4(v[0], v[1], v[2], v[3]));
         if constexpr (Y2) {
           float u[4];
 #pragma unroll
@@ -87,7 +93,7 @@ __device__ __forceinline__ void epilogue_vec_v(const Args& a, Acc (&acc)[NS][MSU
             const float xa = silu_f(x);
             u[e] = (a.y2_act ? xa : x) * sc2_t[j];
           }
-          if (FULL || tok[s]) *reinterpret_cast<float4*>(a.y2 + o) = make_float4(u[0], u[1], u[2], u[3]);
+          buf::store4(r2, o, make_float4(u[0], u[1], u[2], u[3]));
         }
       }
       __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
@@ -95,18 +101,14 @@ __device__ __forceinline__ void epilogue_vec_v(const Args& a, Acc (&acc)[NS][MSU
   }
 }
 
-// Dispatch on what is read and written (wave-uniform) and on the tile lying wholly inside the image.
+// Dispatch on what is read and written (wave-uniform).
 template <int NS, int MSUB, int TN, int TH, int TW, class Args, class Acc>
 __device__ __forceinline__ void epilogue_vec(const Args& a, Acc (&acc)[NS][MSUB], const float (&bias_v)[MSUB],
                                              const float (&sh2_v)[MSUB], const float (&sc2_v)[MSUB], int b, int g, int co0,
                                              int n0, int h0, int w0, int wv, int lane, long plane, float* T,
                                              const int* sub_base = nullptr) {
-  const bool full = n0 + TN <= a.N && h0 + TH <= a.H && w0 + TW <= a.W;
-#define TMDIFF_EPI(Y, R, Y2)                                                                                               \
-  do {                                                                                                                     \
-    if (full) epilogue_vec_v<NS, MSUB, TH, TW, Y, R, Y2, true>(a, acc, bias_v, sh2_v, sc2_v, b, g, co0, n0, h0, w0, wv, lane, plane, T, sub_base);  \
-    else epilogue_vec_v<NS, MSUB, TH, TW, Y, R, Y2, false>(a, acc, bias_v, sh2_v, sc2_v, b, g, co0, n0, h0, w0, wv, lane, plane, T, sub_base);     \
-  } while (0)
+#define TMDIFF_EPI(Y, R, Y2) \
+  epilogue_vec_v<NS, MSUB, TH, TW, Y, R, Y2>(a, acc, bias_v, sh2_v, sc2_v, b, g, co0, n0, h0, w0, wv, lane, plane, T, sub_base)
   if (a.y) {
     if (a.residual) { if (a.y2) TMDIFF_EPI(true, true, true); else TMDIFF_EPI(true, true, false); }
     else            { if (a.y2) TMDIFF_EPI(true, false, true); else TMDIFF_EPI(true, false, false); }
